@@ -1,0 +1,155 @@
+"""Pin the CPU oracle (oracle/lerf_oracle.py) to vectors produced by the
+reference itself (tests/golden/gen_golden.py).  CPU-only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import DATA, GOLDEN
+
+G1_INPUTS = ["noise24x20", "noise33x47", "baby64", "tiny5x6", "extremes8x8"]
+
+
+@pytest.mark.parametrize("name", G1_INPUTS)
+@pytest.mark.parametrize("model", ["lerf-g", "lerf-l"])
+def test_lut_stages_bit_exact(oracle, golden, luts_g, luts_l, model, name):
+    g = golden("g1_lut_stages.npz")
+    luts, oC = (luts_g, 3) if model == "lerf-g" else (luts_l, 1)
+    img = g["%s/%s/img" % (model, name)]
+    feat, hq = oracle.lut_stages(img, luts, oC)
+    assert np.array_equal(feat, g["%s/%s/feat" % (model, name)])
+    assert np.array_equal(hq, g["%s/%s/hq" % (model, name)])
+
+
+def test_single_lut_passes_bit_exact(oracle, golden, luts_g):
+    """per-(mode, rotation) raw numerators (x16) == FourSimplexInterpFaster output x16."""
+    g = golden("g1_lut_stages.npz")
+    img = g["lerf-g/noise24x20/img"]
+    feat = g["lerf-g/noise24x20/feat"]
+    for mode in "sct":
+        for r in range(4):
+            got = oracle.lut_interp_numer(luts_g["s1_%sr0" % mode], img, mode, r)
+            assert np.array_equal(got, g["lerf-g/noise24x20/raw/s1_%s_r%d" % (mode, r)].astype(np.int32))
+            got = oracle.lut_interp_numer(luts_g["s2_%sr%d" % (mode, r & 1)], feat, mode, r)
+            assert np.array_equal(got, g["lerf-g/noise24x20/raw/s2_%s_r%d" % (mode, r)].astype(np.int32))
+
+
+def test_unknown_mode_raises(oracle, luts_g):
+    with pytest.raises(ValueError, match="not implemented"):
+        oracle.lut_interp_numer(luts_g["s1_sr0"], np.zeros((4, 4, 3), np.uint8), "q", 0)
+
+
+@pytest.mark.parametrize("ci", range(8))
+def test_sr_geometry_tables(oracle, golden, ci):
+    g = golden("g23_sr.npz")
+    H, W, sh, sw, S = g["gauss/%d/cfg" % ci]
+    H, W, S = int(H), int(W), int(S)
+    oH, oW = oracle.out_size(H, sh), oracle.out_size(W, sw)
+    lx, dx, plx, phx = oracle.sr_axis_tables(H, oH, sh, S)
+    ly, dy, ply, phy = oracle.sr_axis_tables(W, oW, sw, S)
+    assert [plx, phx, ply, phy] == list(g["gauss/%d/pad" % ci])
+    # reference fov is in padded coordinates: left + pad + ordinal
+    assert np.array_equal(lx[:, None] + plx + np.arange(S)[None], g["gauss/%d/fovx" % ci])
+    assert np.array_equal(ly[:, None] + ply + np.arange(S)[None], g["gauss/%d/fovy" % ci])
+    assert np.array_equal(dx, g["gauss/%d/disx" % ci])      # bit-equal float64
+    assert np.array_equal(dy, g["gauss/%d/disy" % ci])
+
+
+@pytest.mark.parametrize("ci", range(8))
+def test_sr_gauss_float64(oracle, golden, ci):
+    g = golden("g23_sr.npz")
+    H, W, sh, sw, S = g["gauss/%d/cfg" % ci]
+    feat = g["gauss/%d/feat" % ci].astype(np.float32)
+    h = g["gauss/%d/hq" % ci].astype(np.float32) / np.float32(255)
+    out = oracle.resize_params_f32(feat, h[0], h[1], h[2], sh, sw, int(S), 10, "gauss")
+    ref = g["gauss/%d/out" % ci]
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) <= 1e-9
+
+
+@pytest.mark.parametrize("ci", [0, 2, 3, 4, 5, 6])
+def test_sr_linear_float64(oracle, golden, ci):
+    g = golden("g23_sr.npz")
+    H, W, sh, sw, S = g["gauss/%d/cfg" % ci]
+    feat = g["gauss/%d/feat" % ci].astype(np.float32)
+    h = g["gauss/%d/hq" % ci].astype(np.float32) / np.float32(255)
+    out = oracle.resize_params_f32(feat, h[0], None, None, sh, sw, 2, 1, "linear")
+    ref = g["linear/%d/out" % ci]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_warp_float64(oracle, golden, p):
+    g = golden("g4_warp.npz")
+    M = g["%s/matrix" % p]
+    feat = g["%s/feat" % p].astype(np.float32)
+    h = g["%s/hq" % p].astype(np.float32) / np.float32(255)
+    for S in (2, 4):
+        geo = oracle.warp_geometry(M, feat.shape[1:], (60, 70), S)
+        assert list(geo["pad"]) == list(g["%s/60x70/S%d/pad" % (p, S)])
+        out = oracle.warp_params_f32(feat, h[0], h[1], h[2], M, (60, 70), S, 10, "gauss")
+        np.testing.assert_allclose(out, g["%s/60x70/S%d/gauss" % (p, S)], rtol=0, atol=1e-9, equal_nan=True)
+    out = oracle.warp_params_f32(feat, h[0], None, None, M, (60, 70), 2, 1, "linear")
+    np.testing.assert_allclose(out, g["%s/60x70/linear" % p], rtol=0, atol=1e-9, equal_nan=True)
+    out = oracle.warp_params_f32(g["%s/feat" % p].astype(np.float32) * 0 + 7, None, None, None, M, (60, 70), 1, 1, "nearest")
+    assert np.array_equal(np.isnan(out), np.isnan(g["%s/60x70/nearest" % p]))
+    for hw in ((60, 70), (344, 228)):
+        m = oracle.warp_mask(feat.shape[1:], M, hw)
+        assert np.array_equal(m.transpose(2, 0, 1), g["%s/%dx%d/mask" % (p, hw[0], hw[1])])
+    out = oracle.warp_params_f32(feat, h[0], h[1], h[2], M, (344, 228), 2, 10, "gauss")
+    np.testing.assert_allclose(out, g["%s/344x228/S2/gauss_f32" % p], rtol=1e-6, atol=1e-4, equal_nan=True)
+
+
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+SET5 = ["baby", "bird", "butterfly", "head", "woman"]
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+@pytest.mark.parametrize("model", ["lerf-g", "lerf-l"])
+def test_set5_sr_known_answers(oracle, luts_g, luts_l, model, scale):
+    """md5 of the reference's uint8 outputs + the scripts.sh PSNR table."""
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["sr"]
+    luts, linear = (luts_g, False) if model == "lerf-g" else (luts_l, True)
+    published = {"lerf-g": {2: 35.71, 3: 32.02, 4: 30.15}, "lerf-l": {2: 34.84, 3: 30.72, 4: 29.13}}
+    names = SET5 if scale == 2 else ["butterfly", "woman"]     # keep the CPU suite short
+    ps = []
+    for n in names:
+        lr = np.array(Image.open(os.path.join(DATA, "LR_bicubic/rrLR_X%.2f_%.2f" % (scale, scale), n + ".png")))
+        gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+        feat, hq, out, o8 = oracle.sr_pipeline(lr, luts, scale, scale, linear=linear, return_all=True)
+        r = ref["%s/x%d/%s" % (model, scale, n)]
+        assert _md5(feat) == r["md5_feat"]
+        assert _md5(np.transpose(hq, (2, 3, 0, 1))) == r["md5_hq"]      # reference layout [C*oC,H,W]
+        assert _md5(o8) == r["md5_out"]
+        p = oracle.psnr_y(gt, o8, scale)
+        assert abs(p - r["psnr_y"]) < 1e-4
+        ps.append(p)
+    if scale == 2:
+        assert "%.2f" % np.mean(ps) == "%.2f" % published[model][scale]
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_set5_warp_known_answers(oracle, luts_g, p):
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["warp"]
+    published = {"isc": 33.81, "osc": 27.89}
+    ms = []
+    for n in SET5:
+        r = ref["lerf-g/%s/%s" % (p, n)]
+        lr = np.array(Image.open(os.path.join(DATA, "warp", p, n + ".png")))
+        gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+        M = np.array(r["matrix"])
+        o8 = oracle.warp_pipeline(lr, luts_g, M, gt.shape[:2])
+        mask = oracle.warp_mask(lr.shape[:2], M, gt.shape[:2])
+        assert int(mask.sum()) == r["mask_sum"]
+        assert _md5(mask.astype(np.uint8)) == r["md5_mask"]
+        assert _md5(o8 * mask) == r["md5_out_masked"]
+        m = oracle.mpsnr(o8, gt, mask)
+        assert abs(m - r["mpsnr"]) < 1e-3
+        ms.append(m)
+    assert "%.2f" % np.mean(ms) == "%.2f" % published[p]
