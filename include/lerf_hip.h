@@ -1,0 +1,188 @@
+/*
+ * lerf_hip.h -- C ABI of liblerf_hip.so: the MI355X (gfx950) implementation of
+ * the LeRF LUT resampling hot path.
+ *
+ * The reference (ddlee-cn/LeRF-PyTorch) is pure Python and has no FFI; the
+ * boundary a replacement has to offer is its Python class/function API
+ * (SURVEY.md section 8b).  This header is what the Python mirror of that API
+ * (the lerf-pytorch_amd Python package) binds through ctypes.  Every entry point cites the
+ * reference code it replaces (paths relative to the upstream repository).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in the signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = default stream);
+ *   - every function returns 0 on success or a negative LERF_E* code -- no
+ *     exceptions cross the ABI, nothing is allocated, there is no global
+ *     state; the caller owns every buffer, LUT buffers are borrowed read-only;
+ *   - device entry points only enqueue work on `stream`; they never
+ *     synchronise with the host;
+ *   - re-entrant: concurrency = different streams.
+ *   - image operands are described by a base pointer plus ELEMENT strides
+ *     (sy, sx, sc) so that HWC-interleaved uint8 frames and planar CHW float
+ *     tensors go through the same kernels.
+ */
+#ifndef LERF_HIP_H
+#define LERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LERF_ABI_VERSION 1
+#define LERF_MAX_MODES 5          /* s, c, t, d, y  (resample/eval_lut_sr.py:12-18) */
+#define LERF_LUT_ENTRIES 83521    /* 17^4, interval = 4 (resample/eval_lut_sr.py:27-28) */
+#define LERF_MAX_SUPPORT 8
+
+enum {
+    LERF_OK = 0,
+    LERF_EINVAL = -1,        /* bad argument (null pointer, size <= 0, unknown mode ...) */
+    LERF_EUNSUPPORTED = -2,  /* valid request this build has no kernel for */
+    LERF_ELAUNCH = -3,       /* HIP reported a launch error */
+    LERF_ENODEVICE = -4      /* no usable gfx950 device */
+};
+
+enum { LERF_U8 = 0, LERF_F32 = 1, LERF_F64 = 2, LERF_I16 = 3 };
+enum { LERF_KIND_GAUSS = 0, LERF_KIND_LINEAR = 1, LERF_KIND_NEAREST = 2 };
+
+typedef struct {
+    const void* ptr;      /* device pointer */
+    int dtype;            /* LERF_U8 / LERF_F32 / LERF_F64 */
+    int64_t sy, sx, sc;   /* element strides of row, column, channel */
+} lerf_plane_t;
+
+typedef struct {
+    void* ptr;
+    int dtype;
+    int64_t sy, sx, sc;
+} lerf_mplane_t;
+
+/* The LUT set of one model, as the reference loads it
+ * (resample/eval_lut_sr.py:750-775): int8, C order [17^4][oC]. */
+typedef struct {
+    int n_modes1;                               /* len(opt.modes)  */
+    int n_modes2;                               /* len(opt.modes2) */
+    char modes1[LERF_MAX_MODES];                /* e.g. 's','c','t' */
+    char modes2[LERF_MAX_MODES];
+    int oC;                                     /* 3 = LeRF-G (rho, sigma_x, sigma_y), 1 = LeRF-L (alpha) */
+    const int8_t* s1[LERF_MAX_MODES];           /* device, [17^4]      LUT_s1_<mode>r0 */
+    const int8_t* s2[LERF_MAX_MODES][2];        /* device, [17^4][oC]  LUT_s2_<mode>r{0,1} */
+    const uint32_t* s2_packed[LERF_MAX_MODES][2];  /* optional (may be NULL): lerf_lut_pack_s2 output */
+} lerf_luts_t;
+
+/* Separable SR geometry: the 1-D content of Resize2dNumpy.get_distance's dense
+ * maps (resize_right/resize_right2d_numpy.py:106-140); build with
+ * lerf_sr_axis_tables and upload. */
+typedef struct {
+    int S;                   /* support size (2 in every published result, 4 = class default) */
+    int out_h, out_w;
+    const int32_t* left_r;   /* device [out_h]    first source row of the support (unpadded coords) */
+    const float* dis_r;      /* device [out_h*S]  row distances  */
+    const int32_t* left_c;   /* device [out_w] */
+    const float* dis_c;      /* device [out_w*S] */
+    const double* dis_r64;   /* device, optional: float64 distances for LERF_F64 outputs */
+    const double* dis_c64;
+} lerf_sr_geo_t;
+
+/* Homography geometry (resize_right/resize_right2d_numpy.py:306-407): evaluated
+ * per output pixel on the device in float64; pad_* come from lerf_warp_pads. */
+typedef struct {
+    int S;
+    int out_h, out_w;
+    double minv[9];          /* inverse of the 3x3 matrix, row major */
+    int pad_r_lo, pad_r_hi, pad_c_lo, pad_c_hi;
+} lerf_warp_geo_t;
+
+/* ---------------------------------------------------------------- host side */
+int lerf_abi_version(void);
+const char* lerf_strerror(int code);
+
+/* number of visible HIP devices (does not initialise a context); <0 on error */
+int lerf_device_count(void);
+
+/* Rotated sampling offsets of mode in {'s','c','t','d','y'} for rotation r,
+ * expressed in the unrotated frame (resample/eval_lut_sr.py:30-81, 549-553, 468).
+ * LERF_EINVAL for an unknown mode == the reference's ValueError (:84). */
+int lerf_mode_offsets(char mode, int rot, int8_t dy[4], int8_t dx[4]);
+
+/* 1-D SR tables, float64 arithmetic in the reference's exact operation order
+ * (resize_right/resize_right2d_numpy.py:70-79, 85-90, 100-104, 131-134).
+ * left[n_out], dis64[n_out*S], dis32[n_out*S] (class-preserving float32
+ * rounding: the <0 / [0,1] / >1 classes of the linear kernel are kept),
+ * pads[2] = {pad_lo, pad_hi}.  dis32 / pads may be NULL. */
+int lerf_sr_axis_tables(int n_in, int n_out, double scale, int S,
+                        int32_t* left, double* dis64, float* dis32, int32_t* pads);
+
+/* ceil(scale * n_in) (resize_right/resize_right2d_numpy.py:41-45) */
+int lerf_out_size(int n_in, double scale);
+
+/* 3x3 inverse (adjugate).  Callers that need bit parity with the reference pass
+ * np.linalg.inv's result instead (resize_right/resize_right2d_numpy.py:327). */
+int lerf_invert3x3(const double m[9], double out[9]);
+
+/* Pad sizes {r_lo, r_hi, c_lo, c_hi} of Warp2dNumpy.calc_pad_sz from the two
+ * corner pixels (:363-369), for the INVERSE homography `minv`. */
+int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_w, int S,
+                   int32_t pads[4]);
+
+/* -------------------------------------------------------------- device side */
+
+/* FourSimplexInterpFaster (resample/eval_lut_sr.py:24-470) without the final
+ * rot90 and /q: integer numerators (value*16) of the 4-simplex interpolation
+ * of `lut` ([17^4][oC] int8) over 4 pixels sampled at offsets (dy[k], dx[k])
+ * from each of the h x w positions of the uint8 image `img` (coordinates are
+ * clamped to [0,img_h-1] x [0,img_w-1]).  out: int16 [C][oC][h][w]. */
+int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C,
+                        int h, int w, const int8_t dy[4], const int8_t dx[4],
+                        const int8_t* lut, int oC, int16_t* out, void* stream);
+
+/* Repack one stage-2 LUT [17^4][oC] int8 into one uint32 per entry
+ * (biased bytes, layout documented in DESIGN.md) for the tiled kernels. */
+int lerf_lut_pack_s2(const int8_t* lut, int oC, uint32_t* packed, void* stream);
+
+/* Stages 1+2 of eltr._worker (resample/eval_lut_sr.py:541-628,
+ * resample/eval_lut_warp.py:104-191): uint8 image -> feat (uint8, same shape)
+ * and hyper numerators hq (uint8, [H][W][C][oC] through `hyper` strides with
+ * sc = stride of c and the oC values contiguous).  feat/hyper may alias
+ * nothing.  Either output pointer may be NULL to skip writing it. */
+int lerf_lut_stages_u8(const lerf_plane_t* img, int H, int W, int C,
+                       const lerf_luts_t* luts,
+                       const lerf_mplane_t* feat, const lerf_mplane_t* hyper,
+                       void* stream);
+
+/* Stage 3, SR: SteeringGaussianResize2dNumpy.resize (:162-223) /
+ * AmplifiedLinearResize2dNumpy.resize (:243-282) and their Torch twins
+ * (resize_right/resize_right2d_torch.py:154-197, 214-247).
+ * feat: uint8 or float32.  hyper[k]: uint8 numerators (h = u8/255) or float32
+ * maps in [0,1]; k = rho, sigma_x, sigma_y (gauss) or alpha (linear).
+ * out: uint8 (clip(rne)), float32 or float64 (float64 arithmetic). */
+int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
+                int H, int W, int C, const lerf_sr_geo_t* geo,
+                int kind, double max_sigma, const lerf_mplane_t* out, void* stream);
+
+/* Stage 3, homography: SteeringGaussianWarp2dNumpy.warp (:516-577),
+ * AmplifiedLinearWarp2dNumpy.warp (:597-636), NearestWarp2dNumpy (:460-467,
+ * 409-449) and the Torch twins (resize_right2d_torch.py:346-487).
+ * Pixels whose weights all vanish are NaN in float outputs (the reference's
+ * 0/0) and 0 in uint8 outputs.  If `mask_out` (uint8 [out_h][out_w]) is
+ * non-NULL and kind == NEAREST, it receives out == 255 per pixel. */
+int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
+              int H, int W, int C, const lerf_warp_geo_t* geo,
+              int kind, double max_sigma, const lerf_mplane_t* out, void* stream);
+
+/* Whole SR path of eltr._worker (resample/eval_lut_sr.py:541-665) in one
+ * launch per frame batch: uint8 HWC in -> uint8 HWC out, feat and hyper never
+ * leave the chip.  `n` frames with batch strides in_sn / out_sn (elements).
+ * workspace: lerf_sr_fused_workspace_bytes() bytes of device memory (may be 0). */
+size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n);
+int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
+                     const lerf_luts_t* luts, const lerf_sr_geo_t* geo,
+                     int kind, double max_sigma,
+                     uint8_t* out, int64_t out_sn, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LERF_HIP_H */

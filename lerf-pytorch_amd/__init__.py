@@ -1,0 +1,12 @@
+"""lerf-pytorch_amd: the LeRF LUT resampling hot path on MI355X (gfx950).
+
+Importable as `lerf_pytorch_amd` (see lerf_pytorch_amd.py at the repo root).
+Host side = Python mirroring the reference's class / function API; device side
+= hand-written HIP behind a C ABI (include/lerf_hip.h, liblerf_hip.so).
+"""
+from . import _lib  # noqa: F401
+from ._lib import LerfError, LIB_PATH  # noqa: F401
+from .luts import LutSet, load_lut_arrays  # noqa: F401
+from .pipeline import LerfEngine, sr, warp  # noqa: F401
+
+__all__ = ["LerfEngine", "LutSet", "load_lut_arrays", "sr", "warp", "LerfError", "LIB_PATH"]

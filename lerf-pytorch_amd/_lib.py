@@ -1,0 +1,176 @@
+"""ctypes binding of liblerf_hip.so (C ABI: include/lerf_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a device entry
+point is called without a GPU, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblerf_hip.so")
+
+LERF_MAX_MODES = 5
+LERF_LUT_ENTRIES = 83521
+LERF_MAX_SUPPORT = 8
+LERF_U8, LERF_F32, LERF_F64, LERF_I16 = 0, 1, 2, 3
+KIND_GAUSS, KIND_LINEAR, KIND_NEAREST = 0, 1, 2
+KINDS = {"gauss": KIND_GAUSS, "linear": KIND_LINEAR, "nearest": KIND_NEAREST}
+
+EXPORTS = [
+    "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables",
+    "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_lut_pack_s2", "lerf_lut_stages_u8",
+    "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_u8",
+]
+
+
+class LerfError(RuntimeError):
+    pass
+
+
+class Plane(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int), ("sy", C.c_int64), ("sx", C.c_int64), ("sc", C.c_int64)]
+
+
+class Luts(C.Structure):
+    _fields_ = [
+        ("n_modes1", C.c_int), ("n_modes2", C.c_int),
+        ("modes1", C.c_char * LERF_MAX_MODES), ("modes2", C.c_char * LERF_MAX_MODES),
+        ("oC", C.c_int),
+        ("s1", C.c_void_p * LERF_MAX_MODES),
+        ("s2", (C.c_void_p * 2) * LERF_MAX_MODES),
+        ("s2_packed", (C.c_void_p * 2) * LERF_MAX_MODES),
+    ]
+
+
+class SrGeo(C.Structure):
+    _fields_ = [
+        ("S", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
+        ("left_r", C.c_void_p), ("dis_r", C.c_void_p), ("left_c", C.c_void_p), ("dis_c", C.c_void_p),
+        ("dis_r64", C.c_void_p), ("dis_c64", C.c_void_p),
+    ]
+
+
+class WarpGeo(C.Structure):
+    _fields_ = [
+        ("S", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
+        ("minv", C.c_double * 9),
+        ("pad_r_lo", C.c_int), ("pad_r_hi", C.c_int), ("pad_c_lo", C.c_int), ("pad_c_hi", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load liblerf_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LerfError(
+            "liblerf_hip.so not found at %s -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.lerf_abi_version.restype = C.c_int
+    L.lerf_strerror.restype = C.c_char_p
+    L.lerf_strerror.argtypes = [C.c_int]
+    L.lerf_device_count.restype = C.c_int
+    L.lerf_mode_offsets.argtypes = [C.c_char, C.c_int, C.c_void_p, C.c_void_p]
+    L.lerf_sr_axis_tables.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lerf_out_size.argtypes = [C.c_int, C.c_double]
+    L.lerf_invert3x3.argtypes = [C.c_void_p, C.c_void_p]
+    L.lerf_warp_pads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lerf_lut_interp_i16.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lerf_lut_pack_s2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lerf_lut_stages_u8.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
+                                     C.POINTER(Plane), C.POINTER(Plane), C.c_void_p]
+    L.lerf_resize.argtypes = [C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(SrGeo),
+                              C.c_int, C.c_double, C.POINTER(Plane), C.c_void_p]
+    L.lerf_warp.argtypes = [C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo),
+                            C.c_int, C.c_double, C.POINTER(Plane), C.c_void_p]
+    L.lerf_sr_fused_workspace_bytes.restype = C.c_size_t
+    L.lerf_sr_fused_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lerf_sr_fused_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
+                                   C.POINTER(SrGeo), C.c_int, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    for name in EXPORTS:          # AttributeError here = the .so does not match include/lerf_hip.h
+        getattr(L, name)
+    if L.lerf_abi_version() != 1:
+        raise LerfError("liblerf_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().lerf_strerror(rc).decode()
+        if rc == -1:
+            raise ValueError("%s: %s" % (what, msg))
+        raise LerfError("%s: %s (code %d)" % (what, msg, rc))
+
+
+# ------------------------------------------------------------------ host-side helpers (no GPU needed)
+def mode_offsets(mode: str, rot: int):
+    dy = np.zeros(4, np.int8)
+    dx = np.zeros(4, np.int8)
+    rc = lib().lerf_mode_offsets(mode.encode()[:1] if mode else b"\0", int(rot), dy.ctypes.data, dx.ctypes.data)
+    if rc != 0:
+        raise ValueError("Mode {} not implemented.".format(mode))     # resample/eval_lut_sr.py:84
+    return dy, dx
+
+
+def out_size(n_in: int, scale: float) -> int:
+    return int(lib().lerf_out_size(int(n_in), float(scale)))
+
+
+def sr_axis_tables(n_in: int, n_out: int, scale: float, S: int):
+    left = np.zeros(n_out, np.int32)
+    dis64 = np.zeros((n_out, S), np.float64)
+    dis32 = np.zeros((n_out, S), np.float32)
+    pads = np.zeros(2, np.int32)
+    check(lib().lerf_sr_axis_tables(int(n_in), int(n_out), float(scale), int(S), left.ctypes.data,
+                                    dis64.ctypes.data, dis32.ctypes.data, pads.ctypes.data), "lerf_sr_axis_tables")
+    return left, dis64, dis32, (int(pads[0]), int(pads[1]))
+
+
+def warp_pads(minv: np.ndarray, in_hw, out_hw, S: int):
+    """pads (r_lo, r_hi, c_lo, c_hi) for the INVERSE homography (np.linalg.inv of the matrix)."""
+    m = np.ascontiguousarray(minv, dtype=np.float64).reshape(9)
+    pads = np.zeros(4, np.int32)
+    check(lib().lerf_warp_pads(m.ctypes.data, int(in_hw[0]), int(in_hw[1]), int(out_hw[0]), int(out_hw[1]), int(S),
+                               pads.ctypes.data), "lerf_warp_pads")
+    return tuple(int(p) for p in pads)
+
+
+# ------------------------------------------------------------------ device plumbing
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise LerfError("lerf-pytorch_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                        "and there is no CPU fallback.")
+    return torch
+
+
+_TORCH_DT = None
+
+
+def _dt(t):
+    global _TORCH_DT
+    import torch
+    if _TORCH_DT is None:
+        _TORCH_DT = {torch.uint8: LERF_U8, torch.float32: LERF_F32, torch.float64: LERF_F64, torch.int16: LERF_I16}
+    return _TORCH_DT[t.dtype]
+
+
+def plane(t, sy, sx, sc, offset=0):
+    """Plane descriptor of torch tensor `t` (element strides)."""
+    return Plane(t.data_ptr() + offset * t.element_size(), _dt(t), int(sy), int(sx), int(sc))
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

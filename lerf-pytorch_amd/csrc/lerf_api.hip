@@ -1,0 +1,283 @@
+// C ABI of liblerf_hip.so (include/lerf_hip.h): argument checking, host-side
+// geometry, and dispatch to the kernels.  No allocation, no synchronisation,
+// no global state.
+#include <math.h>
+#include <string.h>
+
+#include "lerf_kernels.h"
+
+using namespace lerf;
+
+namespace {
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+}
+
+inline bool plane_ok(const lerf_plane_t* p) { return p && p->ptr; }
+
+// float32 rounding of a float64 distance that keeps its class for the
+// amplified-linear kernel's hard masks (resize_right2d_numpy.py:233-235)
+inline int dclass(double x) { return (x >= -1.0 && x < 0.0) ? 1 : ((x >= 0.0 && x <= 1.0) ? 2 : 0); }
+inline int fclass(float x) { return (x >= -1.0f && x < 0.0f) ? 1 : ((x >= 0.0f && x <= 1.0f) ? 2 : 0); }
+
+float class_preserving_f32(double d) {
+    float f = (float)d;
+    int want = dclass(d);
+    if (fclass(f) == want) return f;
+    float up = nextafterf(f, INFINITY), dn = nextafterf(f, -INFINITY);
+    if (fclass(up) == want) return up;
+    if (fclass(dn) == want) return dn;
+    return f;
+}
+
+int build_stage_luts(const lerf_luts_t* L, int stage, StageLuts* out) {
+    int n = stage == 1 ? L->n_modes1 : L->n_modes2;
+    if (n < 1 || n > LERF_MAX_MODES) return LERF_EINVAL;
+    out->n_modes = n;
+    for (int m = 0; m < n; ++m) {
+        char mode = stage == 1 ? L->modes1[m] : L->modes2[m];
+        for (int r = 0; r < 4; ++r)
+            if (!mode_offsets(mode, r, out->off[m][r].dy, out->off[m][r].dx)) return LERF_EINVAL;
+        if (stage == 1) {
+            if (!L->s1[m]) return LERF_EINVAL;
+            out->lut[m][0] = out->lut[m][1] = L->s1[m];     // stage 1 uses ...r0 for all rotations (:545)
+        } else {
+            if (!L->s2[m][0] || !L->s2[m][1]) return LERF_EINVAL;
+            out->lut[m][0] = L->s2[m][0];                    // r in {0,2} -> r0, {1,3} -> r1 (:582-619)
+            out->lut[m][1] = L->s2[m][1];
+        }
+    }
+    return LERF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lerf_abi_version(void) { return LERF_ABI_VERSION; }
+
+const char* lerf_strerror(int code) {
+    switch (code) {
+        case LERF_OK: return "ok";
+        case LERF_EINVAL: return "invalid argument";
+        case LERF_EUNSUPPORTED: return "unsupported configuration";
+        case LERF_ELAUNCH: return "HIP launch failed";
+        case LERF_ENODEVICE: return "no gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+int lerf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return LERF_ENODEVICE;
+    return n;
+}
+
+int lerf_mode_offsets(char mode, int rot, int8_t dy[4], int8_t dx[4]) {
+    if (!dy || !dx) return LERF_EINVAL;
+    return mode_offsets(mode, rot, dy, dx) ? LERF_OK : LERF_EINVAL;
+}
+
+int lerf_out_size(int n_in, double scale) { return (int)ceil(scale * (double)n_in); }
+
+int lerf_sr_axis_tables(int n_in, int n_out, double scale, int S, int32_t* left, double* dis64, float* dis32,
+                        int32_t* pads) {
+#pragma clang fp contract(off)
+    if (n_in < 1 || n_out < 1 || !(scale > 0.0) || S < 1 || S > LERF_MAX_SUPPORT || !left || !dis64) return LERF_EINVAL;
+    // g = i/s + (n_in-1)/2 - (n_out-1)/(2s)            resize_right2d_numpy.py:70-79
+    const double a = (double)(n_in - 1) / 2;
+    const double b = (double)(n_out - 1) / (2 * scale);
+    int pad_lo = 0;
+    for (int i = 0; i < n_out; ++i) {
+        double g = (double)i / scale + a - b;
+        int l = left_boundary(g, S);                    // :85-90
+        if (i == 0) pad_lo = -l;                        // :101
+        left[i] = l;
+        double gp = g + (double)pad_lo;                 // :103
+        for (int k = 0; k < S; ++k) {
+            double d = gp - (double)(l + pad_lo + k);   // :131-134
+            dis64[i * S + k] = d;
+            if (dis32) dis32[i * S + k] = class_preserving_f32(d);
+        }
+    }
+    if (pads) {
+        pads[0] = pad_lo;
+        pads[1] = left[n_out - 1] + S - 1 - n_in + 1;   // :101
+    }
+    return LERF_OK;
+}
+
+int lerf_invert3x3(const double m[9], double out[9]) {
+    if (!m || !out) return LERF_EINVAL;
+    double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    if (det == 0.0) return LERF_EINVAL;
+    out[0] = c00 / det;
+    out[1] = (m[2] * m[7] - m[1] * m[8]) / det;
+    out[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+    out[3] = c01 / det;
+    out[4] = (m[0] * m[8] - m[2] * m[6]) / det;
+    out[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+    out[6] = c02 / det;
+    out[7] = (m[1] * m[6] - m[0] * m[7]) / det;
+    out[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+    return LERF_OK;
+}
+
+int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_w, int S, int32_t pads[4]) {
+    if (!minv || !pads || in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1 || S < 1) return LERF_EINVAL;
+    double gr, gc;
+    project_point(minv, 0, 0, in_h, in_w, &gr, &gc);
+    int l0r = left_boundary(gr, S), l0c = left_boundary(gc, S);
+    project_point(minv, out_h - 1, out_w - 1, in_h, in_w, &gr, &gc);
+    int l1r = left_boundary(gr, S), l1c = left_boundary(gc, S);
+    // calc_pad_sz: (max(-fov[0,0],0), max(fov[-1,-1]-in+1,0)), fov[-1,-1] = left + S-1   (:363-366)
+    pads[0] = -l0r > 0 ? -l0r : 0;
+    pads[1] = (l1r + S - 1 - in_h + 1) > 0 ? (l1r + S - 1 - in_h + 1) : 0;
+    pads[2] = -l0c > 0 ? -l0c : 0;
+    pads[3] = (l1c + S - 1 - in_w + 1) > 0 ? (l1c + S - 1 - in_w + 1) : 0;
+    return LERF_OK;
+}
+
+int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4],
+                        const int8_t dx[4], const int8_t* lut, int oC, int16_t* out, void* stream) {
+    if (!plane_ok(img) || img->dtype != LERF_U8 || !lut || !out || !dy || !dx) return LERF_EINVAL;
+    if (img_h < 1 || img_w < 1 || C < 1 || h < 1 || w < 1) return LERF_EINVAL;
+    Offsets4 off;
+    memcpy(off.dy, dy, 4);
+    memcpy(off.dx, dx, 4);
+    int rc = launch_lut_interp((const uint8_t*)img->ptr, img->sy, img->sx, img->sc, img_h, img_w, C, h, w, off, lut,
+                               oC, out, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
+int lerf_lut_pack_s2(const int8_t* lut, int oC, uint32_t* packed, void* stream) {
+    if (!lut || !packed) return LERF_EINVAL;
+    int rc = launch_lut_pack(lut, oC, packed, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
+int lerf_lut_stages_u8(const lerf_plane_t* img, int H, int W, int C, const lerf_luts_t* luts,
+                       const lerf_mplane_t* feat, const lerf_mplane_t* hyper, void* stream) {
+    if (!plane_ok(img) || img->dtype != LERF_U8 || !luts || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    if (!feat || !feat->ptr || feat->dtype != LERF_U8) return LERF_EINVAL;   // stage 2 reads feat
+    if (luts->oC != 1 && luts->oC != 3) return LERF_EUNSUPPORTED;
+    StageLuts s1, s2;
+    int rc = build_stage_luts(luts, 1, &s1);
+    if (rc != LERF_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    // feat = rne(clip(pred/len(modes), 0, 255)): numerators carry a factor 16          (:565-577)
+    rc = launch_lut_stage((const uint8_t*)img->ptr, img->sy, img->sx, img->sc, H, W, C, s1, 1, kQ * luts->n_modes1, 0,
+                          (uint8_t*)feat->ptr, feat->sy, feat->sx, feat->sc, st);
+    if (rc != LERF_OK) return rc;
+    if (hyper && hyper->ptr) {
+        if (hyper->dtype != LERF_U8) return LERF_EINVAL;
+        rc = build_stage_luts(luts, 2, &s2);
+        if (rc != LERF_OK) return rc;
+        // hq = rne(clip(pred/(4*len(modes2)) + 127, 0, 255))                              (:621-628)
+        rc = launch_lut_stage((const uint8_t*)feat->ptr, feat->sy, feat->sx, feat->sc, H, W, C, s2, luts->oC,
+                              kQ * 4 * luts->n_modes2, 127, (uint8_t*)hyper->ptr, hyper->sy, hyper->sx, hyper->sc, st);
+        if (rc != LERF_OK) return rc;
+    }
+    return check_launch();
+}
+
+int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int W, int C, const lerf_sr_geo_t* geo,
+                int kind, double max_sigma, const lerf_mplane_t* out, void* stream) {
+    if (!plane_ok(feat) || !hyper || !geo || !out || !out->ptr || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    int nh = kind == LERF_KIND_GAUSS ? 3 : (kind == LERF_KIND_LINEAR ? 1 : 0);
+    if (nh == 0) return LERF_EUNSUPPORTED;
+    for (int k = 0; k < nh; ++k)
+        if (!hyper[k].ptr || hyper[k].dtype != hyper[0].dtype || hyper[k].sy != hyper[0].sy ||
+            hyper[k].sx != hyper[0].sx || hyper[k].sc != hyper[0].sc)
+            return LERF_EINVAL;
+    if (!geo->left_r || !geo->left_c || geo->out_h < 1 || geo->out_w < 1) return LERF_EINVAL;
+    ResizeArgs a{};
+    a.feat = feat->ptr; a.in_dtype = feat->dtype; a.fy = feat->sy; a.fx = feat->sx; a.fc = feat->sc;
+    for (int k = 0; k < 3; ++k) a.h[k] = k < nh ? hyper[k].ptr : hyper[0].ptr;
+    a.h_dtype = hyper[0].dtype; a.hy = hyper[0].sy; a.hx = hyper[0].sx; a.hc = hyper[0].sc;
+    a.H = H; a.W = W; a.C = C; a.S = geo->S; a.oH = geo->out_h; a.oW = geo->out_w;
+    a.left_r = geo->left_r; a.dis_r = geo->dis_r; a.left_c = geo->left_c; a.dis_c = geo->dis_c;
+    a.dis_r64 = geo->dis_r64; a.dis_c64 = geo->dis_c64;
+    a.kind = kind; a.max_sigma = max_sigma;
+    a.out = out->ptr; a.out_dtype = out->dtype; a.oy = out->sy; a.ox = out->sx; a.oc = out->sc;
+    int rc = launch_resize(a, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
+int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int W, int C, const lerf_warp_geo_t* geo,
+              int kind, double max_sigma, const lerf_mplane_t* out, void* stream) {
+    if (!plane_ok(feat) || !geo || !out || !out->ptr || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    int nh = kind == LERF_KIND_GAUSS ? 3 : (kind == LERF_KIND_LINEAR ? 1 : 0);
+    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR && kind != LERF_KIND_NEAREST) return LERF_EUNSUPPORTED;
+    if (nh > 0 && !hyper) return LERF_EINVAL;
+    for (int k = 0; k < nh; ++k)
+        if (!hyper[k].ptr || hyper[k].dtype != hyper[0].dtype || hyper[k].sy != hyper[0].sy ||
+            hyper[k].sx != hyper[0].sx || hyper[k].sc != hyper[0].sc)
+            return LERF_EINVAL;
+    if (geo->out_h < 1 || geo->out_w < 1) return LERF_EINVAL;
+    WarpArgs a{};
+    a.feat = feat->ptr; a.in_dtype = feat->dtype; a.fy = feat->sy; a.fx = feat->sx; a.fc = feat->sc;
+    for (int k = 0; k < 3; ++k) a.h[k] = nh > 0 ? (k < nh ? hyper[k].ptr : hyper[0].ptr) : feat->ptr;
+    a.h_dtype = nh > 0 ? hyper[0].dtype : feat->dtype;
+    a.hy = nh > 0 ? hyper[0].sy : 0; a.hx = nh > 0 ? hyper[0].sx : 0; a.hc = nh > 0 ? hyper[0].sc : 0;
+    a.H = H; a.W = W; a.C = C;
+    a.geo.S = geo->S; a.geo.oH = geo->out_h; a.geo.oW = geo->out_w;
+    memcpy(a.geo.minv, geo->minv, sizeof(a.geo.minv));
+    a.geo.pad_r_lo = geo->pad_r_lo; a.geo.pad_r_hi = geo->pad_r_hi;
+    a.geo.pad_c_lo = geo->pad_c_lo; a.geo.pad_c_hi = geo->pad_c_hi;
+    a.kind = kind; a.max_sigma = max_sigma;
+    a.out = out->ptr; a.out_dtype = out->dtype; a.oy = out->sy; a.ox = out->sx; a.oc = out->sc;
+    int rc = launch_warp(a, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
+size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {
+    // room for the unfused fallback (feat + 3 hyper planes per frame); the tile-fused kernel needs none
+    if (H < 1 || W < 1 || C < 1 || n < 1) return 0;
+    return (size_t)n * H * W * C * 4;
+}
+
+int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts,
+                     const lerf_sr_geo_t* geo, int kind, double max_sigma, uint8_t* out, int64_t out_sn,
+                     void* workspace, void* stream) {
+    if (!img || !out || !luts || !geo || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    if (!geo->left_r || !geo->left_c || !geo->dis_r || !geo->dis_c) return LERF_EINVAL;
+    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return LERF_EUNSUPPORTED;
+    if ((kind == LERF_KIND_GAUSS) != (luts->oC == 3)) return LERF_EINVAL;
+    FusedArgs f{};
+    f.img = img; f.in_sn = in_sn; f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts;
+    f.S = geo->S; f.oH = geo->out_h; f.oW = geo->out_w;
+    f.left_r = geo->left_r; f.dis_r = geo->dis_r; f.left_c = geo->left_c; f.dis_c = geo->dis_c;
+    f.kind = kind; f.max_sigma = (float)max_sigma; f.out = out; f.out_sn = out_sn; f.workspace = workspace;
+    if (fused_supported(f)) {
+        int rc = launch_sr_fused(f, as_stream(stream));
+        return rc != LERF_OK ? rc : check_launch();
+    }
+    // general configuration: the three stages through the caller's workspace
+    if (!workspace) return LERF_EINVAL;
+    const int oC = luts->oC;
+    for (int b = 0; b < n; ++b) {
+        uint8_t* ws = (uint8_t*)workspace + (size_t)b * H * W * C * 4;
+        lerf_plane_t in{img + b * in_sn, LERF_U8, (int64_t)W * C, C, 1};
+        lerf_mplane_t feat{ws, LERF_U8, (int64_t)W * C, C, 1};
+        lerf_mplane_t hyp{ws + (size_t)H * W * C, LERF_U8, (int64_t)W * C * oC, (int64_t)C * oC, oC};
+        int rc = lerf_lut_stages_u8(&in, H, W, C, luts, &feat, &hyp, stream);
+        if (rc != LERF_OK) return rc;
+        lerf_plane_t fin{ws, LERF_U8, (int64_t)W * C, C, 1};
+        lerf_plane_t hp[3];
+        for (int k = 0; k < 3; ++k)
+            hp[k] = lerf_plane_t{ws + (size_t)H * W * C + (k < oC ? k : 0), LERF_U8, (int64_t)W * C * oC,
+                                 (int64_t)C * oC, oC};
+        lerf_mplane_t o{out + b * out_sn, LERF_U8, (int64_t)geo->out_w * C, C, 1};
+        rc = lerf_resize(&fin, hp, H, W, C, geo, kind, max_sigma, &o, stream);
+        if (rc != LERF_OK) return rc;
+    }
+    return LERF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Shared host/device helpers for the LeRF HIP kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lerf_hip.h"
+
+namespace lerf {
+
+constexpr int kL = 17;                 // 2^(8-interval)+1, interval = 4
+constexpr int kQ = 16;                 // 2^interval
+constexpr int kStrideA = kL * kL * kL; // 4913: first sampled pixel = slowest LUT axis
+constexpr int kStrideB = kL * kL;      // 289
+constexpr int kStrideC = kL;           // 17
+constexpr int kStrideD = 1;
+constexpr float kEps32 = 1.1920928955078125e-07f;  // np.finfo(np.float32).eps
+
+// Sampling patterns of resample/eval_lut_sr.py:30-81, (dy, dx) of pixels a,b,c,d.
+__host__ __device__ inline bool mode_pattern(char mode, int8_t dy[4], int8_t dx[4]) {
+    dy[0] = 0; dx[0] = 0;
+    switch (mode) {
+        case 's': dy[1] = 0; dx[1] = 1; dy[2] = 1; dx[2] = 0; dy[3] = 1; dx[3] = 1; return true;
+        case 'd': dy[1] = 0; dx[1] = 2; dy[2] = 2; dx[2] = 0; dy[3] = 2; dx[3] = 2; return true;
+        case 'y': dy[1] = 1; dx[1] = 1; dy[2] = 1; dx[2] = 2; dy[3] = 2; dx[3] = 1; return true;
+        case 'c': dy[1] = 0; dx[1] = 1; dy[2] = 0; dx[2] = 2; dy[3] = 0; dx[3] = 3; return true;
+        case 't': dy[1] = 1; dx[1] = 1; dy[2] = 2; dx[2] = 2; dy[3] = 3; dx[3] = 3; return true;
+        default: return false;
+    }
+}
+
+// np.rot90(img, r) + bottom/right edge pad + pattern + rot90 back
+// == offsets rotated r times by (dy,dx)->(dx,-dy) with clamped coordinates.
+__host__ __device__ inline bool mode_offsets(char mode, int rot, int8_t dy[4], int8_t dx[4]) {
+    if (!mode_pattern(mode, dy, dx)) return false;
+    rot &= 3;
+    for (int k = 0; k < 4; ++k)
+        for (int r = 0; r < rot; ++r) {
+            int8_t t = dy[k];
+            dy[k] = dx[k];
+            dx[k] = (int8_t)(-t);
+        }
+    return true;
+}
+
+// round-half-to-even of n/d for n >= 0 (np.round), clipped to [0,255].
+__host__ __device__ inline int rne_div_clip255(int n, int d) {
+    if (n <= 0) return 0;
+    int q = n / d;
+    int r = n - q * d;
+    int up = (2 * r > d) || ((2 * r == d) && (q & 1));
+    q += up;
+    return q > 255 ? 255 : q;
+}
+
+// compare-exchange, descending
+__device__ __forceinline__ void ce_desc(unsigned& a, unsigned& b) {
+    unsigned hi = a > b ? a : b;
+    unsigned lo = a > b ? b : a;
+    a = hi;
+    b = lo;
+}
+
+// 4-simplex interpolation walk: sorted (LSB<<16 | axis stride) keys.
+// Produces the 5 LUT indices and weights (sum of weights = 16).
+struct SimplexPath {
+    int idx[5];
+    int w[5];
+};
+
+__device__ __forceinline__ SimplexPath simplex_path(int v0, int v1, int v2, int v3) {
+    unsigned k0 = ((unsigned)(v0 & 15) << 16) | (unsigned)kStrideA;
+    unsigned k1 = ((unsigned)(v1 & 15) << 16) | (unsigned)kStrideB;
+    unsigned k2 = ((unsigned)(v2 & 15) << 16) | (unsigned)kStrideC;
+    unsigned k3 = ((unsigned)(v3 & 15) << 16) | (unsigned)kStrideD;
+    int base = (v0 >> 4) * kStrideA + (v1 >> 4) * kStrideB + (v2 >> 4) * kStrideC + (v3 >> 4);
+    ce_desc(k0, k1);
+    ce_desc(k2, k3);
+    ce_desc(k0, k2);
+    ce_desc(k1, k3);
+    ce_desc(k1, k2);
+    int f0 = k0 >> 16, f1 = k1 >> 16, f2 = k2 >> 16, f3 = k3 >> 16;
+    SimplexPath p;
+    p.idx[0] = base;
+    p.idx[1] = p.idx[0] + (int)(k0 & 0xffffu);
+    p.idx[2] = p.idx[1] + (int)(k1 & 0xffffu);
+    p.idx[3] = p.idx[2] + (int)(k2 & 0xffffu);
+    p.idx[4] = p.idx[3] + (int)(k3 & 0xffffu);
+    p.w[0] = kQ - f0;
+    p.w[1] = f0 - f1;
+    p.w[2] = f1 - f2;
+    p.w[3] = f2 - f3;
+    p.w[4] = f3;
+    return p;
+}
+
+__host__ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Homography projection of output pixel (row i, col j) in float64, operation
+// order of resize_right/resize_right2d_numpy.py:321-339 (no FMA contraction).
+__host__ __device__ inline void project_point(const double* m, int i, int j, int H, int W, double* gr, double* gc) {
+#pragma clang fp contract(off)
+    double x = (double)j, y = (double)i;
+    double X = m[0] * x + m[1] * y + m[2];
+    double Y = m[3] * x + m[4] * y + m[5];
+    double Wh = m[6] * x + m[7] * y + m[8];
+    X = X / Wh;
+    Y = Y / Wh;
+    double r = Y, c = X;
+    r = r < 0.0 ? 0.0 : (r > (double)H ? (double)H : r);
+    c = c < 0.0 ? 0.0 : (c > (double)W ? (double)W : c);
+    *gr = r;
+    *gc = c;
+}
+
+__host__ __device__ inline int left_boundary(double g, int S) {
+#pragma clang fp contract(off)
+    return (int)ceil(g - (double)S / 2 - (double)kEps32);
+}
+
+}  // namespace lerf

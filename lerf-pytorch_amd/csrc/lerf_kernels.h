@@ -1,0 +1,67 @@
+// Internal launch interfaces between lerf_api.hip and the kernel files.
+#pragma once
+
+#include "lerf_common.h"
+
+namespace lerf {
+
+struct Offsets4 {
+    int8_t dy[4];
+    int8_t dx[4];
+};
+
+// one LUT stage: per mode two LUTs (rotation parity 0 / 1) and 4 rotated patterns
+struct StageLuts {
+    int n_modes;
+    const int8_t* lut[LERF_MAX_MODES][2];
+    Offsets4 off[LERF_MAX_MODES][4];
+};
+
+struct ResizeArgs {
+    const void* feat; int in_dtype; int64_t fy, fx, fc;
+    const void* h[3]; int h_dtype; int64_t hy, hx, hc;
+    int H, W, C, S, oH, oW;
+    const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
+    const double* dis_r64; const double* dis_c64;
+    int kind; double max_sigma;
+    void* out; int out_dtype; int64_t oy, ox, oc;
+};
+
+struct WarpGeo {
+    int S, oH, oW;
+    double minv[9];
+    int pad_r_lo, pad_r_hi, pad_c_lo, pad_c_hi;
+};
+
+struct WarpArgs {
+    const void* feat; int in_dtype; int64_t fy, fx, fc;
+    const void* h[3]; int h_dtype; int64_t hy, hx, hc;
+    int H, W, C;
+    WarpGeo geo;
+    int kind; double max_sigma;
+    void* out; int out_dtype; int64_t oy, ox, oc;
+};
+
+int launch_lut_interp(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C,
+                      int h, int w, Offsets4 off, const int8_t* lut, int oC, int16_t* out, hipStream_t st);
+int launch_lut_stage(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int H, int W, int C,
+                     const StageLuts& luts, int oC, int div, int bias,
+                     uint8_t* out, int64_t oy, int64_t ox, int64_t ocs, hipStream_t st);
+int launch_resize(const ResizeArgs& a, hipStream_t st);
+int launch_warp(const WarpArgs& a, hipStream_t st);
+int launch_lut_pack(const int8_t* lut, int oC, uint32_t* packed, hipStream_t st);
+
+// lerf_fused.hip
+struct FusedArgs {
+    const uint8_t* img; int64_t in_sn; int n, H, W, C;
+    const lerf_luts_t* luts;
+    int S, oH, oW;
+    const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
+    int kind; float max_sigma;
+    uint8_t* out; int64_t out_sn;
+    void* workspace;
+};
+bool fused_supported(const FusedArgs& a);
+int launch_sr_fused(const FusedArgs& a, hipStream_t st);
+
+}  // namespace lerf

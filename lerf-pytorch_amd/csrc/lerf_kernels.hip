@@ -1,0 +1,443 @@
+// LeRF LUT resampling kernels for MI355X (gfx950, wave64).  Hand-written HIP;
+// no CUDA compatibility paths.  The C ABI (include/lerf_hip.h) is implemented
+// at the bottom of lerf_api.hip; this file holds the general-purpose kernels:
+//
+//   lut_interp_kernel   one (LUT, pattern) simplex pass        A1  (eval_lut_sr.py:24-470)
+//   lut_stage_kernel    rotation/mode ensemble + rounding      A2/A3 (eval_lut_sr.py:541-628)
+//   resize_kernel       separable-geometry stage 3 (SR)        A5/A6 (resize_right2d_numpy.py:142-282)
+//   warp_kernel         homography stage 3                     A7/A8 (resize_right2d_numpy.py:284-636)
+//
+// These "direct" kernels gather the LUTs from global memory (L1/L2) and keep
+// every tensor in HBM between stages; they serve the class-level API (float
+// CHW tensors, arbitrary modes / support sizes).  The tile-fused uint8 path
+// lives in lerf_fused.hip.
+#include "lerf_kernels.h"
+
+namespace lerf {
+
+// ---------------------------------------------------------------------------
+// A1: single LUT pass
+// ---------------------------------------------------------------------------
+template <int OC>
+__global__ void __launch_bounds__(256)
+lut_interp_kernel(const uint8_t* __restrict__ img, int64_t sy, int64_t sx, int64_t sc,
+                  int img_h, int img_w, int C, int h, int w, Offsets4 off,
+                  const int8_t* __restrict__ lut, int16_t* __restrict__ out) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    int c = blockIdx.z;
+    if (x >= w) return;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int yy = clampi(y + off.dy[k], 0, img_h - 1);
+        int xx = clampi(x + off.dx[k], 0, img_w - 1);
+        v[k] = img[yy * sy + xx * sx + c * sc];
+    }
+    SimplexPath p = simplex_path(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int oc = 0; oc < OC; ++oc) {
+        int acc = 0;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) acc += p.w[n] * (int)lut[p.idx[n] * OC + oc];
+        out[(((int64_t)c * OC + oc) * h + y) * w + x] = (int16_t)acc;
+    }
+}
+
+int launch_lut_interp(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C,
+                      int h, int w, Offsets4 off, const int8_t* lut, int oC, int16_t* out, hipStream_t st) {
+    dim3 block(256), grid((w + 255) / 256, h, C);
+    if (oC == 1)
+        hipLaunchKernelGGL(lut_interp_kernel<1>, grid, block, 0, st, img, sy, sx, sc, img_h, img_w, C, h, w, off, lut, out);
+    else if (oC == 3)
+        hipLaunchKernelGGL(lut_interp_kernel<3>, grid, block, 0, st, img, sy, sx, sc, img_h, img_w, C, h, w, off, lut, out);
+    else
+        return LERF_EUNSUPPORTED;
+    return LERF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// A2/A3: one LUT stage (sum over modes x 4 rotations, divide, bias, round, clip)
+// ---------------------------------------------------------------------------
+template <int OC>
+__global__ void __launch_bounds__(256)
+lut_stage_kernel(const uint8_t* __restrict__ img, int64_t sy, int64_t sx, int64_t sc,
+                 int H, int W, int C, StageLuts luts, int div, int bias,
+                 uint8_t* __restrict__ out, int64_t oy, int64_t ox, int64_t oc_stride) {
+    // x runs over (column, channel) so that HWC frames are read/written densely
+    int xc = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (xc >= W * C) return;
+    int x = xc / C;
+    int c = xc - x * C;
+    const uint8_t* plane = img + c * sc;
+    int acc[OC];
+#pragma unroll
+    for (int oc = 0; oc < OC; ++oc) acc[oc] = 0;
+    for (int m = 0; m < luts.n_modes; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int8_t* __restrict__ lut = luts.lut[m][r & 1];
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int yy = clampi(y + luts.off[m][r].dy[k], 0, H - 1);
+                int xx = clampi(x + luts.off[m][r].dx[k], 0, W - 1);
+                v[k] = plane[yy * sy + xx * sx];
+            }
+            SimplexPath p = simplex_path(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+#pragma unroll
+                for (int oc = 0; oc < OC; ++oc) acc[oc] += p.w[n] * (int)lut[p.idx[n] * OC + oc];
+            }
+        }
+    }
+    uint8_t* o = out + y * oy + x * ox + c * oc_stride;
+#pragma unroll
+    for (int oc = 0; oc < OC; ++oc) o[oc] = (uint8_t)rne_div_clip255(acc[oc] + bias * div, div);
+}
+
+int launch_lut_stage(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int H, int W, int C,
+                     const StageLuts& luts, int oC, int div, int bias,
+                     uint8_t* out, int64_t oy, int64_t ox, int64_t ocs, hipStream_t st) {
+    dim3 block(256), grid((W * C + 255) / 256, H);
+    if (oC == 1)
+        hipLaunchKernelGGL(lut_stage_kernel<1>, grid, block, 0, st, img, sy, sx, sc, H, W, C, luts, div, bias, out, oy, ox, ocs);
+    else if (oC == 3)
+        hipLaunchKernelGGL(lut_stage_kernel<3>, grid, block, 0, st, img, sy, sx, sc, H, W, C, luts, div, bias, out, oy, ox, ocs);
+    else
+        return LERF_EUNSUPPORTED;
+    return LERF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stage 3 building blocks
+// ---------------------------------------------------------------------------
+template <typename T> struct Loader;
+template <> struct Loader<uint8_t> {
+    // hyper numerators: h = float32(u8) / 255 exactly as eval_lut_sr.py:623-628
+    static __device__ __forceinline__ float hyper(const uint8_t* p) { return (float)(*p) / 255.0f; }
+    static __device__ __forceinline__ float pixel(const uint8_t* p) { return (float)(*p); }
+};
+template <> struct Loader<float> {
+    static __device__ __forceinline__ float hyper(const float* p) { return *p; }
+    static __device__ __forceinline__ float pixel(const float* p) { return *p; }
+};
+
+template <typename T> struct Storer;
+template <> struct Storer<uint8_t> {
+    // clip(np.round(x), 0, 255).astype(uint8)  (eval_lut_sr.py:663-665); NaN -> 0
+    template <typename A> static __device__ __forceinline__ void put(uint8_t* p, A v) {
+        float f = (float)v;
+        int r = (f != f) ? 0 : __float2int_rn(fminf(fmaxf(f, -1.0f), 256.0f));
+        *p = (uint8_t)clampi(r, 0, 255);
+    }
+};
+template <> struct Storer<float> {
+    template <typename A> static __device__ __forceinline__ void put(float* p, A v) { *p = (float)v; }
+};
+template <> struct Storer<double> {
+    template <typename A> static __device__ __forceinline__ void put(double* p, A v) { *p = (double)v; }
+};
+
+// Tap accumulator.  A = float: exponents are shifted by their minimum over the
+// support before exp (result unchanged mathematically; the largest weight is 1
+// so the normalisation can never be 0/0 where the float64 reference is finite).
+template <typename A, int KIND, int MAXT>
+struct TapAcc {
+    A e[MAXT];   // gauss: quadratic form; linear/nearest: weight
+    A v[MAXT];
+    int n = 0;
+
+    __device__ __forceinline__ void add_gauss(A rho, A sx, A sy, A dx, A dy, A val) {
+        // resize_right2d_numpy.py:150-160
+        A tx = sx * dx, ty = sy * dy;
+        e[n] = tx * tx - (A)2 * rho * (tx * ty) + ty * ty;
+        v[n] = val;
+        ++n;
+    }
+    __device__ __forceinline__ void add_weight(A w, A val) {
+        e[n] = w;
+        v[n] = val;
+        ++n;
+    }
+    __device__ __forceinline__ A finish() const {
+        A num = 0, den = 0;
+        if (KIND == LERF_KIND_GAUSS) {
+            A emin = e[0];
+#pragma unroll
+            for (int k = 1; k < MAXT; ++k)
+                if (k < n) emin = e[k] < emin ? e[k] : emin;
+#pragma unroll
+            for (int k = 0; k < MAXT; ++k)
+                if (k < n) {
+                    A w;
+                    if (sizeof(A) == 4)
+                        w = (A)__expf((float)((A)-0.5 * (e[k] - emin)));
+                    else
+                        w = (A)exp((double)((A)-0.5 * (e[k] - emin)));
+                    num += w * v[k];
+                    den += w;
+                }
+            // float64 reference: every weight underflows to 0 -> 0/0 = NaN
+            if (emin * (A)0.5 > (A)745.2) return (A)(0.0 / 0.0);
+            return num / den;
+        } else {
+#pragma unroll
+            for (int k = 0; k < MAXT; ++k)
+                if (k < n) {
+                    num += e[k] * v[k];
+                    den += e[k];
+                }
+            return num / den;   // 0/0 = NaN like the reference
+        }
+    }
+};
+
+// amplified-linear 1-D factor (resize_right2d_numpy.py:233-241), cls = class of
+// the float64 distance: 0 outside [-1,1], 1 for [-1,0), 2 for [0,1]
+template <typename A>
+__device__ __forceinline__ A lin_factor(A alpha, A x, int cls) {
+    A f = cls == 1 ? alpha * x + (A)1 : (cls == 2 ? (A)1 - alpha * x : (A)0);
+    return f < (A)0 ? (A)0 : f;
+}
+template <typename A>
+__device__ __forceinline__ int dist_class(A x) {
+    return (x >= (A)-1 && x < (A)0) ? 1 : ((x >= (A)0 && x <= (A)1) ? 2 : 0);
+}
+
+// ---------------------------------------------------------------------------
+// A5/A6: SR with separable geometry tables
+// ---------------------------------------------------------------------------
+template <typename TI, typename TH, typename TO, typename A, int KIND, int ST>
+__global__ void __launch_bounds__(256)
+resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
+              const TH* __restrict__ h0, const TH* __restrict__ h1, const TH* __restrict__ h2,
+              int64_t hy, int64_t hx, int64_t hc,
+              int H, int W, int C, int S_rt, int oH, int oW,
+              const int* __restrict__ left_r, const A* __restrict__ dis_r,
+              const int* __restrict__ left_c, const A* __restrict__ dis_c,
+              A max_sigma, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+    const int S = ST > 0 ? ST : S_rt;
+    constexpr int MAXS = ST > 0 ? ST : LERF_MAX_SUPPORT;
+    int xc = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (xc >= oW * C) return;
+    int j = xc / C;
+    int c = xc - j * C;
+    int lr = left_r[i], lc = left_c[j];
+    A num = 0, den = 0;
+    // the reference sums column-offset major, row-offset minor (numpy meshgrid 'xy', :95-98)
+    if (ST > 0) {
+        TapAcc<A, KIND, MAXS * MAXS> acc;
+#pragma unroll
+        for (int a = 0; a < MAXS; ++a) {
+#pragma unroll
+            for (int b = 0; b < MAXS; ++b) {
+                int rr = lr + b, cc = lc + a;
+                int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
+                bool inside = (rr == rcl) && (cc == ccl);
+                A val = inside ? (A)Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : (A)0;   // zero pad (:208)
+                int64_t ho = rcl * hy + ccl * hx + c * hc;                                             // edge pad (:172-174)
+                A dx = dis_r[i * S + b], dy = dis_c[j * S + a];
+                if (KIND == LERF_KIND_GAUSS) {
+                    float p0 = Loader<TH>::hyper(h0 + ho), p1 = Loader<TH>::hyper(h1 + ho), p2 = Loader<TH>::hyper(h2 + ho);
+                    // float32 parameter formation (:168-170)
+                    float rho = p0 * 2.0f - 1.0f, sx = p1 * (float)max_sigma, sy = p2 * (float)max_sigma;
+                    acc.add_gauss((A)rho, (A)sx, (A)sy, dx, dy, val);
+                } else {
+                    float p0 = Loader<TH>::hyper(h0 + ho);
+                    float alpha = (float)max_sigma * (p0 * 2.0f - 1.0f);
+                    A w = lin_factor<A>((A)alpha, dx, dist_class(dx)) * lin_factor<A>((A)alpha, dy, dist_class(dy));
+                    acc.add_weight(w, val);
+                }
+            }
+        }
+        Storer<TO>::put(out + i * oy + j * ox + c * oc, acc.finish());
+        return;
+    }
+    // generic support size: two passes (min exponent, then accumulate)
+    A emin = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b < S; ++b) {
+                int rr = lr + b, cc = lc + a;
+                int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
+                bool inside = (rr == rcl) && (cc == ccl);
+                int64_t ho = rcl * hy + ccl * hx + c * hc;
+                A dx = dis_r[i * S + b], dy = dis_c[j * S + a];
+                A w;
+                if (KIND == LERF_KIND_GAUSS) {
+                    float p0 = Loader<TH>::hyper(h0 + ho), p1 = Loader<TH>::hyper(h1 + ho), p2 = Loader<TH>::hyper(h2 + ho);
+                    A rho = (A)(p0 * 2.0f - 1.0f), sx = (A)(p1 * (float)max_sigma), sy = (A)(p2 * (float)max_sigma);
+                    A tx = sx * dx, ty = sy * dy;
+                    A e = tx * tx - (A)2 * rho * (tx * ty) + ty * ty;
+                    if (pass == 0) {
+                        emin = (a == 0 && b == 0) ? e : (e < emin ? e : emin);
+                        continue;
+                    }
+                    w = sizeof(A) == 4 ? (A)__expf((float)((A)-0.5 * (e - emin))) : (A)exp((double)((A)-0.5 * (e - emin)));
+                } else {
+                    if (pass == 0) continue;
+                    float p0 = Loader<TH>::hyper(h0 + ho);
+                    A alpha = (A)((float)max_sigma * (p0 * 2.0f - 1.0f));
+                    w = lin_factor<A>(alpha, dx, dist_class(dx)) * lin_factor<A>(alpha, dy, dist_class(dy));
+                }
+                A val = inside ? (A)Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : (A)0;
+                num += w * val;
+                den += w;
+            }
+    }
+    Storer<TO>::put(out + i * oy + j * ox + c * oc, num / den);
+}
+
+template <typename TI, typename TH, typename TO, typename A, int KIND>
+static int resize_dispatch_S(const ResizeArgs& a, hipStream_t st) {
+    dim3 block(256), grid((a.oW * a.C + 255) / 256, a.oH);
+    const A* dr = sizeof(A) == 4 ? (const A*)a.dis_r : (const A*)a.dis_r64;
+    const A* dc = sizeof(A) == 4 ? (const A*)a.dis_c : (const A*)a.dis_c64;
+    if (!dr || !dc) return LERF_EINVAL;
+#define LERF_RS(ST)                                                                                         \
+    hipLaunchKernelGGL((resize_kernel<TI, TH, TO, A, KIND, ST>), grid, block, 0, st, (const TI*)a.feat,     \
+                       a.fy, a.fx, a.fc, (const TH*)a.h[0], (const TH*)a.h[1], (const TH*)a.h[2], a.hy,     \
+                       a.hx, a.hc, a.H, a.W, a.C, a.S, a.oH, a.oW, a.left_r, dr, a.left_c, dc,              \
+                       (A)a.max_sigma, (TO*)a.out, a.oy, a.ox, a.oc)
+    if (a.S == 2) LERF_RS(2);
+    else if (a.S == 4) LERF_RS(4);
+    else LERF_RS(0);
+#undef LERF_RS
+    return LERF_OK;
+}
+
+template <typename TI, typename TH, typename TO, typename A>
+static int resize_dispatch_kind(const ResizeArgs& a, hipStream_t st) {
+    if (a.kind == LERF_KIND_GAUSS) return resize_dispatch_S<TI, TH, TO, A, LERF_KIND_GAUSS>(a, st);
+    if (a.kind == LERF_KIND_LINEAR) return resize_dispatch_S<TI, TH, TO, A, LERF_KIND_LINEAR>(a, st);
+    return LERF_EUNSUPPORTED;
+}
+
+int launch_resize(const ResizeArgs& a, hipStream_t st) {
+    if (a.S < 1 || a.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
+    if (a.in_dtype == LERF_U8 && a.h_dtype == LERF_U8) {
+        if (a.out_dtype == LERF_U8) return resize_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
+        if (a.out_dtype == LERF_F32) return resize_dispatch_kind<uint8_t, uint8_t, float, float>(a, st);
+        if (a.out_dtype == LERF_F64) return resize_dispatch_kind<uint8_t, uint8_t, double, double>(a, st);
+    } else if (a.in_dtype == LERF_F32 && a.h_dtype == LERF_F32) {
+        if (a.out_dtype == LERF_F32) return resize_dispatch_kind<float, float, float, float>(a, st);
+        if (a.out_dtype == LERF_F64) return resize_dispatch_kind<float, float, double, double>(a, st);
+    }
+    return LERF_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// A7/A8: homographic warp, geometry per output pixel in float64
+// ---------------------------------------------------------------------------
+template <typename TI, typename TH, typename TO, typename A, int KIND>
+__global__ void __launch_bounds__(256)
+warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
+            const TH* __restrict__ h0, const TH* __restrict__ h1, const TH* __restrict__ h2,
+            int64_t hy, int64_t hx, int64_t hc, int H, int W, int C, WarpGeo g,
+            A max_sigma, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+    int xc = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (xc >= g.oW * C) return;
+    int j = xc / C;
+    int c = xc - j * C;
+    const int S = g.S;
+    double gr, gc;
+    project_point(g.minv, i, j, H, W, &gr, &gc);
+    int lr = left_boundary(gr, S) + g.pad_r_lo;
+    int lc = left_boundary(gc, S) + g.pad_c_lo;
+    gr += (double)g.pad_r_lo;      // calc_pad_sz shifts grid and field of view (:366-367)
+    gc += (double)g.pad_c_lo;
+    A emin = 0, num = 0, den = 0;
+    for (int pass = (KIND == LERF_KIND_GAUSS ? 0 : 1); pass < 2; ++pass) {
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b < S; ++b) {
+                // field of view clipped to [0, in-1] while indexing the PADDED arrays (:396-398)
+                int pr = clampi(lr + b, 0, H - 1), pc = clampi(lc + a, 0, W - 1);
+                double dxd = gr - (double)pr, dyd = gc - (double)pc;
+                A dx = (A)dxd, dy = (A)dyd;
+                int sr = pr - g.pad_r_lo, sc_ = pc - g.pad_c_lo;       // unpadded source coordinates
+                int rcl = clampi(sr, 0, H - 1), ccl = clampi(sc_, 0, W - 1);
+                bool inside = (sr == rcl) && (sc_ == ccl);
+                int64_t ho = rcl * hy + ccl * hx + c * hc;
+                A w;
+                if (KIND == LERF_KIND_GAUSS) {
+                    float p0 = Loader<TH>::hyper(h0 + ho), p1 = Loader<TH>::hyper(h1 + ho), p2 = Loader<TH>::hyper(h2 + ho);
+                    A rho = (A)(p0 * 2.0f - 1.0f), sx = (A)(p1 * (float)max_sigma), sy = (A)(p2 * (float)max_sigma);
+                    A tx = sx * dx, ty = sy * dy;
+                    A e = tx * tx - (A)2 * rho * (tx * ty) + ty * ty;
+                    if (pass == 0) {
+                        emin = (a == 0 && b == 0) ? e : (e < emin ? e : emin);
+                        continue;
+                    }
+                    w = sizeof(A) == 4 ? (A)__expf((float)((A)-0.5 * (e - emin))) : (A)exp((double)((A)-0.5 * (e - emin)));
+                } else if (KIND == LERF_KIND_LINEAR) {
+                    float p0 = Loader<TH>::hyper(h0 + ho);
+                    A alpha = (A)((float)max_sigma * (p0 * 2.0f - 1.0f));
+                    // class decisions on the float64 distances
+                    w = lin_factor<A>(alpha, dx, dist_class(dxd)) * lin_factor<A>(alpha, dy, dist_class(dyd));
+                } else {
+                    w = (dist_class(dxd) != 0 && dist_class(dyd) != 0) ? (A)1 : (A)0;     // box2d
+                }
+                A val = inside ? (A)Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : (A)0;
+                num += w * val;
+                den += w;
+            }
+    }
+    A res = num / den;
+    if (KIND == LERF_KIND_GAUSS && emin * (A)0.5 > (A)745.2) res = (A)(0.0 / 0.0);
+    Storer<TO>::put(out + i * oy + j * ox + c * oc, res);
+}
+
+template <typename TI, typename TH, typename TO, typename A>
+static int warp_dispatch_kind(const WarpArgs& a, hipStream_t st) {
+    dim3 block(256), grid((a.geo.oW * a.C + 255) / 256, a.geo.oH);
+#define LERF_WP(KIND)                                                                                        \
+    hipLaunchKernelGGL((warp_kernel<TI, TH, TO, A, KIND>), grid, block, 0, st, (const TI*)a.feat, a.fy,      \
+                       a.fx, a.fc, (const TH*)a.h[0], (const TH*)a.h[1], (const TH*)a.h[2], a.hy, a.hx,      \
+                       a.hc, a.H, a.W, a.C, a.geo, (A)a.max_sigma, (TO*)a.out, a.oy, a.ox, a.oc)
+    if (a.kind == LERF_KIND_GAUSS) LERF_WP(LERF_KIND_GAUSS);
+    else if (a.kind == LERF_KIND_LINEAR) LERF_WP(LERF_KIND_LINEAR);
+    else if (a.kind == LERF_KIND_NEAREST) LERF_WP(LERF_KIND_NEAREST);
+    else return LERF_EUNSUPPORTED;
+#undef LERF_WP
+    return LERF_OK;
+}
+
+int launch_warp(const WarpArgs& a, hipStream_t st) {
+    if (a.geo.S < 1 || a.geo.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
+    if (a.in_dtype == LERF_U8 && (a.h_dtype == LERF_U8 || a.kind == LERF_KIND_NEAREST)) {
+        if (a.out_dtype == LERF_U8) return warp_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
+        if (a.out_dtype == LERF_F32) return warp_dispatch_kind<uint8_t, uint8_t, float, float>(a, st);
+        if (a.out_dtype == LERF_F64) return warp_dispatch_kind<uint8_t, uint8_t, double, double>(a, st);
+    } else if (a.in_dtype == LERF_F32 && (a.h_dtype == LERF_F32 || a.kind == LERF_KIND_NEAREST)) {
+        if (a.out_dtype == LERF_F32) return warp_dispatch_kind<float, float, float, float>(a, st);
+        if (a.out_dtype == LERF_F64) return warp_dispatch_kind<float, float, double, double>(a, st);
+    }
+    return LERF_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// stage-2 LUT repack: [17^4][oC] int8 -> uint32 per entry, biased bytes
+//   bits  0.. 7 = e0 + 128, bits 8..15 = e1 + 128, bits 16..23 = e2 + 128
+// (oC = 1: only e0).  The tiled kernels read A = d & 0x00FF00FF (e0 | e2<<16)
+// and B = (d >> 8) & 0xFF and accumulate both fields of A with one 24-bit MAD.
+// ---------------------------------------------------------------------------
+__global__ void lut_pack_kernel(const int8_t* __restrict__ lut, int oC, uint32_t* __restrict__ packed) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= LERF_LUT_ENTRIES) return;
+    uint32_t d = 0;
+    for (int k = 0; k < oC; ++k) d |= (uint32_t)((int)lut[i * oC + k] + 128) << (8 * k);
+    packed[i] = d;
+}
+
+int launch_lut_pack(const int8_t* lut, int oC, uint32_t* packed, hipStream_t st) {
+    if (oC < 1 || oC > 3) return LERF_EUNSUPPORTED;
+    hipLaunchKernelGGL(lut_pack_kernel, dim3((LERF_LUT_ENTRIES + 255) / 256), dim3(256), 0, st, lut, oC, packed);
+    return LERF_OK;
+}
+
+}  // namespace lerf

@@ -1,0 +1,241 @@
+"""Device operators: thin wrappers that hand torch-owned HBM buffers to the
+C ABI on the current HIP stream.  torch is plumbing here (memory, streams);
+all arithmetic happens in liblerf_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KINDS
+
+
+def _torch():
+    return _lib.require_gpu()
+
+
+# --------------------------------------------------------------------------- geometry
+class SrGeometry:
+    """Separable SR geometry (Resize2dNumpy.set_shape, resize_right2d_numpy.py:18-140)
+    as two 1-D tables per axis, resident on the device."""
+
+    def __init__(self, in_hw, scale_factors=None, out_hw=None, support=2, device=None):
+        torch = _torch()
+        H, W = int(in_hw[0]), int(in_hw[1])
+        if out_hw is not None and scale_factors is None:
+            scale_factors = [out_hw[0] / H, out_hw[1] / W]                 # :28-31
+        if not isinstance(scale_factors, (list, tuple)):
+            scale_factors = [scale_factors, scale_factors]                 # :33-37
+        sh, sw = float(scale_factors[0]), float(scale_factors[1])
+        if sh < 1.0 or sw < 1.0:
+            raise NotImplementedError("down-sampling (anti-aliasing, resize_right2d_numpy.py:51-55) is out of scope")
+        if out_hw is None:
+            out_hw = (_lib.out_size(H, sh), _lib.out_size(W, sw))          # :41-45
+        self.in_hw, self.out_hw, self.scales, self.S = (H, W), (int(out_hw[0]), int(out_hw[1])), (sh, sw), int(support)
+        self.device = torch.device(device if device is not None else "cuda")
+        lr, dr64, dr32, pr = _lib.sr_axis_tables(H, self.out_hw[0], sh, self.S)
+        lc, dc64, dc32, pc = _lib.sr_axis_tables(W, self.out_hw[1], sw, self.S)
+        self.pad_vec = ((0, 0), pr, pc)                                     # :129
+        self.host = dict(left_r=lr, dis_r=dr64, left_c=lc, dis_c=dc64)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.t = dict(left_r=up(lr), dis_r=up(dr32), left_c=up(lc), dis_c=up(dc32), dis_r64=up(dr64), dis_c64=up(dc64))
+        g = _lib.SrGeo()
+        g.S, g.out_h, g.out_w = self.S, self.out_hw[0], self.out_hw[1]
+        for k in ("left_r", "dis_r", "left_c", "dis_c", "dis_r64", "dis_c64"):
+            setattr(g, k, self.t[k].data_ptr())
+        self.struct = g
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+class WarpGeometry:
+    """Homography geometry (Warp2dNumpy.set_shape, resize_right2d_numpy.py:292-407)."""
+
+    def __init__(self, in_hw, matrix, out_hw, support=2):
+        m = np.asarray(matrix.detach().cpu().numpy() if hasattr(matrix, "detach") else matrix, dtype=np.float64)
+        if m.shape != (3, 3):
+            raise ValueError("matrix must be 3x3")
+        self.matrix = m
+        self.minv = np.linalg.inv(m)                                       # :327
+        self.in_hw, self.out_hw, self.S = (int(in_hw[0]), int(in_hw[1])), (int(out_hw[0]), int(out_hw[1])), int(support)
+        pads = _lib.warp_pads(self.minv, self.in_hw, self.out_hw, self.S)
+        self.pad_vec = ((0, 0), (pads[0], pads[1]), (pads[2], pads[3]))    # :392
+        g = _lib.WarpGeo()
+        g.S, g.out_h, g.out_w = self.S, self.out_hw[0], self.out_hw[1]
+        for i, v in enumerate(self.minv.reshape(9)):
+            g.minv[i] = float(v)
+        g.pad_r_lo, g.pad_r_hi, g.pad_c_lo, g.pad_c_hi = pads
+        self.struct = g
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+# --------------------------------------------------------------------------- helpers
+def _planes_chw(t):
+    """[N,H,W] contiguous-ish tensor -> Plane with channel = leading dim."""
+    return _lib.plane(t, t.stride(1), t.stride(2), t.stride(0))
+
+
+def _planes_hwc(t):
+    return _lib.plane(t, t.stride(0), t.stride(1), t.stride(2))
+
+
+def _out_dtype(name):
+    torch = _torch()
+    return {"u8": torch.uint8, "f32": torch.float32, "f64": torch.float64}[name]
+
+
+# --------------------------------------------------------------------------- A1
+def lut_interp_i16(img_u8_chw, h, w, dy, dx, lut_i8):
+    """int16 numerators [C,oC,h,w] of one LUT pass (FourSimplexInterpFaster core)."""
+    torch = _torch()
+    if img_u8_chw.dtype != torch.uint8 or img_u8_chw.dim() != 3:
+        raise ValueError("img must be uint8 [C,H,W]")
+    if lut_i8.dtype != torch.int8 or lut_i8.dim() != 2 or lut_i8.shape[0] != _lib.LERF_LUT_ENTRIES:
+        raise ValueError("lut must be int8 [17^4,oC]")
+    img = img_u8_chw.contiguous()
+    lut = lut_i8.contiguous()
+    Cn, Hp, Wp = img.shape
+    oC = lut.shape[1]
+    out = torch.empty((Cn, oC, h, w), dtype=torch.int16, device=img.device)
+    dy = np.ascontiguousarray(dy, dtype=np.int8)
+    dx = np.ascontiguousarray(dx, dtype=np.int8)
+    p = _planes_chw(img)
+    _lib.check(_lib.lib().lerf_lut_interp_i16(C.byref(p), Hp, Wp, Cn, int(h), int(w), dy.ctypes.data, dx.ctypes.data,
+                                              lut.data_ptr(), oC, out.data_ptr(), _lib.current_stream()),
+               "lerf_lut_interp_i16")
+    return out
+
+
+# --------------------------------------------------------------------------- A2/A3
+def lut_stages(img_u8_hwc, luts):
+    """uint8 [H,W,C] -> (feat uint8 [H,W,C], hq uint8 [H,W,C,oC])."""
+    torch = _torch()
+    if img_u8_hwc.dtype != torch.uint8 or img_u8_hwc.dim() != 3:
+        raise ValueError("img must be uint8 [H,W,C]")
+    img = img_u8_hwc.contiguous()
+    H, W, Cn = img.shape
+    feat = torch.empty_like(img)
+    hq = torch.empty((H, W, Cn, luts.oC), dtype=torch.uint8, device=img.device)
+    pi = _planes_hwc(img)
+    pf = _planes_hwc(feat)
+    ph = _lib.plane(hq, hq.stride(0), hq.stride(1), hq.stride(2))
+    _lib.check(_lib.lib().lerf_lut_stages_u8(C.byref(pi), H, W, Cn, luts.ref(), C.byref(pf), C.byref(ph),
+                                             _lib.current_stream()), "lerf_lut_stages_u8")
+    return feat, hq
+
+
+# --------------------------------------------------------------------------- A5/A6/A8
+def _hyper_planes(hyper, layout, nh):
+    arr = (_lib.Plane * 3)()
+    keep = []
+    if layout == "hwck":          # one uint8 tensor [H,W,C,oC]
+        hq = hyper
+        for k in range(3):
+            arr[k] = _lib.plane(hq, hq.stride(0), hq.stride(1), hq.stride(2), offset=(k if k < nh else 0) * hq.stride(3))
+        keep.append(hq)
+    else:                          # separate planar [N,H,W] tensors with identical strides
+        for k in range(3):
+            t = hyper[k if k < nh else 0]
+            arr[k] = _planes_chw(t)
+        keep.extend(hyper)
+    return arr, keep
+
+
+def resize_hwc_u8(feat_u8, hq_u8, geo: SrGeometry, kind="gauss", max_sigma=10.0, out="u8"):
+    """stage 3 on the uint8 stage outputs: feat [H,W,C], hq [H,W,C,oC] -> [oH,oW,C]."""
+    torch = _torch()
+    feat = feat_u8.contiguous()
+    hq = hq_u8.contiguous()
+    H, W, Cn = feat.shape
+    nh = 3 if kind == "gauss" else 1
+    if hq.shape[:3] != feat.shape or hq.shape[3] < nh:
+        raise ValueError("hyper shape mismatch")
+    o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=feat.device)
+    pf = _planes_hwc(feat)
+    ph, _keep = _hyper_planes(hq, "hwck", nh)
+    po = _planes_hwc(o)
+    _lib.check(_lib.lib().lerf_resize(C.byref(pf), ph, H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
+                                      C.byref(po), _lib.current_stream()), "lerf_resize")
+    return o
+
+
+def resize_planar(feat, hypers, geo: SrGeometry, kind="gauss", max_sigma=10.0, out="f32"):
+    """stage 3 on planar float32 maps: feat [N,H,W], hypers = list of [N,H,W] in [0,1] -> [N,oH,oW]."""
+    torch = _torch()
+    feat = feat.contiguous().float()
+    nh = 3 if kind == "gauss" else 1
+    hypers = [h.contiguous().float() for h in hypers[:nh]]
+    for h in hypers:
+        if h.shape != feat.shape:
+            raise ValueError("hyper maps must have the shape of the input")
+    N, H, W = feat.shape
+    o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
+    pf = _planes_chw(feat)
+    ph, _keep = _hyper_planes(hypers, "planar", nh)
+    po = _planes_chw(o)
+    _lib.check(_lib.lib().lerf_resize(C.byref(pf), ph, H, W, N, geo.ref(), KINDS[kind], float(max_sigma),
+                                      C.byref(po), _lib.current_stream()), "lerf_resize")
+    return o
+
+
+def warp_hwc_u8(feat_u8, hq_u8, geo: WarpGeometry, kind="gauss", max_sigma=10.0, out="u8"):
+    torch = _torch()
+    feat = feat_u8.contiguous()
+    H, W, Cn = feat.shape
+    nh = {"gauss": 3, "linear": 1, "nearest": 0}[kind]
+    o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=feat.device)
+    pf = _planes_hwc(feat)
+    if nh:
+        hq = hq_u8.contiguous()
+        ph, _keep = _hyper_planes(hq, "hwck", nh)
+    else:
+        ph = None
+    po = _planes_hwc(o)
+    _lib.check(_lib.lib().lerf_warp(C.byref(pf), ph, H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
+                                    C.byref(po), _lib.current_stream()), "lerf_warp")
+    return o
+
+
+def warp_planar(feat, hypers, geo: WarpGeometry, kind="gauss", max_sigma=10.0, out="f32"):
+    torch = _torch()
+    feat = feat.contiguous().float()
+    nh = {"gauss": 3, "linear": 1, "nearest": 0}[kind]
+    N, H, W = feat.shape
+    o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
+    pf = _planes_chw(feat)
+    if nh:
+        hypers = [h.contiguous().float() for h in hypers[:nh]]
+        ph, _keep = _hyper_planes(hypers, "planar", nh)
+    else:
+        ph = None
+    po = _planes_chw(o)
+    _lib.check(_lib.lib().lerf_warp(C.byref(pf), ph, H, W, N, geo.ref(), KINDS[kind], float(max_sigma),
+                                    C.byref(po), _lib.current_stream()), "lerf_warp")
+    return o
+
+
+# --------------------------------------------------------------------------- fused SR
+def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out=None, workspace=None):
+    """uint8 [H,W,C] or [N,H,W,C] -> uint8 [oH,oW,C] / [N,oH,oW,C]; one launch per call."""
+    torch = _torch()
+    if img_u8.dtype != torch.uint8:
+        raise ValueError("img must be uint8")
+    squeeze = img_u8.dim() == 3
+    img = (img_u8.unsqueeze(0) if squeeze else img_u8).contiguous()
+    N, H, W, Cn = img.shape
+    if (H, W) != geo.in_hw:
+        raise ValueError("geometry was built for another input size")
+    if out is None:
+        out = torch.empty((N, geo.out_hw[0], geo.out_hw[1], Cn), dtype=torch.uint8, device=img.device)
+    need = _lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(int(need), 1), dtype=torch.uint8, device=img.device)
+    _lib.check(_lib.lib().lerf_sr_fused_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(), geo.ref(),
+                                           KINDS[kind], float(max_sigma), out.data_ptr(), out.stride(0),
+                                           workspace.data_ptr(), _lib.current_stream()), "lerf_sr_fused_u8")
+    return out[0] if squeeze else out

@@ -1,0 +1,121 @@
+"""End-to-end LUT pipelines: the counterpart of `eltr._worker` in the
+reference's resample/eval_lut_sr.py:514-665 (SR) and
+resample/eval_lut_warp.py:70-222 (homographic warp), uint8 in -> uint8 out,
+everything between staying on the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib, ops
+from .luts import LutSet
+
+
+class LerfEngine:
+    """One model's LUTs resident in HBM + cached geometry per shape.
+
+    support / max_sigma follow common/option.py:25,29 (suppSize=2, maxSigma=10);
+    LeRF-L (`linear=True`) always runs S=2, max_sigma=1 because the reference
+    harness builds AmplifiedLinearResize2dNumpy() with its defaults
+    (eval_lut_sr.py:482-484, eval_lut_warp.py:37-39).
+    """
+
+    def __init__(self, luts: LutSet, support=2, max_sigma=10.0):
+        self.luts = luts
+        self.linear = luts.oC == 1
+        self.kind = "linear" if self.linear else "gauss"
+        self.support = 2 if self.linear else int(support)
+        self.max_sigma = 1.0 if self.linear else float(max_sigma)
+        self._sr_geo = {}
+        self._ws = None
+
+    @classmethod
+    def shipped(cls, name="lerf-g", **kw):
+        return cls(LutSet.shipped(name), **kw)
+
+    # -- helpers
+    def _dev(self, img):
+        torch = _lib.require_gpu()
+        if isinstance(img, torch.Tensor):
+            return img.to(self.luts.device), False
+        a = np.ascontiguousarray(np.asarray(img))
+        if a.dtype != np.uint8:
+            raise ValueError("images are uint8 HWC")
+        return torch.from_numpy(a).to(self.luts.device), True
+
+    def sr_geometry(self, in_hw, scale):
+        if not isinstance(scale, (list, tuple)):
+            scale = (scale, scale)
+        key = (int(in_hw[0]), int(in_hw[1]), float(scale[0]), float(scale[1]), self.support)
+        if key not in self._sr_geo:
+            self._sr_geo[key] = ops.SrGeometry(in_hw, list(scale), None, self.support, self.luts.device)
+        return self._sr_geo[key]
+
+    # -- stages 1+2
+    def stages(self, img):
+        x, as_np = self._dev(img)
+        feat, hq = ops.lut_stages(x, self.luts)
+        return (feat.cpu().numpy(), hq.cpu().numpy()) if as_np else (feat, hq)
+
+    # -- SR
+    def sr(self, img, scale, fused=True):
+        """uint8 [H,W,C] (or [N,H,W,C]) -> uint8 [ceil(sh*H), ceil(sw*W), C]."""
+        x, as_np = self._dev(img)
+        hw = x.shape[-3:-1]
+        geo = self.sr_geometry(hw, scale)
+        if fused:
+            out = ops.sr_fused_u8(x, self.luts, geo, self.kind, self.max_sigma)
+        else:
+            if x.dim() != 3:
+                raise ValueError("unfused path takes one frame")
+            feat, hq = ops.lut_stages(x, self.luts)
+            out = ops.resize_hwc_u8(feat, hq, geo, self.kind, self.max_sigma, out="u8")
+        return out.cpu().numpy() if as_np else out
+
+    def sr_float(self, img, scale):
+        """float32 [oH,oW,C] before the final rounding (for tolerance checks)."""
+        x, as_np = self._dev(img)
+        geo = self.sr_geometry(x.shape[:2], scale)
+        feat, hq = ops.lut_stages(x, self.luts)
+        out = ops.resize_hwc_u8(feat, hq, geo, self.kind, self.max_sigma, out="f32")
+        return out.cpu().numpy() if as_np else out
+
+    # -- homographic warp
+    def warp(self, img, matrix, out_hw, border=4, return_mask=True, out="u8"):
+        """uint8 [H,W,C] -> (uint8 [oH,oW,C], bool mask [oH,oW,C]).
+
+        mask = validity mask of eval_lut_warp.py:197-204,229 (nearest warp of a
+        white frame with a `border`-px black rim, == 255)."""
+        torch = _lib.require_gpu()
+        x, as_np = self._dev(img)
+        H, W, Cn = x.shape
+        geo = ops.WarpGeometry((H, W), matrix, out_hw, self.support)
+        feat, hq = ops.lut_stages(x, self.luts)
+        o = ops.warp_hwc_u8(feat, hq, geo, self.kind, self.max_sigma, out=out)
+        mask = None
+        if return_mask:
+            white = torch.zeros((H, W, Cn), dtype=torch.uint8, device=x.device)
+            white[border:H - border, border:W - border] = 255
+            ngeo = ops.WarpGeometry((H, W), matrix, out_hw, 1)
+            mask = ops.warp_hwc_u8(white, None, ngeo, "nearest", 1.0, out="f32") == 255
+        if as_np:
+            return o.cpu().numpy(), (mask.cpu().numpy() if mask is not None else None)
+        return o, mask
+
+
+_ENGINES = {}
+
+
+def _engine(model, support, max_sigma):
+    key = (model, support, max_sigma)
+    if key not in _ENGINES:
+        _ENGINES[key] = LerfEngine.shipped(model, support=support, max_sigma=max_sigma)
+    return _ENGINES[key]
+
+
+def sr(img_u8_hwc, scale, model="lerf-g", support=2, max_sigma=10.0):
+    return _engine(model, support, max_sigma).sr(img_u8_hwc, scale)
+
+
+def warp(img_u8_hwc, matrix, out_hw, model="lerf-g", support=2, max_sigma=10.0):
+    return _engine(model, support, max_sigma).warp(img_u8_hwc, matrix, out_hw)

@@ -1,0 +1,138 @@
+"""numpy-facing resampler classes: drop-in for the LeRF classes of the
+reference's resize_right/resize_right2d_numpy.py (same names, constructor
+arguments, set_shape/resize/warp signatures, float64 [C,oH,oW] results).
+
+Inputs are numpy arrays; they are staged to the MI355X, resampled by the HIP
+kernels in float64 arithmetic (LERF_F64 outputs) and copied back.  There is no
+CPU implementation here.
+"""
+from __future__ import annotations
+
+from math import ceil
+
+import numpy as np
+
+from .. import _lib, ops
+
+
+def _to_dev(a):
+    torch = _lib.require_gpu()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).cuda()
+
+
+class Resize2dNumpy(object):
+    """Geometry holder (reference: resize_right2d_numpy.py:10-140)."""
+
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
+        if pad_mode != "constant":
+            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self.eps = np.finfo(np.float32).eps
+        self.device = device
+        self.support_sz = support_sz
+        self.pad_mode = pad_mode
+        self.antialias = False
+
+    def set_shape(self, in_shape, scale_factors=None, out_shape=None):
+        in_shape = list(in_shape)                       # [C, H, W]
+        if len(in_shape) != 3:
+            raise ValueError("in_shape must be [C, H, W]")
+        out_hw = None
+        if out_shape is not None:                       # :26-31
+            out_shape = list(out_shape) + list(in_shape[len(out_shape):])
+            out_hw = (out_shape[1], out_shape[2])
+            if scale_factors is None:
+                scale_factors = [o / i for o, i in zip(out_shape, in_shape)][1:]
+        if scale_factors is None:
+            raise ValueError("either scale_factors or out_shape is required")
+        if not isinstance(scale_factors, (list, tuple)):
+            scale_factors = [scale_factors, scale_factors]
+        scale_factors = [1] * (3 - len(scale_factors)) + list(scale_factors)
+        self.in_shape = in_shape
+        self.scale_factors = [float(s) for s in scale_factors]
+        self.geo = ops.SrGeometry(in_shape[1:], self.scale_factors[1:], out_hw, self.support_sz)
+        self.out_shape = [ceil(self.scale_factors[0] * in_shape[0]), self.geo.out_hw[0], self.geo.out_hw[1]]
+        self.in_sz = [in_shape[1], in_shape[2]]
+        self.out_sz = [self.geo.out_hw[0], self.geo.out_hw[1]]
+        self.pad_vec = self.geo.pad_vec
+
+    def _run(self, kind, input, hypers, max_sigma):
+        x = _to_dev(input)
+        if list(x.shape) != list(self.in_shape):
+            raise ValueError("input shape {} does not match set_shape({})".format(list(x.shape), self.in_shape))
+        hs = [_to_dev(h) for h in hypers]
+        out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f64")
+        return out.cpu().numpy()
+
+
+class SteeringGaussianResize2dNumpy(Resize2dNumpy):
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant", max_sigma=10):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def resize(self, input, rho, sigma_x, sigma_y):
+        return self._run("gauss", input, [rho, sigma_x, sigma_y], self.max_sigma)
+
+
+class AmplifiedLinearResize2dNumpy(Resize2dNumpy):
+    def __init__(self, support_sz=2, device="CPU", pad_mode="constant", max_sigma=1):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def resize(self, input, alpha):
+        return self._run("linear", input, [alpha], self.max_sigma)
+
+
+class Warp2dNumpy(object):
+    """Homography geometry holder (reference: resize_right2d_numpy.py:284-407)."""
+    kind = None
+
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
+        if pad_mode != "constant":
+            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self.eps = np.finfo(np.float32).eps
+        self.device = device
+        self.support_sz = support_sz
+        self.pad_mode = pad_mode
+        self.antialias = False
+
+    def set_shape(self, in_shape, matrix, out_shape):
+        in_shape = list(in_shape)
+        out_shape = list(out_shape) + list(in_shape[len(out_shape):])      # :301
+        self.in_shape, self.out_shape, self.matrix = in_shape, out_shape, matrix
+        self.in_sz = [in_shape[1], in_shape[2]]
+        self.out_sz = [out_shape[1], out_shape[2]]
+        self.geo = ops.WarpGeometry(self.in_sz, matrix, self.out_sz, self.support_sz)
+        self.pad_vec = self.geo.pad_vec
+
+    def _run(self, kind, input, hypers, max_sigma):
+        x = _to_dev(input)
+        if list(x.shape) != list(self.in_shape):
+            raise ValueError("input shape {} does not match set_shape({})".format(list(x.shape), self.in_shape))
+        hs = [_to_dev(h) for h in hypers]
+        return ops.warp_planar(x, hs, self.geo, kind, max_sigma, out="f64").cpu().numpy()
+
+
+class NearestWarp2dNumpy(Warp2dNumpy):
+    def __init__(self, support_sz=1, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+    def warp(self, input):
+        return self._run("nearest", input, [], 1.0)
+
+
+class SteeringGaussianWarp2dNumpy(Warp2dNumpy):
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant", max_sigma=10):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def warp(self, input, rho, sigma_x, sigma_y):
+        return self._run("gauss", input, [rho, sigma_x, sigma_y], self.max_sigma)
+
+
+class AmplifiedLinearWarp2dNumpy(Warp2dNumpy):
+    def __init__(self, support_sz=2, device="CPU", pad_mode="constant", max_sigma=1):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def warp(self, input, alpha):
+        return self._run("linear", input, [alpha], self.max_sigma)

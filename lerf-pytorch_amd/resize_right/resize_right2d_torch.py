@@ -1,0 +1,145 @@
+"""torch-facing resampler classes: drop-in for the LeRF classes of the
+reference's resize_right/resize_right2d_torch.py ([B,C,H,W] tensors on the GPU).
+
+Geometry follows the normative numpy path (float64 on the host, see
+resize_right2d_numpy.py:57-140); SR returns float32, warps return float64 like
+the reference (its warp distances are double, resize_right2d_torch.py:286-296).
+Forward only: these operators carry no autograd graph.
+"""
+from __future__ import annotations
+
+from math import ceil
+
+import torch
+
+from .. import _lib, ops
+
+
+def _check_dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("{} must be a tensor on the GPU (there is no CPU path)".format(name))
+
+
+class Resize2dTorch(object):
+    def __init__(self, support_sz=4, device="GPU", pad_mode="constant"):
+        if pad_mode != "constant":
+            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self.eps = torch.finfo(torch.float32).eps
+        self.device = device
+        self.init_support_sz = support_sz
+        self.pad_mode = pad_mode
+        self.antialias = False
+
+    def set_shape(self, in_shape, scale_factors=None, out_shape=None):
+        self.support_sz = self.init_support_sz                 # :19
+        in_shape = list(in_shape)
+        if len(in_shape) != 4:
+            raise ValueError("in_shape must be [B, C, H, W]")
+        out_hw = None
+        if out_shape is not None:                              # :26-29
+            out_shape = list(in_shape[:-len(out_shape)]) + list(out_shape)
+            out_hw = (out_shape[2], out_shape[3])
+            if scale_factors is None:
+                scale_factors = [o / i for o, i in zip(out_shape, in_shape)][2:]
+        if scale_factors is None:
+            raise ValueError("either scale_factors or out_shape is required")
+        if not isinstance(scale_factors, (list, tuple)):
+            scale_factors = [scale_factors, scale_factors]
+        scale_factors = [1] * (4 - len(scale_factors)) + list(scale_factors)
+        self.in_shape = in_shape
+        self.scale_factors = [float(s) for s in scale_factors]
+        self.geo = ops.SrGeometry(in_shape[2:], self.scale_factors[2:], out_hw, self.support_sz)
+        self.out_shape = [ceil(self.scale_factors[0] * in_shape[0]), ceil(self.scale_factors[1] * in_shape[1]),
+                          self.geo.out_hw[0], self.geo.out_hw[1]]
+        pr, pc = self.geo.pad_vec[1], self.geo.pad_vec[2]
+        self.pad_vec = [pr[0], pr[1], pc[0], pc[1]]            # the reference's ordering (:93-95)
+
+    def _run(self, kind, input, hypers, max_sigma):
+        _check_dev(input, "input")
+        B, Cn, H, W = input.shape
+        if [H, W] != list(self.in_shape[2:]):
+            raise ValueError("input shape does not match set_shape")
+        x = input.reshape(B * Cn, H, W)
+        hs = []
+        for h in hypers:
+            _check_dev(h, "hyper-parameter map")
+            hs.append(h.reshape(B * Cn, H, W))
+        out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f32")
+        return out.reshape(B, Cn, self.geo.out_hw[0], self.geo.out_hw[1])
+
+
+class SteeringGaussianResize2dTorch(Resize2dTorch):
+    def __init__(self, support_sz=4, device="GPU", pad_mode="constant", max_sigma=10):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def resize(self, input, rho, sigma_x, sigma_y):
+        return self._run("gauss", input, [rho, sigma_x, sigma_y], self.max_sigma)
+
+
+class AmplifiedLinearResize2dTorch(Resize2dTorch):
+    def __init__(self, support_sz=2, device="GPU", pad_mode="constant", max_sigma=1):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def resize(self, input, alpha):
+        return self._run("linear", input, [alpha], self.max_sigma)
+
+
+class Warp2dTorch(object):
+    def __init__(self, support_sz=4, device="GPU", pad_mode="constant"):
+        if pad_mode != "constant":
+            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self.eps = torch.finfo(torch.float32).eps
+        self.device = device
+        self.support_sz = support_sz
+        self.pad_mode = pad_mode
+
+    def set_shape(self, in_shape, matrix, out_shape):
+        in_shape = list(in_shape)
+        out_shape = list(out_shape) + list(in_shape[len(out_shape):])      # :263
+        self.in_shape, self.out_shape, self.matrix = in_shape, out_shape, matrix
+        self.in_sz = [in_shape[2], in_shape[3]]
+        self.out_sz = [out_shape[2], out_shape[3]]
+        self.geo = ops.WarpGeometry(self.in_sz, matrix, self.out_sz, self.support_sz)
+        pr, pc = self.geo.pad_vec[1], self.geo.pad_vec[2]
+        self.pad_vec = [pc[0], pc[1], pr[0], pr[1]]                         # last dim first (:330-332)
+
+    def _run(self, kind, input, hypers, max_sigma):
+        _check_dev(input, "input")
+        B, Cn, H, W = input.shape
+        if [H, W] != list(self.in_sz):
+            raise ValueError("input shape does not match set_shape")
+        x = input.reshape(B * Cn, H, W)
+        hs = []
+        for h in hypers:
+            _check_dev(h, "hyper-parameter map")
+            hs.append(h.reshape(B * Cn, H, W))
+        out = ops.warp_planar(x, hs, self.geo, kind, max_sigma, out="f64")
+        return out.reshape(B, Cn, self.out_sz[0], self.out_sz[1])
+
+
+class NearestWarp2dTorch(Warp2dTorch):
+    def __init__(self, support_sz=1, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+    def warp(self, input):
+        return self._run("nearest", input, [], 1.0)
+
+
+class SteeringGaussianWarp2dTorch(Warp2dTorch):
+    def __init__(self, support_sz=4, device="GPU", pad_mode="constant", max_sigma=10):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def warp(self, input, rho, sigma_x, sigma_y):
+        return self._run("gauss", input, [rho, sigma_x, sigma_y], self.max_sigma)
+
+
+class AmplifiedLinearWarp2dTorch(Warp2dTorch):
+    def __init__(self, support_sz=2, device="GPU", pad_mode="constant", max_sigma=1):
+        super().__init__(support_sz, device, pad_mode)
+        self.max_sigma = max_sigma
+
+    def warp(self, input, alpha):
+        return self._run("linear", input, [alpha], self.max_sigma)

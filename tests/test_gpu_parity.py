@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and
+the reference-generated golden vectors.  Run with `-m gpu` on an MI355X.
+
+Tolerances
+  * LUT stages (integer):            bit-exact
+  * stage 3, float64 outputs:        <= 1e-9 absolute (0..255 scale)
+  * stage 3, float32 outputs:        <= 2.55e-2 absolute (= 1e-4 of the 255 range, north_star's fp32 bound);
+                                     the observed maximum is also asserted to stay below 5e-4
+  * uint8 outputs:                   <= 1 LSB, and the Set5 md5s of the reference must match exactly
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import DATA, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2.55e-2
+F32_OBSERVED = 5e-4
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "GPU tests need an MI355X"
+    return t
+
+
+@pytest.fixture(scope="module")
+def eng_g(torch):
+    import lerf_pytorch_amd as L
+    return L.LerfEngine.shipped("lerf-g")
+
+
+@pytest.fixture(scope="module")
+def eng_l(torch):
+    import lerf_pytorch_amd as L
+    return L.LerfEngine.shipped("lerf-l")
+
+
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+G1_INPUTS = ["noise24x20", "noise33x47", "baby64", "tiny5x6", "extremes8x8"]
+
+
+@pytest.mark.parametrize("name", G1_INPUTS)
+@pytest.mark.parametrize("model", ["lerf-g", "lerf-l"])
+def test_lut_stages_golden_bit_exact(golden, eng_g, eng_l, model, name):
+    g = golden("g1_lut_stages.npz")
+    eng = eng_g if model == "lerf-g" else eng_l
+    feat, hq = eng.stages(g["%s/%s/img" % (model, name)])
+    assert np.array_equal(feat, g["%s/%s/feat" % (model, name)])
+    assert np.array_equal(hq, g["%s/%s/hq" % (model, name)])
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 3), (2, 3, 3), (7, 1, 3), (64, 64, 1), (97, 131, 3), (256, 256, 3)])
+def test_lut_stages_random_vs_oracle(oracle, luts_g, luts_l, eng_g, eng_l, shape):
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    for eng, luts, oC in ((eng_g, luts_g, 3), (eng_l, luts_l, 1)):
+        feat, hq = eng.stages(img)
+        of, oh = oracle.lut_stages(img, luts, oC)
+        assert np.array_equal(feat, of)
+        assert np.array_equal(hq, oh)
+
+
+def test_four_simplex_interp_mirror(golden, luts_g):
+    """FourSimplexInterpFaster drop-in == the reference's raw per-pass outputs."""
+    from lerf_pytorch_amd.resample.eval_lut_sr import FourSimplexInterpFaster, mode_pad_dict
+    g = golden("g1_lut_stages.npz")
+    img = g["lerf-g/noise24x20/img"].astype(np.float32)
+    feat = g["lerf-g/noise24x20/feat"].astype(np.float32)
+    for stage, src in ((1, img), (2, feat)):
+        for mode in "sct":
+            pad = mode_pad_dict[mode]
+            for r in range(4):
+                key = "s1_%sr0" % mode if stage == 1 else "s2_%sr%d" % (mode, r & 1)
+                oC = 1 if stage == 1 else 3
+                rot = np.rot90(src, r)
+                h, w, _ = rot.shape
+                img_in = np.pad(rot, ((0, pad), (0, pad), (0, 0)), mode="edge").transpose((2, 0, 1))
+                out = FourSimplexInterpFaster(luts_g[key].astype(np.float32), img_in, h, w, 4, 4 - r,
+                                              upscale=1, mode=mode, oC=oC)
+                assert out.dtype == np.float64 and out.shape == (3 * oC, 24, 20)
+                ref = g["lerf-g/noise24x20/raw/s%d_%s_r%d" % (stage, mode, r)]      # [H,W,C,oC] x16
+                ref = ref.transpose(2, 3, 0, 1).reshape(3 * oC, 24, 20) / 16.0
+                assert np.array_equal(out, ref)
+    with pytest.raises(ValueError, match="Mode q not implemented."):
+        FourSimplexInterpFaster(luts_g["s1_sr0"], np.zeros((3, 5, 5), np.float32), 4, 4, 4, 0, mode="q")
+
+
+@pytest.mark.parametrize("ci", range(8))
+def test_sr_gauss_numpy_class_vs_golden(golden, ci):
+    from lerf_pytorch_amd.resize_right.resize_right2d_numpy import SteeringGaussianResize2dNumpy
+    g = golden("g23_sr.npz")
+    H, W, sh, sw, S = g["gauss/%d/cfg" % ci]
+    feat = g["gauss/%d/feat" % ci].astype(np.float32)
+    h = g["gauss/%d/hq" % ci].astype(np.float32) / np.float32(255)
+    r = SteeringGaussianResize2dNumpy(support_sz=int(S), max_sigma=10)
+    r.set_shape([3, int(H), int(W)], scale_factors=[sh, sw])
+    assert [list(p) for p in r.pad_vec[1:]] == [list(g["gauss/%d/pad" % ci][:2]), list(g["gauss/%d/pad" % ci][2:])]
+    out = r.resize(feat, h[0], h[1], h[2])
+    ref = g["gauss/%d/out" % ci]
+    assert out.dtype == np.float64 and out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) <= 1e-9
+
+
+@pytest.mark.parametrize("ci", [0, 2, 3, 4, 5, 6])
+def test_sr_linear_numpy_class_vs_golden(golden, ci):
+    from lerf_pytorch_amd.resize_right.resize_right2d_numpy import AmplifiedLinearResize2dNumpy
+    g = golden("g23_sr.npz")
+    H, W, sh, sw, S = g["gauss/%d/cfg" % ci]
+    feat = g["gauss/%d/feat" % ci].astype(np.float32)
+    h = g["gauss/%d/hq" % ci].astype(np.float32) / np.float32(255)
+    r = AmplifiedLinearResize2dNumpy()
+    r.set_shape([3, int(H), int(W)], scale_factors=[sh, sw])
+    out = r.resize(feat, h[0])
+    np.testing.assert_allclose(out, g["linear/%d/out" % ci], rtol=0, atol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("ci", range(8))
+@pytest.mark.parametrize("kind", ["gauss", "linear"])
+def test_sr_float32_and_uint8_vs_golden(torch, golden, ci, kind):
+    """the uint8-input production kernels (float32 arithmetic) against the float64 reference."""
+    from lerf_pytorch_amd import ops
+    g = golden("g23_sr.npz")
+    H, W, sh, sw, S = g["gauss/%d/cfg" % ci]
+    if kind == "linear" and int(S) != 2:
+        pytest.skip("LeRF-L is S=2 only")
+    feat = torch.from_numpy(g["gauss/%d/feat" % ci].transpose(1, 2, 0).copy()).cuda()            # HWC
+    hq = torch.from_numpy(g["gauss/%d/hq" % ci].transpose(2, 3, 1, 0).copy()).cuda()             # [H,W,C,k]
+    geo = ops.SrGeometry((int(H), int(W)), [sh, sw], None, int(S))
+    ms = 10 if kind == "gauss" else 1
+    ref = (g["gauss/%d/out" % ci] if kind == "gauss" else g["linear/%d/out" % ci]).transpose(1, 2, 0)
+    o32 = ops.resize_hwc_u8(feat, hq, geo, kind, ms, out="f32").cpu().numpy()
+    err = np.max(np.abs(o32 - ref))
+    assert err <= F32_TOL and err <= F32_OBSERVED, err
+    o8 = ops.resize_hwc_u8(feat, hq, geo, kind, ms, out="u8").cpu().numpy()
+    r8 = np.clip(np.round(ref), 0, 255).astype(np.uint8)
+    assert np.max(np.abs(o8.astype(int) - r8.astype(int))) <= 1
+    o64 = ops.resize_hwc_u8(feat, hq, geo, kind, ms, out="f64").cpu().numpy()
+    assert np.max(np.abs(o64 - ref)) <= 1e-9
+
+
+def test_sr_torch_class_vs_reference_torch_path(torch, golden):
+    """secondary oracle: fp32 outputs of the reference's SteeringGaussianResize2dTorch."""
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch
+    g = golden("g6_torch.npz")
+    for ci in range(3):
+        H, W, s = g["%d/cfg" % ci]
+        feat = torch.from_numpy(g["%d/feat" % ci].astype(np.float32)).cuda()
+        h = torch.from_numpy(g["%d/hq" % ci].astype(np.float32) / np.float32(255)).cuda()
+        r = SteeringGaussianResize2dTorch(support_sz=2, device=torch.device("cuda"), max_sigma=10)
+        r.set_shape([2, 1, int(H), int(W)], scale_factors=[s, s])
+        out = r.resize(feat, h[0], h[1], h[2])
+        assert out.dtype == torch.float32 and out.is_cuda
+        ref = g["%d/out" % ci]
+        assert out.shape == ref.shape
+        # the reference's own fp32 path (float32 geometry, resize_right2d_torch.py:60-62) deviates from its
+        # float64 numpy path by 1.3e-4 (x2), 1.5e-4 (x4) and 2.6e-3 (x2.5) on these inputs (measured with
+        # the oracle); the numpy path is normative, so this check only bounds the distance to the twin.
+        assert np.max(np.abs(out.cpu().numpy() - ref)) <= (5e-4, 5e-4, 5e-3)[ci]
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_warp_classes_vs_golden(golden, p):
+    from lerf_pytorch_amd.resize_right.resize_right2d_numpy import (
+        AmplifiedLinearWarp2dNumpy, NearestWarp2dNumpy, SteeringGaussianWarp2dNumpy)
+    g = golden("g4_warp.npz")
+    M = g["%s/matrix" % p]
+    feat = g["%s/feat" % p].astype(np.float32)
+    h = g["%s/hq" % p].astype(np.float32) / np.float32(255)
+    for S in (2, 4):
+        w = SteeringGaussianWarp2dNumpy(support_sz=S, max_sigma=10)
+        w.set_shape([3, 52, 52], M, [3, 60, 70])
+        assert [w.pad_vec[1][0], w.pad_vec[1][1], w.pad_vec[2][0], w.pad_vec[2][1]] == list(g["%s/60x70/S%d/pad" % (p, S)])
+        out = w.warp(feat, h[0], h[1], h[2])
+        np.testing.assert_allclose(out, g["%s/60x70/S%d/gauss" % (p, S)], rtol=0, atol=1e-9, equal_nan=True)
+    wl = AmplifiedLinearWarp2dNumpy()
+    wl.set_shape([3, 52, 52], M, [3, 60, 70])
+    np.testing.assert_allclose(wl.warp(feat, h[0]), g["%s/60x70/linear" % p], rtol=0, atol=1e-9, equal_nan=True)
+    nn = NearestWarp2dNumpy()
+    white = np.zeros((3, 52, 52), np.float32)
+    white[:, 4:48, 4:48] = 255
+    for hw in ((60, 70), (344, 228)):
+        nn.set_shape([3, 52, 52], M, [3, hw[0], hw[1]])
+        mo = nn.warp(white)
+        assert np.array_equal(mo == 255, g["%s/%dx%d/mask" % (p, hw[0], hw[1])])
+    nn.set_shape([3, 52, 52], M, [3, 60, 70])
+    np.testing.assert_allclose(nn.warp(white), g["%s/60x70/nearest" % p], rtol=0, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_warp_float32_vs_golden(torch, golden, p):
+    from lerf_pytorch_amd import ops
+    g = golden("g4_warp.npz")
+    M = g["%s/matrix" % p]
+    feat = torch.from_numpy(g["%s/feat" % p].transpose(1, 2, 0).copy()).cuda()
+    hq = torch.from_numpy(g["%s/hq" % p].transpose(2, 3, 1, 0).copy()).cuda()
+    geo = ops.WarpGeometry((52, 52), M, (344, 228), 2)
+    o = ops.warp_hwc_u8(feat, hq, geo, "gauss", 10, out="f32").cpu().numpy()
+    ref = g["%s/344x228/S2/gauss_f32" % p].transpose(1, 2, 0)
+    assert np.array_equal(np.isnan(o), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.max(np.abs(o[ok] - ref[ok])) <= F32_OBSERVED
+
+
+SET5 = ["baby", "bird", "butterfly", "head", "woman"]
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("scale", [2, 3, 4])
+@pytest.mark.parametrize("model", ["lerf-g", "lerf-l"])
+def test_set5_sr_md5_and_psnr(oracle, eng_g, eng_l, model, scale, fused):
+    """End-to-end known answers: md5 of the reference's uint8 outputs and the
+    scripts.sh PSNR table (35.71/32.02/30.15 and 34.84/30.72/29.13)."""
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["sr"]
+    published = {"lerf-g": {2: 35.71, 3: 32.02, 4: 30.15}, "lerf-l": {2: 34.84, 3: 30.72, 4: 29.13}}
+    eng = eng_g if model == "lerf-g" else eng_l
+    ps = []
+    for n in SET5:
+        lr = np.array(Image.open(os.path.join(DATA, "LR_bicubic/rrLR_X%.2f_%.2f" % (scale, scale), n + ".png")))
+        gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+        o8 = eng.sr(lr, scale, fused=fused)
+        r = ref["%s/x%d/%s" % (model, scale, n)]
+        assert list(o8.shape) == r["shape"]
+        assert _md5(o8) == r["md5_out"], "uint8 output differs from the reference for %s" % n
+        p = oracle.psnr_y(gt, o8, scale)
+        assert abs(p - r["psnr_y"]) <= 0.01
+        ps.append(p)
+    assert "%.2f" % np.mean(ps) == "%.2f" % published[model][scale]
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+@pytest.mark.parametrize("model", ["lerf-g", "lerf-l"])
+def test_set5_warp_md5_and_mpsnr(oracle, eng_g, eng_l, model, p):
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["warp"]
+    published = {"lerf-g": {"isc": 33.81, "osc": 27.89}, "lerf-l": {"isc": 32.90, "osc": 27.13}}
+    eng = eng_g if model == "lerf-g" else eng_l
+    ms = []
+    for n in SET5:
+        r = ref["%s/%s/%s" % (model, p, n)]
+        lr = np.array(Image.open(os.path.join(DATA, "warp", p, n + ".png")))
+        gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+        o8, mask = eng.warp(lr, np.array(r["matrix"]), gt.shape[:2])
+        assert int(mask.sum()) == r["mask_sum"] and _md5(mask.astype(np.uint8)) == r["md5_mask"]
+        assert o8.shape == gt.shape
+        assert _md5(o8 * mask) == r["md5_out_masked"], "masked uint8 output differs from the reference for %s" % n
+        m = oracle.mpsnr(o8, gt, mask)
+        assert abs(m - r["mpsnr"]) <= 0.01
+        ms.append(m)
+    assert "%.2f" % np.mean(ms) == "%.2f" % published[model][p]
+
+
+def test_sr_full_size_properties(torch, eng_g):
+    """BASELINE config 2 size (1920x1080 -> 3840x2160): size-independent properties.
+    (a) tiling invariance: any interior crop, processed alone with a 7-px halo, reproduces the
+        full-frame output exactly (stage radii 3+3+1);
+    (b) a constant image stays constant away from the zero-padded border;
+    (c) fused and unfused paths agree bit for bit."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    x = torch.from_numpy(img).cuda()
+    full = eng_g.sr(x, 2)
+    assert tuple(full.shape) == (2160, 3840, 3)
+    assert torch.equal(full, eng_g.sr(x, 2, fused=False))
+    for (y0, x0, h, w) in ((100, 200, 64, 96), (500, 1000, 33, 47), (1000, 1800, 60, 100)):
+        crop = x[y0 - 7:y0 + h + 7, x0 - 7:x0 + w + 7].contiguous()
+        oc = eng_g.sr(crop, 2)
+        assert torch.equal(oc[14:-14, 14:-14], full[2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)])
+    const = torch.full((1080, 1920, 3), 77, dtype=torch.uint8, device="cuda")
+    oc = eng_g.sr(const, 2)
+    inner = oc[2:-2, 2:-2]
+    assert int(inner.min()) == int(inner.max())
+
+
+def test_batched_frames(torch, eng_g):
+    rng = np.random.default_rng(5)
+    imgs = torch.from_numpy(rng.integers(0, 256, (3, 40, 56, 3), dtype=np.uint8)).cuda()
+    out = eng_g.sr(imgs, 2)
+    for b in range(3):
+        assert torch.equal(out[b], eng_g.sr(imgs[b], 2))
+
+
+def test_error_behaviour(torch, eng_g):
+    from lerf_pytorch_amd import ops
+    with pytest.raises(ValueError):
+        eng_g.sr(np.zeros((8, 8, 3), np.float32), 2)
+    with pytest.raises(NotImplementedError):
+        ops.SrGeometry((8, 8), [0.5, 0.5], None, 2)
+    with pytest.raises(ValueError):
+        ops.lut_stages(torch.zeros((8, 8, 3), dtype=torch.float32, device="cuda"), eng_g.luts)
