@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LeRF-G LUT x2 SR, 1920x1080 -> 3840x2160 RGB (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one launch of the hot path (stage-1 LUTs -> stage-2 LUTs -> steering-
+Gaussian resampling, uint8 HWC in / uint8 HWC out) over a batch of `--frames`
+synthetic frames already resident in HBM.  For N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank processes its own batch --
+frames are independent, so there is no collective in the data path (weak
+scaling); the barrier only brackets the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against
+HBM bandwidth using the ALGORITHMIC bytes of SURVEY.md 8(d); `cpu_baseline` is
+the C port of the oracle timed on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, C = 1080, 1920, 3
+SCALE = 2
+LUT_BYTES_G = 1753941          # 3 x 83521 + 6 x 83521 x 3
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_frames(kind, n, seed):
+    """SURVEY.md 8(d) inputs.  'noise': uniform uint8 (worst case for LUT locality);
+    'natural': low-pass field (box blur radius 8, 3 passes) + 5 % uniform noise."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (n, H, W, C), dtype=np.uint8)
+    out = np.empty((n, H, W, C), np.uint8)
+    for i in range(n):
+        x = rng.random((H, W, C))
+        for _ in range(3):
+            for ax in (0, 1):
+                k = 17
+                pad = [(0, 0)] * 3
+                pad[ax] = (k // 2 + 1, k // 2)
+                cs = np.cumsum(np.pad(x, pad, mode="reflect"), axis=ax)
+                hi = [slice(None)] * 3
+                lo = [slice(None)] * 3
+                hi[ax] = slice(k, None)
+                lo[ax] = slice(0, -k)
+                x = (cs[tuple(hi)] - cs[tuple(lo)]) / k
+        x = (x - x.min()) / (x.max() - x.min())
+        x = x * 255.0 + (rng.random((H, W, C)) - 0.5) * 0.05 * 255.0
+        out[i] = np.clip(np.round(x), 0, 255).astype(np.uint8)
+    return out
+
+
+def cpu_baseline(frames_u8, budget_s=12.0):
+    """C port of the oracle (oracle/lerf_oracle.c, OpenMP) on this host, bounded sample."""
+    from oracle import c_oracle, lerf_oracle
+    luts = lerf_oracle.load_luts(os.path.join(ROOT, "lerf-pytorch_amd", "assets", "models", "lerf-g"))
+    thr = c_oracle.threads()
+    t0 = time.perf_counter()
+    n = 0
+    out = None
+    while True:
+        out = c_oracle.sr_u8(frames_u8[n % len(frames_u8)], luts, SCALE, SCALE)
+        n += 1
+        if time.perf_counter() - t0 >= budget_s or n >= 64:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n * out.shape[0] * out.shape[1] / dt / 1e6, 4), "unit": "Mpix/s", "cores": thr, "kind": "port",
+        "sample": "%d frame(s) %dx%d->%dx%d, same synthetic input, oracle/lerf_oracle.c (OpenMP, %d threads), %.1f s"
+                  % (n, W, H, out.shape[1], out.shape[0], thr, dt),
+    }, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--input", choices=["noise", "natural"], default="noise")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="time the 3-launch direct path instead")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import ops
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+
+    eng = L.LerfEngine.shipped("lerf-g", support=2, max_sigma=10.0)
+    geo = eng.sr_geometry((H, W), SCALE)
+    B = args.frames
+    host = {k: synth_frames(k, B if k == args.input else 2, seed=1000 + rank) for k in ("noise", "natural")}
+    frames = torch.from_numpy(host[args.input]).cuda()
+    oH, oW = geo.out_hw
+    out = torch.empty((B, oH, oW, C), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, B)), dtype=torch.uint8, device="cuda")
+
+    def step(x, o):
+        if args.unfused:
+            for b in range(x.shape[0]):
+                feat, hq = ops.lut_stages(x[b], eng.luts)
+                o[b] = ops.resize_hwc_u8(feat, hq, geo, "gauss", 10.0, out="u8")
+        else:
+            ops.sr_fused_u8(x, eng.luts, geo, "gauss", 10.0, out=o, workspace=ws)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(frames, out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step(frames, out)
+        ev[k][1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # secondary distribution (same shapes), short run, rank 0 only
+    other = "natural" if args.input == "noise" else "noise"
+    other_mpix = None
+    if rank == 0:
+        xo = torch.from_numpy(np.ascontiguousarray(np.tile(host[other], (B // 2 + 1, 1, 1, 1))[:B])).cuda()
+        step(xo, out)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(3, args.steps // 4)):
+            step(xo, out)
+        torch.cuda.synchronize()
+        other_mpix = max(3, args.steps // 4) * B * oH * oW / (time.perf_counter() - t1) / 1e6
+        step(frames, out)
+        torch.cuda.synchronize()
+
+    pix_per_step = n_gpus * B * oH * oW
+    value = pix_per_step * args.steps / dt / 1e6
+    alg_bytes = B * (H * W * C + oH * oW * C) + LUT_BYTES_G          # per launch (fused uint8 path)
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile) and not args.unfused:
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("frames") == B and tj.get("input") == args.input:
+                traffic = tj.get("bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    res = {
+        "metric": "Mpix/s LeRF-G x2 SR (2K->4K)", "value": round(value, 2), "unit": "Mpix/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8 io, i32 LUT stages, f32 resampling", "data": "synthetic",
+        "config": {"workload": "LeRF-G LUT x2 SR, 1920x1080->3840x2160 RGB uint8, S=2, max_sigma=10 (BASELINE configs[1])",
+                   "frames_per_step_per_gpu": B, "input": args.input, "path": "unfused-3-launch" if args.unfused else "sr_fused_u8",
+                   "parallelism": "independent frames per GPU, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "gather/VALU-bound path: 3.75 B per output pixel, see DESIGN.md"},
+        "mpix_s_other_input": {other: round(other_mpix, 2)} if other_mpix else None,
+    }
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        cb, cpu_out = cpu_baseline(host[args.input])
+        res["cpu_baseline"] = cb
+        # the timed product output must equal the checker's (<= 1 LSB)
+        n_cpu = int(cb["sample"].split()[0])
+        ref_idx = (n_cpu - 1) % len(host[args.input])
+        diff = np.abs(out[ref_idx].cpu().numpy().astype(int) - cpu_out.astype(int))
+        res["parity_vs_cpu_port"] = {"max_abs_diff_u8": int(diff.max()), "mismatches": int((diff != 0).sum())}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""ctypes wrapper of oracle/liblerf_oracle.so (the C restatement of the oracle).
+
+TEST INFRASTRUCTURE ONLY -- see lerf_oracle.c.  Used by tests/ for sizes the
+numpy oracle is too slow for, and by bench.py's cpu_baseline leg ("port").
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liblerf_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            import subprocess
+            subprocess.check_call(["make", "-C", _HERE])
+        _lib = C.CDLL(LIB)
+    return _lib
+
+
+def threads():
+    return int(lib().lerf_oracle_threads())
+
+
+def _lut_ptrs(luts, modes, modes2, oC):
+    keep = []
+    s1 = (C.c_void_p * len(modes))()
+    for i, m in enumerate(modes):
+        a = np.ascontiguousarray(np.asarray(luts["s1_%sr0" % m]).astype(np.int8).reshape(-1))
+        keep.append(a)
+        s1[i] = a.ctypes.data
+    s2 = (C.c_void_p * (2 * len(modes2)))()
+    for i, m in enumerate(modes2):
+        for r in (0, 1):
+            a = np.ascontiguousarray(np.asarray(luts["s2_%sr%d" % (m, r)]).astype(np.int8).reshape(-1, oC))
+            keep.append(a)
+            s2[2 * i + r] = a.ctypes.data
+    return s1, s2, keep
+
+
+def lut_stages(img_u8, luts, oC, modes="sct", modes2="sct"):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    H, W, Cn = img.shape
+    s1, s2, keep = _lut_ptrs(luts, modes, modes2, oC)
+    feat = np.empty((H, W, Cn), np.uint8)
+    hq = np.empty((H, W, Cn, oC), np.uint8)
+    rc = lib().lerf_oracle_lut_stages(C.c_void_p(img.ctypes.data), H, W, Cn, modes.encode(), len(modes), s1,
+                                      modes2.encode(), len(modes2), s2, oC, C.c_void_p(feat.ctypes.data),
+                                      C.c_void_p(hq.ctypes.data))
+    if rc:
+        raise ValueError("lerf_oracle_lut_stages failed")
+    return feat, hq
+
+
+def resize(feat_u8, hq_u8, sh, sw, S=2, max_sigma=10.0, kind="gauss"):
+    feat = np.ascontiguousarray(feat_u8, dtype=np.uint8)
+    hq = np.ascontiguousarray(hq_u8, dtype=np.uint8)
+    H, W, Cn = feat.shape
+    oC = hq.shape[3]
+    oH, oW = int(np.ceil(sh * H)), int(np.ceil(sw * W))
+    out = np.empty((oH, oW, Cn), np.float64)
+    rc = lib().lerf_oracle_resize(C.c_void_p(feat.ctypes.data), C.c_void_p(hq.ctypes.data), H, W, Cn, oC,
+                                  C.c_double(sh), C.c_double(sw), int(S), C.c_double(max_sigma),
+                                  0 if kind == "gauss" else 1, C.c_void_p(out.ctypes.data))
+    if rc:
+        raise ValueError("lerf_oracle_resize failed")
+    return out
+
+
+def sr_u8(img_u8, luts, sh, sw, S=2, max_sigma=10.0, linear=False, modes="sct", modes2="sct"):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    H, W, Cn = img.shape
+    oC = 1 if linear else 3
+    if linear:
+        S, max_sigma = 2, 1.0
+    s1, s2, keep = _lut_ptrs(luts, modes, modes2, oC)
+    oH, oW = int(np.ceil(sh * H)), int(np.ceil(sw * W))
+    out = np.empty((oH, oW, Cn), np.uint8)
+    rc = lib().lerf_oracle_sr_u8(C.c_void_p(img.ctypes.data), H, W, Cn, modes.encode(), len(modes), s1,
+                                 modes2.encode(), len(modes2), s2, oC, C.c_double(sh), C.c_double(sw), int(S),
+                                 C.c_double(max_sigma), 1 if linear else 0, C.c_void_p(out.ctypes.data))
+    if rc:
+        raise ValueError("lerf_oracle_sr_u8 failed")
+    return out
