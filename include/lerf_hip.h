@@ -69,7 +69,7 @@ typedef struct {
     int oC;                                     /* 3 = LeRF-G (rho, sigma_x, sigma_y), 1 = LeRF-L (alpha) */
     const int8_t* s1[LERF_MAX_MODES];           /* device, [17^4]      LUT_s1_<mode>r0 */
     const int8_t* s2[LERF_MAX_MODES][2];        /* device, [17^4][oC]  LUT_s2_<mode>r{0,1} */
-    const uint32_t* s2_packed[LERF_MAX_MODES][2];  /* optional (may be NULL): lerf_lut_pack_s2 output */
+    const void* fused_pack;                     /* optional (may be NULL): lerf_fused_lutpack_build output */
 } lerf_luts_t;
 
 /* Separable SR geometry: the 1-D content of Resize2dNumpy.get_distance's dense
@@ -138,9 +138,13 @@ int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C,
                         int h, int w, const int8_t dy[4], const int8_t dx[4],
                         const int8_t* lut, int oC, int16_t* out, void* stream);
 
-/* Repack one stage-2 LUT [17^4][oC] int8 into one uint32 per entry
- * (biased bytes, layout documented in DESIGN.md) for the tiled kernels. */
-int lerf_lut_pack_s2(const int8_t* lut, int oC, uint32_t* packed, void* stream);
+/* LUT pack for the tile-fused kernel (modes "sct"/"sct" only): the stage-1
+ * LUTs padded to 16-byte multiples, and the stage-2 LUTs as one uint32 per
+ * entry holding the oC biased bytes (layout in DESIGN.md).  The caller owns
+ * `buf` (lerf_fused_lutpack_bytes(oC) bytes of device memory) and stores it in
+ * lerf_luts_t.fused_pack. */
+size_t lerf_fused_lutpack_bytes(int oC);
+int lerf_fused_lutpack_build(const lerf_luts_t* luts, void* buf, void* stream);
 
 /* Stages 1+2 of eltr._worker (resample/eval_lut_sr.py:541-628,
  * resample/eval_lut_warp.py:104-191): uint8 image -> feat (uint8, same shape)

@@ -22,7 +22,8 @@ KINDS = {"gauss": KIND_GAUSS, "linear": KIND_LINEAR, "nearest": KIND_NEAREST}
 
 EXPORTS = [
     "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables",
-    "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_lut_pack_s2", "lerf_lut_stages_u8",
+    "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
+    "lerf_lut_stages_u8",
     "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_u8",
 ]
 
@@ -42,7 +43,7 @@ class Luts(C.Structure):
         ("oC", C.c_int),
         ("s1", C.c_void_p * LERF_MAX_MODES),
         ("s2", (C.c_void_p * 2) * LERF_MAX_MODES),
-        ("s2_packed", (C.c_void_p * 2) * LERF_MAX_MODES),
+        ("fused_pack", C.c_void_p),
     ]
 
 
@@ -86,7 +87,9 @@ def lib():
     L.lerf_warp_pads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lerf_lut_interp_i16.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-    L.lerf_lut_pack_s2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lerf_fused_lutpack_bytes.restype = C.c_size_t
+    L.lerf_fused_lutpack_bytes.argtypes = [C.c_int]
+    L.lerf_fused_lutpack_build.argtypes = [C.POINTER(Luts), C.c_void_p, C.c_void_p]
     L.lerf_lut_stages_u8.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
                                      C.POINTER(Plane), C.POINTER(Plane), C.c_void_p]
     L.lerf_resize.argtypes = [C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(SrGeo),

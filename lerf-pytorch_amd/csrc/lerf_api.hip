@@ -155,9 +155,14 @@ int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C, in
     return rc != LERF_OK ? rc : check_launch();
 }
 
-int lerf_lut_pack_s2(const int8_t* lut, int oC, uint32_t* packed, void* stream) {
-    if (!lut || !packed) return LERF_EINVAL;
-    int rc = launch_lut_pack(lut, oC, packed, as_stream(stream));
+size_t lerf_fused_lutpack_bytes(int oC) { return (oC == 1 || oC == 3) ? fused_lutpack_bytes(oC) : 0; }
+
+int lerf_fused_lutpack_build(const lerf_luts_t* luts, void* buf, void* stream) {
+    if (!luts || !buf) return LERF_EINVAL;
+    if (luts->n_modes1 != 3 || luts->n_modes2 != 3 || memcmp(luts->modes1, "sct", 3) != 0 ||
+        memcmp(luts->modes2, "sct", 3) != 0)
+        return LERF_EUNSUPPORTED;
+    int rc = fused_lutpack_build(luts, buf, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
 

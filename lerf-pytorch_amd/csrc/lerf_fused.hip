@@ -1,8 +1,602 @@
-// Tile-fused uint8 SR path (stages 1+2+3 in one launch).  Placeholder until the
-// tiled kernel lands: reports "not supported" so the API takes the 3-launch path.
+// Tile-fused uint8 SR path for MI355X (gfx950): stage-1 LUTs -> stage-2 LUTs ->
+// spatially-varying resampling in ONE launch; feat and hyper never leave the CU.
+//
+// Reference path being replaced: eltr._worker, resample/eval_lut_sr.py:541-665
+// (FourSimplexInterpFaster :24-470 x 24 passes, SteeringGaussianResize2dNumpy /
+// AmplifiedLinearResize2dNumpy, resize_right/resize_right2d_numpy.py:142-282).
+//
+// Work decomposition
+//   one 1024-thread workgroup (16 waves, 1 per CU: LDS-bound) per 64x64 LR tile
+//   of one frame.  The tile owns the output pixels whose support starts inside
+//   it.  Halo: 3 (stage 1) + 3 (stage 2) + S/2 (stage 3) LR pixels per side,
+//   recomputed per tile; true image borders use the reference's rules (clamped
+//   sampling for the LUT stages, zero image / edge hyper for stage 3).
+//
+// LDS plan (dynamic, one array; sizes for S=2 / S=4)
+//   B    feat tile u8                   (72x72x3 = 15.5 KB / 74x74x3)     all stages
+//   LUT  stage 1: one int8 LUT          83.5 KB
+//        stage 2 (LeRF-G): a QUARTER of one packed LUT = the 5 top-axis levels
+//        that pixels with (centre >> 6) == q can touch, 5*4913 dwords = 96 KB
+//   C    input tile u8 (78x78x3)        stage 1 only
+//   ACC  int16 partial sums             stage 1 (and stage 2 of LeRF-L)
+//   LST  pixel lists sorted by quarter  stage 2 (LeRF-G), transient
+//   D    (hq0,hq1,hq2,feat) dwords      stage 3, overlays LUT
+//
+// Stage 2 of LeRF-G keeps the whole 3-channel LUT entry in one dword, so one
+// simplex walk (index sort + 5 LDS gathers) serves all three hyper channels.
+// The full packed LUT (326 KB) cannot live in LDS; pixels are therefore binned
+// by the top two bits of their centre value (which select the slowest LUT axis
+// for every mode and rotation), and each (LUT, quarter) phase processes only
+// the pixels of that bin with all 64 lanes busy.  Per-pixel accumulators stay
+// in VGPRs across phases (two packed 16-bit fields + one).
+#include <string.h>
+
 #include "lerf_kernels.h"
+#include "lerf_stage3.h"
 
 namespace lerf {
-bool fused_supported(const FusedArgs&) { return false; }
-int launch_sr_fused(const FusedArgs&, hipStream_t) { return LERF_EUNSUPPORTED; }
+namespace fused {
+
+constexpr int NT = 1024;           // threads per workgroup
+constexpr int NW = NT / 64;        // waves
+constexpr int TH = 64, TW = 64;    // LR tile
+constexpr int CH = 3;              // channels (RGB frames)
+constexpr int R1 = 3, R2 = 3;      // stage radii for modes s,c,t
+constexpr int LUT_PAD = 83584;     // padded entries per LUT in the pack (16-B multiple)
+constexpr int QSTRIDE = 4 * kStrideA;        // entries between quarter origins
+constexpr int QENTRIES = 5 * kStrideA;       // entries a quarter piece holds
+constexpr int MAXR = 17;           // max slot rounds: ceil(NH/1024) + 4 (S=4: 13872/1024 -> 14 + 3)
+
+template <int S>
+struct Dims {
+    static constexpr int R3 = S / 2;
+    static constexpr int HY = TH + 2 * R3, HX = TW + 2 * R3, HP = HX * CH, NH = HY * HP;   // hyper region
+    static constexpr int FY = HY + 2 * R2, FX = HX + 2 * R2, FP = FX * CH, NF = FY * FP;   // feat region
+    static constexpr int IY = FY + 2 * R1, IX = FX + 2 * R1, IP = IX * CH, NI = IY * IP;   // input region
+    static constexpr int up16(int x) { return (x + 15) / 16 * 16; }
+    static constexpr int OFF_B = 0;
+    static constexpr int OFF_X = up16(NF);                       // stage-dependent area starts here
+    // stage 1 (and byte-LUT stage 2)
+    static constexpr int OFF_LUT = OFF_X;
+    static constexpr int OFF_C = OFF_LUT + LUT_PAD;
+    static constexpr int OFF_ACC = OFF_C + up16(NI);
+    static constexpr int END1 = OFF_ACC + up16(NF * 2);
+    // stage 2 quarter path
+    static constexpr int SZ_Q = up16(QENTRIES * 4);
+    static constexpr int OFF_LST = OFF_X + SZ_Q;
+    static constexpr int END2 = OFF_LST + MAXR * NT * 2;
+    // stage 3
+    static constexpr int OFF_D = OFF_X;
+    static constexpr int OFF_GEO = OFF_D + up16(NH * 4);
+    static constexpr int GEO_ROWS = 320;                          // max owned output rows / cols per tile (scale <= 4.9)
+    static constexpr int SZ_GEO = 2 * GEO_ROWS * (4 + 4 * S);
+    static constexpr int END3 = OFF_GEO + SZ_GEO;
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int LDS_BYTES = cmax(END1, cmax(END2, END3)) + 64;   // + small control block
+    static constexpr int OFF_CTL = LDS_BYTES - 64;
+};
+
+struct Params {
+    const uint8_t* img; int64_t in_sn;
+    uint8_t* out; int64_t out_sn;
+    int H, W, oH, oW, tiles_y, tiles_x;
+    const uint8_t* pack;             // fused LUT pack (see lerf_fused_lutpack_*)
+    const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
+    float max_sigma;
+    int s2off[6][6];                 // stage-2 LUT l: feat-tile byte offsets of pixels b,c,d for rotations par, par+2
+};
+
+// byte offsets of the 3 non-centre pixels of (mode, rot) in a u8 tile of pitch P
+struct Off3 { int o[3]; };
+template <int P>
+__host__ __device__ constexpr Off3 tile_offsets(char mode, int rot) {
+    int dy[4] = {0, 0, 0, 0}, dx[4] = {0, 0, 0, 0};
+    switch (mode) {
+        case 's': dy[1] = 0; dx[1] = 1; dy[2] = 1; dx[2] = 0; dy[3] = 1; dx[3] = 1; break;
+        case 'c': dy[1] = 0; dx[1] = 1; dy[2] = 0; dx[2] = 2; dy[3] = 0; dx[3] = 3; break;
+        default:  dy[1] = 1; dx[1] = 1; dy[2] = 2; dx[2] = 2; dy[3] = 3; dx[3] = 3; break;   // 't'
+    }
+    Off3 r{};
+    for (int k = 1; k < 4; ++k) {
+        int y = dy[k], x = dx[k];
+        for (int i = 0; i < (rot & 3); ++i) { int t = y; y = x; x = -t; }
+        r.o[k - 1] = y * P + x * CH;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// simplex walk on a byte LUT in LDS: returns the numerator (sum w*P, weights sum 16)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int simplex_bytes(const int8_t* __restrict__ lut, int va, int vb, int vc, int vd) {
+    SimplexPath p = simplex_path(va, vb, vc, vd);
+    int acc = p.w[0] * (int)lut[p.idx[0]];
+    acc += p.w[1] * (int)lut[p.idx[1]];
+    acc += p.w[2] * (int)lut[p.idx[2]];
+    acc += p.w[3] * (int)lut[p.idx[3]];
+    acc += p.w[4] * (int)lut[p.idx[4]];
+    return acc;
+}
+
+__device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__ src, int bytes, int tid) {
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    const int n = (bytes + 15) >> 4;
+    for (int i = tid; i < n; i += NT) d[i] = s[i];
+}
+
+// One byte-LUT phase over a destination region of NDST px-ch positions (row pitch DP)
+// whose centres live in a source tile (pitch SP).  MODE/ROT0/NROT/RSTEP are static so
+// the neighbour offsets fold into DS immediates.  PHASE: 0 = first (store), 1 = add,
+// 2 = add and finalise with (div, bias) into `dst8`.
+template <int SP, char MODE, int ROT0, int NROT, int RSTEP>
+__device__ __forceinline__ int byte_lookups(const int8_t* lut, const uint8_t* src_center) {
+    int va = src_center[0];
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < NROT; ++i) {
+        const int r = ROT0 + i * RSTEP;
+        Off3 o = tile_offsets<SP>(MODE, r);
+        acc += simplex_bytes(lut, va, src_center[o.o[0]], src_center[o.o[1]], src_center[o.o[2]]);
+    }
+    return acc;
+}
+
+// position p of a region (pitch DPc px-ch per row, origin (y0g,x0g) in the frame) ->
+// byte address of its clamped centre in the source tile (pitch SP, origin (sy0g,sx0g))
+template <int DPc, int SP>
+__device__ __forceinline__ int center_addr(int p, int y0g, int x0g, int sy0g, int sx0g, int H, int W, bool* inside) {
+    int ry = p / DPc;
+    int r3 = p - ry * DPc;
+    int rx = r3 / CH;
+    int c = r3 - rx * CH;
+    int gy = y0g + ry, gx = x0g + rx;
+    int cy = clampi(gy, 0, H - 1), cx = clampi(gx, 0, W - 1);
+    if (inside) *inside = (cy == gy) && (cx == gx);
+    return (cy - sy0g) * SP + (cx - sx0g) * CH + c;
+}
+
+template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, int PHASE>
+__device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src, int16_t* acc16, uint8_t* dst8,
+                                           int y0g, int x0g, int sy0g, int sx0g, int H, int W, int div, int bias,
+                                           int tid) {
+    for (int p = tid; p < NDST; p += NT) {
+        int a = center_addr<DPc, SP>(p, y0g, x0g, sy0g, sx0g, H, W, nullptr);
+        int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut, src + a);
+        if (PHASE != 0) v += (int)acc16[p];
+        if (PHASE == 2)
+            dst8[p] = (uint8_t)rne_div_clip255(v + bias * div, div);
+        else
+            acc16[p] = (int16_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stage 3 helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lower_bound_i(const int* __restrict__ a, int n, int key) {
+    int lo = 0, hi = n;      // first i with a[i] >= key
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------
+template <int S, int KIND>
+__global__ void __launch_bounds__(NT)
+sr_fused_kernel(Params P) {
+    using D = Dims<S>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    int bid = blockIdx.x;
+    const int tiles = P.tiles_y * P.tiles_x;
+    const int frame = bid / tiles;
+    bid -= frame * tiles;
+    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int H = P.H, W = P.W;
+    const uint8_t* __restrict__ img = P.img + frame * P.in_sn;
+    uint8_t* __restrict__ outp = P.out + frame * P.out_sn;
+
+    // region origins in frame coordinates
+    const int hy0 = ty0 - D::R3, hx0 = tx0 - D::R3;
+    const int fy0 = hy0 - R2, fx0 = hx0 - R2;
+    const int iy0 = fy0 - R1, ix0 = fx0 - R1;
+
+    uint8_t* Bt = smem + D::OFF_B;
+    int* ctl = reinterpret_cast<int*>(smem + D::OFF_CTL);
+
+    // ---- input tile with clamped coordinates (np.pad(..., 'edge') in every rotated frame)
+    {
+        uint8_t* Ct = smem + D::OFF_C;
+        for (int p = tid; p < D::NI; p += NT) {
+            int ry = p / D::IP;
+            int r3 = p - ry * D::IP;
+            int rx = r3 / CH;
+            int c = r3 - rx * CH;
+            int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
+            Ct[p] = img[((int64_t)gy * W + gx) * CH + c];
+        }
+    }
+
+    // ---- stage 1: three byte LUTs, 4 rotations each (eval_lut_sr.py:541-577)
+    {
+        const uint8_t* Ct = smem + D::OFF_C;
+        int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
+        int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
+        const int div1 = kQ * 3;
+        copy16(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, LERF_LUT_ENTRIES, tid);
+        __syncthreads();
+        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
+        __syncthreads();
+        copy16(smem + D::OFF_LUT, P.pack + 1 * LUT_PAD, LERF_LUT_ENTRIES, tid);
+        __syncthreads();
+        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
+        __syncthreads();
+        copy16(smem + D::OFF_LUT, P.pack + 2 * LUT_PAD, LERF_LUT_ENTRIES, tid);
+        __syncthreads();
+        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
+        __syncthreads();
+    }
+
+    uint32_t* Dt = reinterpret_cast<uint32_t*>(smem + D::OFF_D);
+
+    if (KIND == LERF_KIND_LINEAR) {
+        // ---- stage 2, LeRF-L: six byte LUTs (mode x rotation parity), 2 rotations each (eval_lut_sr.py:579-628)
+        int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
+        int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
+        uint8_t* hq8 = smem + D::OFF_C;                   // input tile is dead: reuse for the u8 hyper values
+        const uint8_t* s2 = P.pack + 3 * LUT_PAD;
+        const int div2 = kQ * 12;
+#define LERF_L2(IDX, MODE, PAR, PH)                                                                        \
+        copy16(smem + D::OFF_LUT, s2 + (IDX) * LUT_PAD, LERF_LUT_ENTRIES, tid);                          \
+        __syncthreads();                                                                                   \
+        byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, H, W, div2, 127, tid); \
+        __syncthreads();
+        LERF_L2(0, 's', 0, 0)
+        LERF_L2(1, 's', 1, 1)
+        LERF_L2(2, 'c', 0, 1)
+        LERF_L2(3, 'c', 1, 1)
+        LERF_L2(4, 't', 0, 1)
+        LERF_L2(5, 't', 1, 2)
+#undef LERF_L2
+        // pack (alpha_q, 0, 0, feat-or-0) dwords for stage 3
+        uint32_t tmp[(D::NH + NT - 1) / NT];
+#pragma unroll
+        for (int k = 0; k < (D::NH + NT - 1) / NT; ++k) {
+            int p = k * NT + tid;
+            tmp[k] = 0;
+            if (p < D::NH) {
+                bool inside;
+                int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, &inside);
+                tmp[k] = (uint32_t)hq8[p] | ((inside ? (uint32_t)Bt[a] : 0u) << 24);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < (D::NH + NT - 1) / NT; ++k) {
+            int p = k * NT + tid;
+            if (p < D::NH) Dt[p] = tmp[k];
+        }
+    } else {
+        // ---- stage 2, LeRF-G: packed 3-channel LUT quarters, pixels binned by centre >> 6
+        uint16_t* lst = reinterpret_cast<uint16_t*>(smem + D::OFF_LST);
+        // ctl[0..3] counts, ctl[4..7] cursors / bases
+        if (tid < 8) ctl[tid] = 0;
+        for (int i = tid; i < MAXR * NT / 2; i += NT) reinterpret_cast<uint32_t*>(lst)[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        constexpr int KH = (D::NH + NT - 1) / NT;
+        // pass 1: count
+        for (int k = 0; k < KH; ++k) {
+            int p = k * NT + tid;
+            int q = -1;
+            if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, nullptr)] >> 6;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                unsigned long long m = __ballot(q == qq);
+                if (lane == 0 && m) atomicAdd(&ctl[qq], __popcll(m));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int base = 0;
+            for (int qq = 0; qq < 4; ++qq) {
+                ctl[4 + qq] = base;                 // cursor
+                ctl[8 + qq] = base / NT;            // first round of the quarter
+                base += (ctl[qq] + NT - 1) / NT * NT;
+                ctl[12 + qq] = base / NT;           // one past its last round
+            }
+        }
+        __syncthreads();
+        // pass 2: scatter position ids into the quarter segments
+        for (int k = 0; k < KH; ++k) {
+            int p = k * NT + tid;
+            int q = -1;
+            if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, nullptr)] >> 6;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                unsigned long long m = __ballot(q == qq);
+                if (m) {
+                    int start = 0;
+                    if (lane == 0) start = atomicAdd(&ctl[4 + qq], __popcll(m));
+                    start = __shfl(start, 0);
+                    if (q == qq) lst[start + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
+                }
+            }
+        }
+        __syncthreads();
+        // slots -> registers: (feat-tile address of the clamped centre) | p << 16
+        uint32_t slot[MAXR];
+        uint32_t accA[MAXR], accB[MAXR];
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            uint32_t p = lst[k * NT + tid];
+            uint32_t a = 0;
+            if (p != 0xFFFFu) a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, H, W, nullptr);
+            slot[k] = a | (p << 16);
+            accA[k] = 0;
+            accB[k] = 0;
+        }
+        __syncthreads();
+
+        const uint32_t* qlut = reinterpret_cast<const uint32_t*>(smem + D::OFF_X);
+        const uint32_t* s2 = reinterpret_cast<const uint32_t*>(P.pack + 3 * LUT_PAD);
+        for (int q = 0; q < 4; ++q) {
+            if (ctl[q] == 0) continue;             // uniform: nobody in this quarter
+            for (int l = 0; l < 6; ++l) {
+                // LUT l = mode (l>>1), rotation parity (l&1); rotations par, par+2
+                copy16(smem + D::OFF_X, reinterpret_cast<const uint8_t*>(s2 + (size_t)l * LUT_PAD + q * QSTRIDE),
+                       QENTRIES * 4, tid);
+                Off3 o0, o1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    o0.o[i] = P.s2off[l][i];
+                    o1.o[i] = P.s2off[l][3 + i];
+                }
+                const int rsq = __builtin_amdgcn_readfirstlane(ctl[8 + q]);
+                const int req = __builtin_amdgcn_readfirstlane(ctl[12 + q]);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < MAXR; ++k) {
+                    if (k >= rsq && k < req) {
+                        const uint32_t sl = slot[k];
+                        if ((sl >> 16) != 0xFFFFu) {
+                            const uint8_t* cp = Bt + (sl & 0xFFFFu);
+                            const int va = cp[0];
+                            const int basea = ((va >> 4) - 4 * q) * kStrideA;
+                            const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)kStrideA;
+#pragma unroll
+                            for (int rr = 0; rr < 2; ++rr) {
+                                const Off3& o = rr == 0 ? o0 : o1;
+                                const int vb = cp[o.o[0]], vc = cp[o.o[1]], vd = cp[o.o[2]];
+                                unsigned k0 = ka;
+                                unsigned k1 = ((unsigned)(vb & 15) << 16) | (unsigned)kStrideB;
+                                unsigned k2 = ((unsigned)(vc & 15) << 16) | (unsigned)kStrideC;
+                                unsigned k3 = ((unsigned)(vd & 15) << 16) | (unsigned)kStrideD;
+                                int idx = basea + (vb >> 4) * kStrideB + (vc >> 4) * kStrideC + (vd >> 4);
+                                ce_desc(k0, k1);
+                                ce_desc(k2, k3);
+                                ce_desc(k0, k2);
+                                ce_desc(k1, k3);
+                                ce_desc(k1, k2);
+                                const unsigned f0 = k0 >> 16, f1 = k1 >> 16, f2 = k2 >> 16, f3 = k3 >> 16;
+                                uint32_t d, w;
+                                uint32_t a = accA[k], b = accB[k];
+                                d = qlut[idx]; w = kQ - f0;
+                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
+                                idx += (int)(k0 & 0xFFFFu);
+                                d = qlut[idx]; w = f0 - f1;
+                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
+                                idx += (int)(k1 & 0xFFFFu);
+                                d = qlut[idx]; w = f1 - f2;
+                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
+                                idx += (int)(k2 & 0xFFFFu);
+                                d = qlut[idx]; w = f2 - f3;
+                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
+                                idx += (int)(k3 & 0xFFFFu);
+                                d = qlut[idx]; w = f3;
+                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
+                                accA[k] = a;
+                                accB[k] = b;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // finalise: hq = rne(clip(N/192 + 127)); entries are biased by +128 -> 12 lookups * 16 * 128 = 24576
+        //           N + 127*192 = field - 24576 + 24384 = field - 192
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            const uint32_t sl = slot[k];
+            const uint32_t p = sl >> 16;
+            if (p != 0xFFFFu) {
+                const int div2 = kQ * 12;
+                int n0 = (int)(accA[k] & 0xFFFFu) - div2;
+                int n2 = (int)(accA[k] >> 16) - div2;
+                int n1 = (int)accB[k] - div2;
+                uint32_t h0 = (uint32_t)rne_div_clip255(n0, div2);
+                uint32_t h1 = (uint32_t)rne_div_clip255(n1, div2);
+                uint32_t h2 = (uint32_t)rne_div_clip255(n2, div2);
+                bool inside;
+                int a = center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, H, W, &inside);
+                uint32_t fv = inside ? (uint32_t)Bt[a] : 0u;      // zero-padded image outside the frame (:208)
+                Dt[p] = h0 | (h1 << 8) | (h2 << 16) | (fv << 24);
+            }
+        }
+    }
+
+    // ---- stage 3 geometry of the owned output block into LDS
+    int* g_lr = reinterpret_cast<int*>(smem + D::OFF_GEO);
+    float* g_dr = reinterpret_cast<float*>(g_lr + D::GEO_ROWS);
+    int* g_lc = reinterpret_cast<int*>(g_dr + D::GEO_ROWS * S);
+    float* g_dc = reinterpret_cast<float*>(g_lc + D::GEO_ROWS);
+    if (tid == 0) {
+        ctl[16] = tyi == 0 ? 0 : lower_bound_i(P.left_r, P.oH, ty0 - D::R3);
+        ctl[17] = tyi == P.tiles_y - 1 ? P.oH : lower_bound_i(P.left_r, P.oH, ty0 + TH - D::R3);
+        ctl[18] = txi == 0 ? 0 : lower_bound_i(P.left_c, P.oW, tx0 - D::R3);
+        ctl[19] = txi == P.tiles_x - 1 ? P.oW : lower_bound_i(P.left_c, P.oW, tx0 + TW - D::R3);
+    }
+    __syncthreads();
+    const int i0 = ctl[16], i1 = ctl[17], j0 = ctl[18], j1 = ctl[19];
+    const int nrow = i1 - i0, ncol = j1 - j0;
+    for (int e = tid; e < nrow; e += NT) {
+        g_lr[e] = P.left_r[i0 + e] - hy0;
+#pragma unroll
+        for (int b = 0; b < S; ++b) g_dr[e * S + b] = P.dis_r[(i0 + e) * S + b];
+    }
+    for (int e = tid; e < ncol; e += NT) {
+        g_lc[e] = P.left_c[j0 + e] - hx0;
+#pragma unroll
+        for (int a = 0; a < S; ++a) g_dc[e * S + a] = P.dis_c[(j0 + e) * S + a];
+    }
+    __syncthreads();
+
+    // ---- stage 3: one wave per output row, lanes along (column, channel)
+    const int ncolc = ncol * CH;
+    const float ms = P.max_sigma;
+    for (int il = wave; il < nrow; il += NW) {
+        const int lr = g_lr[il];
+        float dxr[S];
+#pragma unroll
+        for (int b = 0; b < S; ++b) dxr[b] = g_dr[il * S + b];
+        uint8_t* orow = outp + ((int64_t)(i0 + il) * P.oW + j0) * CH;
+        for (int xc = lane; xc < ncolc; xc += 64) {
+            const int jl = xc / CH;
+            const int c = xc - jl * CH;
+            const int lc = g_lc[jl];
+            float e[S * S], v[S * S];
+#pragma unroll
+            for (int a = 0; a < S; ++a) {                 // column offset major (numpy meshgrid 'xy', :95-98)
+                const float dy = g_dc[jl * S + a];
+#pragma unroll
+                for (int b = 0; b < S; ++b) {
+                    const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                    const float dx = dxr[b];
+                    v[a * S + b] = (float)(d >> 24);
+                    const float h0 = s3::u8_over_255((float)(d & 0xFFu));
+                    if (KIND == LERF_KIND_GAUSS) {
+                        const float h1 = s3::u8_over_255((float)((d >> 8) & 0xFFu));
+                        const float h2 = s3::u8_over_255((float)((d >> 16) & 0xFFu));
+                        e[a * S + b] = s3::gauss_form(h0, h1, h2, ms, dx, dy);
+                    } else {
+                        const float alpha = s3::lin_alpha_of(h0, ms);
+                        e[a * S + b] = s3::lin_factor(alpha, dx, s3::dist_class_f(dx)) *
+                                       s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
+                    }
+                }
+            }
+            orow[xc] = s3::to_u8(s3::finish<KIND == LERF_KIND_GAUSS, S * S>(e, v));
+        }
+    }
+}
+
+}  // namespace fused
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+bool fused_supported(const FusedArgs& a) {
+    const lerf_luts_t* L = a.luts;
+    if (!L || !L->fused_pack) return false;
+    if (a.C != 3 || (a.S != 2 && a.S != 4)) return false;
+    if (L->n_modes1 != 3 || L->n_modes2 != 3) return false;
+    if (memcmp(L->modes1, "sct", 3) != 0 || memcmp(L->modes2, "sct", 3) != 0) return false;
+    if (a.oH < a.H || a.oW < a.W) return false;                     // up-sampling only
+    if ((int64_t)a.oH > 4 * (int64_t)a.H + 8 || (int64_t)a.oW > 4 * (int64_t)a.W + 8) return false;   // geometry staging
+    if (a.kind == LERF_KIND_LINEAR && a.S != 2) return false;
+    return true;
+}
+
+template <int S, int KIND>
+static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
+    using D = fused::Dims<S>;
+    fused::Params P;
+    P.img = a.img; P.in_sn = a.in_sn; P.out = a.out; P.out_sn = a.out_sn;
+    P.H = a.H; P.W = a.W; P.oH = a.oH; P.oW = a.oW;
+    P.tiles_y = (a.H + fused::TH - 1) / fused::TH;
+    P.tiles_x = (a.W + fused::TW - 1) / fused::TW;
+    P.pack = (const uint8_t*)a.luts->fused_pack;
+    P.left_r = a.left_r; P.dis_r = a.dis_r; P.left_c = a.left_c; P.dis_c = a.dis_c;
+    P.max_sigma = a.max_sigma;
+    for (int l = 0; l < 6; ++l) {
+        const char mc = "sct"[l >> 1];
+        fused::Off3 o0 = fused::tile_offsets<D::FP>(mc, l & 1), o1 = fused::tile_offsets<D::FP>(mc, (l & 1) + 2);
+        for (int i = 0; i < 3; ++i) {
+            P.s2off[l][i] = o0.o[i];
+            P.s2off[l][3 + i] = o1.o[i];
+        }
+    }
+    auto kern = fused::sr_fused_kernel<S, KIND>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            D::LDS_BYTES) != hipSuccess)
+        return LERF_ELAUNCH;
+    const int64_t blocks = (int64_t)a.n * P.tiles_y * P.tiles_x;
+    if (blocks > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(fused::NT), D::LDS_BYTES, st, P);
+    return LERF_OK;
+}
+
+int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
+    if (a.kind == LERF_KIND_GAUSS) {
+        if (a.S == 2) return launch_fused_t<2, LERF_KIND_GAUSS>(a, st);
+        if (a.S == 4) return launch_fused_t<4, LERF_KIND_GAUSS>(a, st);
+    } else if (a.kind == LERF_KIND_LINEAR) {
+        if (a.S == 2) return launch_fused_t<2, LERF_KIND_LINEAR>(a, st);
+    }
+    return LERF_EUNSUPPORTED;
+}
+
+// fused LUT pack: [n1 x LUT_PAD int8 stage-1 LUTs][stage-2 LUTs], stage 2 as
+//   oC == 3: 6 x LUT_PAD uint32 (biased bytes e0+128 | e1+128 << 8 | e2+128 << 16), order s_r0, s_r1, c_r0, ...
+//   oC == 1: 6 x LUT_PAD int8
+size_t fused_lutpack_bytes(int oC) {
+    return (size_t)3 * fused::LUT_PAD + (size_t)6 * fused::LUT_PAD * (oC == 3 ? 4 : 1);
+}
+
+__global__ void pack_bytes_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < fused::LUT_PAD) dst[i] = i < LERF_LUT_ENTRIES ? src[i] : (int8_t)0;
+}
+__global__ void pack_dwords_kernel(const int8_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fused::LUT_PAD) return;
+    uint32_t d = 0;
+    if (i < LERF_LUT_ENTRIES)
+        for (int k = 0; k < 3; ++k) d |= (uint32_t)((int)src[i * 3 + k] + 128) << (8 * k);
+    dst[i] = d;
+}
+
+int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st) {
+    if (L->n_modes1 != 3 || L->n_modes2 != 3) return LERF_EUNSUPPORTED;
+    if (L->oC != 1 && L->oC != 3) return LERF_EUNSUPPORTED;
+    uint8_t* base = (uint8_t*)buf;
+    dim3 block(256), grid((fused::LUT_PAD + 255) / 256);
+    for (int m = 0; m < 3; ++m) {
+        if (!L->s1[m]) return LERF_EINVAL;
+        hipLaunchKernelGGL(pack_bytes_kernel, grid, block, 0, st, L->s1[m], (int8_t*)(base + (size_t)m * fused::LUT_PAD));
+    }
+    uint8_t* s2 = base + (size_t)3 * fused::LUT_PAD;
+    for (int m = 0; m < 3; ++m)
+        for (int r = 0; r < 2; ++r) {
+            if (!L->s2[m][r]) return LERF_EINVAL;
+            int l = m * 2 + r;
+            if (L->oC == 3)
+                hipLaunchKernelGGL(pack_dwords_kernel, grid, block, 0, st, L->s2[m][r],
+                                   (uint32_t*)(s2 + (size_t)l * fused::LUT_PAD * 4));
+            else
+                hipLaunchKernelGGL(pack_bytes_kernel, grid, block, 0, st, L->s2[m][r],
+                                   (int8_t*)(s2 + (size_t)l * fused::LUT_PAD));
+        }
+    return LERF_OK;
+}
+
 }  // namespace lerf

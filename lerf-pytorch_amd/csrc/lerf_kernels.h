@@ -49,7 +49,6 @@ int launch_lut_stage(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int
                      uint8_t* out, int64_t oy, int64_t ox, int64_t ocs, hipStream_t st);
 int launch_resize(const ResizeArgs& a, hipStream_t st);
 int launch_warp(const WarpArgs& a, hipStream_t st);
-int launch_lut_pack(const int8_t* lut, int oC, uint32_t* packed, hipStream_t st);
 
 // lerf_fused.hip
 struct FusedArgs {
@@ -62,6 +61,8 @@ struct FusedArgs {
     void* workspace;
 };
 bool fused_supported(const FusedArgs& a);
+size_t fused_lutpack_bytes(int oC);
+int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st);
 int launch_sr_fused(const FusedArgs& a, hipStream_t st);
 
 }  // namespace lerf

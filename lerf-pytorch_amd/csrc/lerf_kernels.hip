@@ -12,6 +12,7 @@
 // CHW tensors, arbitrary modes / support sizes).  The tile-fused uint8 path
 // lives in lerf_fused.hip.
 #include "lerf_kernels.h"
+#include "lerf_stage3.h"
 
 namespace lerf {
 
@@ -117,7 +118,7 @@ int launch_lut_stage(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int
 template <typename T> struct Loader;
 template <> struct Loader<uint8_t> {
     // hyper numerators: h = float32(u8) / 255 exactly as eval_lut_sr.py:623-628
-    static __device__ __forceinline__ float hyper(const uint8_t* p) { return (float)(*p) / 255.0f; }
+    static __device__ __forceinline__ float hyper(const uint8_t* p) { return s3::u8_over_255((float)(*p)); }
     static __device__ __forceinline__ float pixel(const uint8_t* p) { return (float)(*p); }
 };
 template <> struct Loader<float> {
@@ -128,11 +129,7 @@ template <> struct Loader<float> {
 template <typename T> struct Storer;
 template <> struct Storer<uint8_t> {
     // clip(np.round(x), 0, 255).astype(uint8)  (eval_lut_sr.py:663-665); NaN -> 0
-    template <typename A> static __device__ __forceinline__ void put(uint8_t* p, A v) {
-        float f = (float)v;
-        int r = (f != f) ? 0 : __float2int_rn(fminf(fmaxf(f, -1.0f), 256.0f));
-        *p = (uint8_t)clampi(r, 0, 255);
-    }
+    template <typename A> static __device__ __forceinline__ void put(uint8_t* p, A v) { *p = s3::to_u8((float)v); }
 };
 template <> struct Storer<float> {
     template <typename A> static __device__ __forceinline__ void put(float* p, A v) { *p = (float)v; }
@@ -229,6 +226,31 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
     int lr = left_r[i], lc = left_c[j];
     A num = 0, den = 0;
     // the reference sums column-offset major, row-offset minor (numpy meshgrid 'xy', :95-98)
+    if (ST > 0 && sizeof(A) == 4) {
+        // float32 production path: same arithmetic as the tile-fused kernel (lerf_stage3.h)
+        float e[MAXS * MAXS], v[MAXS * MAXS];
+#pragma unroll
+        for (int a = 0; a < MAXS; ++a) {
+#pragma unroll
+            for (int b = 0; b < MAXS; ++b) {
+                int rr = lr + b, cc = lc + a;
+                int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
+                bool inside = (rr == rcl) && (cc == ccl);
+                v[a * MAXS + b] = inside ? Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : 0.0f;   // zero pad (:208)
+                int64_t ho = rcl * hy + ccl * hx + c * hc;                                                    // edge pad (:172-174)
+                float dx = (float)dis_r[i * S + b], dy = (float)dis_c[j * S + a];
+                if (KIND == LERF_KIND_GAUSS) {
+                    e[a * MAXS + b] = s3::gauss_form(Loader<TH>::hyper(h0 + ho), Loader<TH>::hyper(h1 + ho),
+                                                     Loader<TH>::hyper(h2 + ho), (float)max_sigma, dx, dy);
+                } else {
+                    float alpha = s3::lin_alpha_of(Loader<TH>::hyper(h0 + ho), (float)max_sigma);
+                    e[a * MAXS + b] = s3::lin_factor(alpha, dx, s3::dist_class_f(dx)) * s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
+                }
+            }
+        }
+        Storer<TO>::put(out + i * oy + j * ox + c * oc, s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS>(e, v));
+        return;
+    }
     if (ST > 0) {
         TapAcc<A, KIND, MAXS * MAXS> acc;
 #pragma unroll
@@ -418,26 +440,6 @@ int launch_warp(const WarpArgs& a, hipStream_t st) {
         if (a.out_dtype == LERF_F64) return warp_dispatch_kind<float, float, double, double>(a, st);
     }
     return LERF_EUNSUPPORTED;
-}
-
-// ---------------------------------------------------------------------------
-// stage-2 LUT repack: [17^4][oC] int8 -> uint32 per entry, biased bytes
-//   bits  0.. 7 = e0 + 128, bits 8..15 = e1 + 128, bits 16..23 = e2 + 128
-// (oC = 1: only e0).  The tiled kernels read A = d & 0x00FF00FF (e0 | e2<<16)
-// and B = (d >> 8) & 0xFF and accumulate both fields of A with one 24-bit MAD.
-// ---------------------------------------------------------------------------
-__global__ void lut_pack_kernel(const int8_t* __restrict__ lut, int oC, uint32_t* __restrict__ packed) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= LERF_LUT_ENTRIES) return;
-    uint32_t d = 0;
-    for (int k = 0; k < oC; ++k) d |= (uint32_t)((int)lut[i * oC + k] + 128) << (8 * k);
-    packed[i] = d;
-}
-
-int launch_lut_pack(const int8_t* lut, int oC, uint32_t* packed, hipStream_t st) {
-    if (oC < 1 || oC > 3) return LERF_EUNSUPPORTED;
-    hipLaunchKernelGGL(lut_pack_kernel, dim3((LERF_LUT_ENTRIES + 255) / 256), dim3(256), 0, st, lut, oC, packed);
-    return LERF_OK;
 }
 
 }  // namespace lerf

@@ -62,13 +62,16 @@ class LutSet:
                 t = self._up(arrays[key], self.oC)
                 self.tensors[key] = t
                 st.s2[i][r] = t.data_ptr()
-                p = torch.empty(_lib.LERF_LUT_ENTRIES, dtype=torch.int32, device=self.device)
-                _lib.check(_lib.lib().lerf_lut_pack_s2(t.data_ptr(), self.oC, p.data_ptr(), _lib.current_stream()),
-                           "lerf_lut_pack_s2")
-                self.tensors[key + "_packed"] = p
-                st.s2_packed[i][r] = p.data_ptr()
         self.struct = st
-        self.nbytes = sum(v.numel() for k, v in self.tensors.items() if not k.endswith("_packed"))
+        st.fused_pack = None
+        if modes == "sct" and modes2 == "sct":
+            nb = int(_lib.lib().lerf_fused_lutpack_bytes(self.oC))
+            pack = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib().lerf_fused_lutpack_build(C.byref(st), pack.data_ptr(), _lib.current_stream()),
+                       "lerf_fused_lutpack_build")
+            self.tensors["fused_pack"] = pack
+            st.fused_pack = pack.data_ptr()
+        self.nbytes = sum(v.numel() for k, v in self.tensors.items() if k != "fused_pack")
 
     def _up(self, a, oC):
         import torch
