@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblerf_hip.so")
+# LERF_HIP_LIB selects a diagnostic build (tools/stamps.py); the default is the in-tree product library
+LIB_PATH = os.environ.get("LERF_HIP_LIB") or os.path.join(_HERE, "liblerf_hip.so")
 
 LERF_MAX_MODES = 5
 LERF_LUT_ENTRIES = 83521

@@ -72,8 +72,8 @@ struct Dims {
     static constexpr int SZ_GEO = 2 * GEO_ROWS * (4 + 4 * S);
     static constexpr int END3 = OFF_GEO + SZ_GEO;
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-    static constexpr int LDS_BYTES = cmax(END1, cmax(END2, END3)) + 64;   // + small control block
-    static constexpr int OFF_CTL = LDS_BYTES - 64;
+    static constexpr int LDS_BYTES = cmax(END1, cmax(END2, END3)) + 512;  // + small control block
+    static constexpr int OFF_CTL = LDS_BYTES - 512;
 };
 
 struct Params {
@@ -84,7 +84,18 @@ struct Params {
     const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
     float max_sigma;
     int s2off[6][6];                 // stage-2 LUT l: feat-tile byte offsets of pixels b,c,d for rotations par, par+2
+    unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
 };
+
+#ifdef LERF_STAMPS
+#define LERF_STAMP(k) do { if (tid == 0) P.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LERF_STAMP_ADD(k, t0) do { if (tid == 0) P.stamps[(size_t)blockIdx.x * 16 + (k)] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define LERF_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define LERF_STAMP(k) do {} while (0)
+#define LERF_STAMP_ADD(k, t0) do {} while (0)
+#define LERF_NOW() 0ull
+#endif
 
 // byte offsets of the 3 non-centre pixels of (mode, rot) in a u8 tile of pitch P
 struct Off3 { int o[3]; };
@@ -106,23 +117,64 @@ __host__ __device__ constexpr Off3 tile_offsets(char mode, int rot) {
 }
 
 // ---------------------------------------------------------------------------
-// simplex walk on a byte LUT in LDS: returns the numerator (sum w*P, weights sum 16)
+// simplex walk (index/weight computation only).  Keys are (LSB << 16) | axis stride so that one
+// unsigned sort orders the four axes by decreasing LSB (ties: zero weight, any order).
+// STRIDE_SCALE = bytes per LUT entry, folded into the strides so idx[] are byte offsets.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int simplex_bytes(const int8_t* __restrict__ lut, int va, int vb, int vc, int vd) {
-    SimplexPath p = simplex_path(va, vb, vc, vd);
-    int acc = p.w[0] * (int)lut[p.idx[0]];
-    acc += p.w[1] * (int)lut[p.idx[1]];
-    acc += p.w[2] * (int)lut[p.idx[2]];
-    acc += p.w[3] * (int)lut[p.idx[3]];
-    acc += p.w[4] * (int)lut[p.idx[4]];
-    return acc;
+template <int STRIDE_SCALE>
+__device__ __forceinline__ void simplex_walk(unsigned ka, int basea, int vb, int vc, int vd, int (&idx)[5], unsigned (&w)[5]) {
+    unsigned k0 = ka;
+    unsigned k1 = ((unsigned)(vb & 15) << 16) | (unsigned)(kStrideB * STRIDE_SCALE);
+    unsigned k2 = ((unsigned)(vc & 15) << 16) | (unsigned)(kStrideC * STRIDE_SCALE);
+    unsigned k3 = ((unsigned)(vd & 15) << 16) | (unsigned)(kStrideD * STRIDE_SCALE);
+    idx[0] = basea + (int)__umul24((unsigned)(vb >> 4), kStrideB * STRIDE_SCALE) +
+             (int)__umul24((unsigned)(vc >> 4), kStrideC * STRIDE_SCALE) + (vd >> 4) * STRIDE_SCALE;
+    ce_desc(k0, k1);
+    ce_desc(k2, k3);
+    ce_desc(k0, k2);
+    ce_desc(k1, k3);
+    ce_desc(k1, k2);
+    const unsigned f0 = k0 >> 16, f1 = k1 >> 16, f2 = k2 >> 16, f3 = k3 >> 16;
+    idx[1] = idx[0] + (int)(k0 & 0xFFFFu);
+    idx[2] = idx[1] + (int)(k1 & 0xFFFFu);
+    idx[3] = idx[2] + (int)(k2 & 0xFFFFu);
+    idx[4] = idx[3] + (int)(k3 & 0xFFFFu);
+    w[0] = kQ - f0;
+    w[1] = f0 - f1;
+    w[2] = f1 - f2;
+    w[3] = f2 - f3;
+    w[4] = f3;
 }
 
-__device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__ src, int bytes, int tid) {
-    const uint4* s = reinterpret_cast<const uint4*>(src);
-    uint4* d = reinterpret_cast<uint4*>(dst);
-    const int n = (bytes + 15) >> 4;
-    for (int i = tid; i < n; i += NT) d[i] = s[i];
+// global -> LDS copy of `bytes` (rounded up to 16) by the whole workgroup; every load of a
+// thread is issued before its first LDS write so the L2 latency is paid once per copy
+template <int BYTES>
+struct Stage16 {
+    static constexpr int n = (BYTES + 15) >> 4;
+    static constexpr int FULL = n / NT;       // iterations every thread takes part in
+    static constexpr int TAIL = n - FULL * NT;
+    uint4 r[FULL];
+    uint4 rt;
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ src, int tid) {
+        const uint4* s = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+        for (int i = 0; i < FULL; ++i) r[i] = s[tid + i * NT];
+        rt = make_uint4(0, 0, 0, 0);
+        if (TAIL > 0 && tid < TAIL) rt = s[tid + FULL * NT];
+    }
+    __device__ __forceinline__ void store(uint8_t* dst, int tid) const {
+        uint4* d = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+        for (int i = 0; i < FULL; ++i) d[tid + i * NT] = r[i];
+        if (TAIL > 0 && tid < TAIL) d[tid + FULL * NT] = rt;
+    }
+};
+
+template <int BYTES>
+__device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__ src, int tid) {
+    Stage16<BYTES> st;
+    st.load(src, tid);
+    st.store(dst, tid);
 }
 
 // One byte-LUT phase over a destination region of NDST px-ch positions (row pitch DP)
@@ -131,14 +183,36 @@ __device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__
 // 2 = add and finalise with (div, bias) into `dst8`.
 template <int SP, char MODE, int ROT0, int NROT, int RSTEP>
 __device__ __forceinline__ int byte_lookups(const int8_t* lut, const uint8_t* src_center) {
-    int va = src_center[0];
-    int acc = 0;
+    // stage A: every pixel read of the NROT rotations
+    const int va = src_center[0];
+    int vb[NROT], vc[NROT], vd[NROT];
 #pragma unroll
     for (int i = 0; i < NROT; ++i) {
-        const int r = ROT0 + i * RSTEP;
-        Off3 o = tile_offsets<SP>(MODE, r);
-        acc += simplex_bytes(lut, va, src_center[o.o[0]], src_center[o.o[1]], src_center[o.o[2]]);
+        const Off3 o = tile_offsets<SP>(MODE, ROT0 + i * RSTEP);
+        vb[i] = src_center[o.o[0]];
+        vc[i] = src_center[o.o[1]];
+        vd[i] = src_center[o.o[2]];
     }
+    // stage B: walks
+    const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)kStrideA;
+    const int basea = (int)__umul24((unsigned)(va >> 4), kStrideA);
+    int idx[NROT][5];
+    unsigned w[NROT][5];
+#pragma unroll
+    for (int i = 0; i < NROT; ++i) simplex_walk<1>(ka, basea, vb[i], vc[i], vd[i], idx[i], w[i]);
+    // stage C: all LUT gathers in flight together
+    int e[NROT][5];
+#pragma unroll
+    for (int i = 0; i < NROT; ++i)
+#pragma unroll
+        for (int n = 0; n < 5; ++n) e[i][n] = (int)lut[idx[i][n]];
+    __builtin_amdgcn_sched_barrier(0);
+    // stage D: MACs
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < NROT; ++i)
+#pragma unroll
+        for (int n = 0; n < 5; ++n) acc += __mul24((int)w[i][n], e[i][n]);
     return acc;
 }
 
@@ -213,6 +287,10 @@ sr_fused_kernel(Params P) {
     uint8_t* Bt = smem + D::OFF_B;
     int* ctl = reinterpret_cast<int*>(smem + D::OFF_CTL);
 
+    LERF_STAMP(0);
+#ifdef LERF_STAMPS
+    if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
+#endif
     // ---- input tile with clamped coordinates (np.pad(..., 'edge') in every rotated frame)
     {
         uint8_t* Ct = smem + D::OFF_C;
@@ -232,18 +310,24 @@ sr_fused_kernel(Params P) {
         int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
         int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
         const int div1 = kQ * 3;
-        copy16(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, LERF_LUT_ENTRIES, tid);
+        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
         __syncthreads();
+        LERF_STAMP(1);
         byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
         __syncthreads();
-        copy16(smem + D::OFF_LUT, P.pack + 1 * LUT_PAD, LERF_LUT_ENTRIES, tid);
+        LERF_STAMP(2);
+        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 1 * LUT_PAD, tid);
         __syncthreads();
+        LERF_STAMP(3);
         byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
         __syncthreads();
-        copy16(smem + D::OFF_LUT, P.pack + 2 * LUT_PAD, LERF_LUT_ENTRIES, tid);
+        LERF_STAMP(4);
+        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 2 * LUT_PAD, tid);
         __syncthreads();
+        LERF_STAMP(5);
         byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
         __syncthreads();
+        LERF_STAMP(6);
     }
 
     uint32_t* Dt = reinterpret_cast<uint32_t*>(smem + D::OFF_D);
@@ -256,7 +340,7 @@ sr_fused_kernel(Params P) {
         const uint8_t* s2 = P.pack + 3 * LUT_PAD;
         const int div2 = kQ * 12;
 #define LERF_L2(IDX, MODE, PAR, PH)                                                                        \
-        copy16(smem + D::OFF_LUT, s2 + (IDX) * LUT_PAD, LERF_LUT_ENTRIES, tid);                          \
+        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, s2 + (IDX) * LUT_PAD, tid);                          \
         __syncthreads();                                                                                   \
         byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, H, W, div2, 127, tid); \
         __syncthreads();
@@ -288,72 +372,138 @@ sr_fused_kernel(Params P) {
     } else {
         // ---- stage 2, LeRF-G: packed 3-channel LUT quarters, pixels binned by centre >> 6
         uint16_t* lst = reinterpret_cast<uint16_t*>(smem + D::OFF_LST);
-        // ctl[0..3] counts, ctl[4..7] cursors / bases
-        if (tid < 8) ctl[tid] = 0;
+        // Binning without atomics: wave w owns positions [w*PW, (w+1)*PW); per-wave counts per quarter
+        // go through LDS, one thread turns them into segment bases (each quarter padded to a multiple
+        // of NT so that a slot round never mixes quarters), then every wave scatters its ids in order.
+        // ctl[0..3] totals, ctl[8..11] first round, ctl[12..15] end round, ctl[32 + w*4 + q] wave counts/bases
         for (int i = tid; i < MAXR * NT / 2; i += NT) reinterpret_cast<uint32_t*>(lst)[i] = 0xFFFFFFFFu;
-        __syncthreads();
         constexpr int KH = (D::NH + NT - 1) / NT;
-        // pass 1: count
-        for (int k = 0; k < KH; ++k) {
-            int p = k * NT + tid;
-            int q = -1;
-            if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, nullptr)] >> 6;
+        constexpr int PW = KH * 64;
+        uint32_t qpack = 0;                     // 2 bits per owned position
+        {
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                unsigned long long m = __ballot(q == qq);
-                if (lane == 0 && m) atomicAdd(&ctl[qq], __popcll(m));
+            for (int k = 0; k < KH; ++k) {
+                const int p = wave * PW + k * 64 + lane;
+                int q = 4;
+                if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, nullptr)] >> 6;
+                qpack |= (uint32_t)(q & 3) << (2 * k);
+                c0 += __popcll(__ballot(q == 0));
+                c1 += __popcll(__ballot(q == 1));
+                c2 += __popcll(__ballot(q == 2));
+                c3 += __popcll(__ballot(q == 3));
+            }
+            if (lane == 0) {
+                ctl[32 + wave * 4 + 0] = c0;
+                ctl[32 + wave * 4 + 1] = c1;
+                ctl[32 + wave * 4 + 2] = c2;
+                ctl[32 + wave * 4 + 3] = c3;
             }
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 4) {
+            int tot = 0;
+            for (int w = 0; w < NW; ++w) tot += ctl[32 + w * 4 + tid];
+            ctl[tid] = tot;
+        }
+        __syncthreads();
+        if (tid < 4) {
             int base = 0;
-            for (int qq = 0; qq < 4; ++qq) {
-                ctl[4 + qq] = base;                 // cursor
-                ctl[8 + qq] = base / NT;            // first round of the quarter
-                base += (ctl[qq] + NT - 1) / NT * NT;
-                ctl[12 + qq] = base / NT;           // one past its last round
+            for (int qq = 0; qq < tid; ++qq) base += (ctl[qq] + NT - 1) / NT * NT;
+            ctl[8 + tid] = base / NT;                                   // first round of the quarter
+            ctl[12 + tid] = (base + (ctl[tid] + NT - 1) / NT * NT) / NT;  // one past its last round
+            for (int w = 0; w < NW; ++w) {                              // exclusive prefix over waves
+                const int c = ctl[32 + w * 4 + tid];
+                ctl[32 + w * 4 + tid] = base;
+                base += c;
             }
         }
         __syncthreads();
-        // pass 2: scatter position ids into the quarter segments
-        for (int k = 0; k < KH; ++k) {
-            int p = k * NT + tid;
-            int q = -1;
-            if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, nullptr)] >> 6;
+        {
+            int cur0 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 0]);
+            int cur1 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 1]);
+            int cur2 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 2]);
+            int cur3 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 3]);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                unsigned long long m = __ballot(q == qq);
-                if (m) {
-                    int start = 0;
-                    if (lane == 0) start = atomicAdd(&ctl[4 + qq], __popcll(m));
-                    start = __shfl(start, 0);
-                    if (q == qq) lst[start + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
-                }
+            for (int k = 0; k < KH; ++k) {
+                const int p = wave * PW + k * 64 + lane;
+                const int q = p < D::NH ? (int)((qpack >> (2 * k)) & 3u) : 4;
+                const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2),
+                                         m3 = __ballot(q == 3);
+                const unsigned long long mm = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
+                const int cur = q == 0 ? cur0 : (q == 1 ? cur1 : (q == 2 ? cur2 : cur3));
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                if (q < 4) lst[cur + rank] = (uint16_t)p;
+                cur0 += __popcll(m0);
+                cur1 += __popcll(m1);
+                cur2 += __popcll(m2);
+                cur3 += __popcll(m3);
             }
         }
         __syncthreads();
-        // slots -> registers: (feat-tile address of the clamped centre) | p << 16
-        uint32_t slot[MAXR];
-        uint32_t accA[MAXR], accB[MAXR];
+        // slots -> registers.  Per slot: the feat-tile address of its clamped centre (16 bits, two slots per
+        // VGPR; 0xFFFF = padding) and three 16-bit accumulators (accA: e0 | e2 << 16; accB: e1, two slots
+        // per VGPR).  The position ids stay in LST and are re-read when the sums are finalised.
+        constexpr int MAXP = (MAXR + 1) / 2;
+        uint32_t slot2[MAXP];
+        uint32_t accA[MAXR], accB2[MAXP];
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
-            uint32_t p = lst[k * NT + tid];
-            uint32_t a = 0;
+            const uint32_t p = lst[k * NT + tid];
+            uint32_t a = 0xFFFFu;
             if (p != 0xFFFFu) a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, H, W, nullptr);
-            slot[k] = a | (p << 16);
+            if (k & 1) slot2[k >> 1] |= a << 16; else slot2[k >> 1] = a;
             accA[k] = 0;
-            accB[k] = 0;
+            if (!(k & 1)) accB2[k >> 1] = 0;
         }
         __syncthreads();
 
-        const uint32_t* qlut = reinterpret_cast<const uint32_t*>(smem + D::OFF_X);
+        LERF_STAMP(7);
         const uint32_t* s2 = reinterpret_cast<const uint32_t*>(P.pack + 3 * LUT_PAD);
-        for (int q = 0; q < 4; ++q) {
-            if (ctl[q] == 0) continue;             // uniform: nobody in this quarter
-            for (int l = 0; l < 6; ++l) {
-                // LUT l = mode (l>>1), rotation parity (l&1); rotations par, par+2
-                copy16(smem + D::OFF_X, reinterpret_cast<const uint8_t*>(s2 + (size_t)l * LUT_PAD + q * QSTRIDE),
-                       QENTRIES * 4, tid);
+        // phases = (non-empty quarter) x (6 LUTs).  The next piece is fetched into registers while the
+        // current one is being used, so the L2 latency of the piece copies hides behind the lookups.
+        int nph = 0;
+        {
+            int nq = 0;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int c = __builtin_amdgcn_readfirstlane(ctl[qq]);
+                if (c > 0) {
+                    if (tid == 0) ctl[24 + nq] = qq;
+                    ++nq;
+                }
+            }
+            nph = nq * 6;
+        }
+        __syncthreads();
+        // explicit scalars (a struct/array here ends up in scratch): 6 x uint4 per thread cover the 6142 uint4
+        static_assert((QENTRIES * 4 + 15) / 16 > 5 * NT && (QENTRIES * 4 + 15) / 16 <= 6 * NT, "piece = 6 uint4 per thread");
+        constexpr int PTAIL = (QENTRIES * 4 + 15) / 16 - 5 * NT;
+        uint4 pr0, pr1, pr2, pr3, pr4, pr5;
+        pr0 = pr1 = pr2 = pr3 = pr4 = pr5 = make_uint4(0, 0, 0, 0);
+#define LERF_PRE_LOAD(SRC)                                                     \
+        do {                                                                   \
+            const uint4* s_ = reinterpret_cast<const uint4*>(SRC);             \
+            pr0 = s_[tid]; pr1 = s_[tid + NT]; pr2 = s_[tid + 2 * NT];         \
+            pr3 = s_[tid + 3 * NT]; pr4 = s_[tid + 4 * NT];                    \
+            if (tid < PTAIL) pr5 = s_[tid + 5 * NT];                           \
+        } while (0)
+#define LERF_PRE_STORE(DST)                                                    \
+        do {                                                                   \
+            uint4* d_ = reinterpret_cast<uint4*>(DST);                         \
+            d_[tid] = pr0; d_[tid + NT] = pr1; d_[tid + 2 * NT] = pr2;         \
+            d_[tid + 3 * NT] = pr3; d_[tid + 4 * NT] = pr4;                    \
+            if (tid < PTAIL) d_[tid + 5 * NT] = pr5;                           \
+        } while (0)
+        if (nph > 0) LERF_PRE_LOAD(s2 + (size_t)__builtin_amdgcn_readfirstlane(ctl[24]) * QSTRIDE);
+        for (int ph = 0; ph < nph; ++ph) {
+            {
+                const int qi = ph / 6;
+                const int l = ph - qi * 6;                       // LUT l = mode (l>>1), rotation parity (l&1)
+                const int q = __builtin_amdgcn_readfirstlane(ctl[24 + qi]);
+                const unsigned long long t_copy = LERF_NOW();
+                (void)t_copy;
+                LERF_PRE_STORE(smem + D::OFF_X);
                 Off3 o0, o1;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -363,66 +513,72 @@ sr_fused_kernel(Params P) {
                 const int rsq = __builtin_amdgcn_readfirstlane(ctl[8 + q]);
                 const int req = __builtin_amdgcn_readfirstlane(ctl[12 + q]);
                 __syncthreads();
+                if (ph + 1 < nph) {
+                    const int qi2 = (ph + 1) / 6;
+                    const int l2 = (ph + 1) - qi2 * 6;
+                    const int q2 = __builtin_amdgcn_readfirstlane(ctl[24 + qi2]);
+                    LERF_PRE_LOAD(s2 + (size_t)l2 * LUT_PAD + q2 * QSTRIDE);
+                }
+                LERF_STAMP_ADD(8, t_copy);
+                const unsigned long long t_look = LERF_NOW();
+                (void)t_look;
 #pragma unroll
                 for (int k = 0; k < MAXR; ++k) {
                     if (k >= rsq && k < req) {
-                        const uint32_t sl = slot[k];
-                        if ((sl >> 16) != 0xFFFFu) {
-                            const uint8_t* cp = Bt + (sl & 0xFFFFu);
+                        const uint32_t sa = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
+                        if (sa != 0xFFFFu) {
+                            const uint8_t* cp = Bt + sa;
+                            // stage A: the 7 pixel reads of the two rotations
                             const int va = cp[0];
-                            const int basea = ((va >> 4) - 4 * q) * kStrideA;
-                            const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)kStrideA;
+                            const int vb0 = cp[o0.o[0]], vc0 = cp[o0.o[1]], vd0 = cp[o0.o[2]];
+                            const int vb1 = cp[o1.o[0]], vc1 = cp[o1.o[1]], vd1 = cp[o1.o[2]];
+                            // stage B: both walks (byte offsets into the quarter piece)
+                            const int basea = (int)__umul24((unsigned)((va >> 4) - 4 * q), kStrideA * 4);
+                            const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)(kStrideA * 4);
+                            int i0x[5], i1x[5];
+                            unsigned w0[5], w1[5];
+                            simplex_walk<4>(ka, basea, vb0, vc0, vd0, i0x, w0);
+                            simplex_walk<4>(ka, basea, vb1, vc1, vd1, i1x, w1);
+                            // stage C: ten dword gathers in flight together
+                            const uint8_t* qb = smem + D::OFF_X;
+                            uint32_t d0[5], d1[5];
 #pragma unroll
-                            for (int rr = 0; rr < 2; ++rr) {
-                                const Off3& o = rr == 0 ? o0 : o1;
-                                const int vb = cp[o.o[0]], vc = cp[o.o[1]], vd = cp[o.o[2]];
-                                unsigned k0 = ka;
-                                unsigned k1 = ((unsigned)(vb & 15) << 16) | (unsigned)kStrideB;
-                                unsigned k2 = ((unsigned)(vc & 15) << 16) | (unsigned)kStrideC;
-                                unsigned k3 = ((unsigned)(vd & 15) << 16) | (unsigned)kStrideD;
-                                int idx = basea + (vb >> 4) * kStrideB + (vc >> 4) * kStrideC + (vd >> 4);
-                                ce_desc(k0, k1);
-                                ce_desc(k2, k3);
-                                ce_desc(k0, k2);
-                                ce_desc(k1, k3);
-                                ce_desc(k1, k2);
-                                const unsigned f0 = k0 >> 16, f1 = k1 >> 16, f2 = k2 >> 16, f3 = k3 >> 16;
-                                uint32_t d, w;
-                                uint32_t a = accA[k], b = accB[k];
-                                d = qlut[idx]; w = kQ - f0;
-                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
-                                idx += (int)(k0 & 0xFFFFu);
-                                d = qlut[idx]; w = f0 - f1;
-                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
-                                idx += (int)(k1 & 0xFFFFu);
-                                d = qlut[idx]; w = f1 - f2;
-                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
-                                idx += (int)(k2 & 0xFFFFu);
-                                d = qlut[idx]; w = f2 - f3;
-                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
-                                idx += (int)(k3 & 0xFFFFu);
-                                d = qlut[idx]; w = f3;
-                                a += w * (d & 0x00FF00FFu); b += w * ((d >> 8) & 0xFFu);
-                                accA[k] = a;
-                                accB[k] = b;
+                            for (int n = 0; n < 5; ++n) d0[n] = *reinterpret_cast<const uint32_t*>(qb + i0x[n]);
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) d1[n] = *reinterpret_cast<const uint32_t*>(qb + i1x[n]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // stage D: two 24-bit MADs per corner (fields e0|e2<<16, and e1)
+                            uint32_t a = accA[k], bb = accB2[k >> 1];
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) {
+                                a += __umul24(w0[n], d0[n] & 0x00FF00FFu);
+                                bb += __umul24(w0[n], (k & 1) ? ((d0[n] << 8) & 0x00FF0000u) : ((d0[n] >> 8) & 0xFFu));
                             }
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) {
+                                a += __umul24(w1[n], d1[n] & 0x00FF00FFu);
+                                bb += __umul24(w1[n], (k & 1) ? ((d1[n] << 8) & 0x00FF0000u) : ((d1[n] >> 8) & 0xFFu));
+                            }
+                            accA[k] = a;
+                            accB2[k >> 1] = bb;
                         }
                     }
                 }
                 __syncthreads();
+                LERF_STAMP_ADD(9, t_look);
             }
         }
+        LERF_STAMP(10);
         // finalise: hq = rne(clip(N/192 + 127)); entries are biased by +128 -> 12 lookups * 16 * 128 = 24576
         //           N + 127*192 = field - 24576 + 24384 = field - 192
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
-            const uint32_t sl = slot[k];
-            const uint32_t p = sl >> 16;
+            const uint32_t p = lst[k * NT + tid];
             if (p != 0xFFFFu) {
                 const int div2 = kQ * 12;
                 int n0 = (int)(accA[k] & 0xFFFFu) - div2;
                 int n2 = (int)(accA[k] >> 16) - div2;
-                int n1 = (int)accB[k] - div2;
+                int n1 = (int)((k & 1) ? (accB2[k >> 1] >> 16) : (accB2[k >> 1] & 0xFFFFu)) - div2;
                 uint32_t h0 = (uint32_t)rne_div_clip255(n0, div2);
                 uint32_t h1 = (uint32_t)rne_div_clip255(n1, div2);
                 uint32_t h2 = (uint32_t)rne_div_clip255(n2, div2);
@@ -444,6 +600,8 @@ sr_fused_kernel(Params P) {
         ctl[17] = tyi == P.tiles_y - 1 ? P.oH : lower_bound_i(P.left_r, P.oH, ty0 + TH - D::R3);
         ctl[18] = txi == 0 ? 0 : lower_bound_i(P.left_c, P.oW, tx0 - D::R3);
         ctl[19] = txi == P.tiles_x - 1 ? P.oW : lower_bound_i(P.left_c, P.oW, tx0 + TW - D::R3);
+        const unsigned ndw0 = (unsigned)(((ctl[19] - ctl[18]) * CH + 6) >> 2);
+        ctl[20] = (int)(unsigned)((0x100000000ull + ndw0 - 1) / (ndw0 ? ndw0 : 1));
     }
     __syncthreads();
     const int i0 = ctl[16], i1 = ctl[17], j0 = ctl[18], j1 = ctl[19];
@@ -460,43 +618,68 @@ sr_fused_kernel(Params P) {
     }
     __syncthreads();
 
-    // ---- stage 3: one wave per output row, lanes along (column, channel)
-    const int ncolc = ncol * CH;
-    const float ms = P.max_sigma;
-    for (int il = wave; il < nrow; il += NW) {
-        const int lr = g_lr[il];
-        float dxr[S];
+    LERF_STAMP(11);
+    // ---- stage 3: one task = one 4-byte-aligned dword of an output row segment (coalesced dword stores)
+    {
+        const int ncolc = ncol * CH;
+        const int ndw = (ncolc + 6) >> 2;                         // dwords that can touch a row segment
+        const unsigned magic = (unsigned)ctl[20];                 // ceil(2^32 / ndw)
+        const float ms255 = P.max_sigma * (1.0f / 255.0f);
+        const int64_t rowpitch = (int64_t)P.oW * CH;
+        uint8_t* seg0 = outp + ((int64_t)i0 * P.oW + j0) * CH;
+        const int ntask = nrow * ndw;
+        for (int t = tid; t < ntask; t += NT) {
+            const int il = (int)__umulhi((unsigned)t, magic);
+            const int dw = t - il * ndw;
+            uint8_t* seg = seg0 + il * rowpitch;
+            const int a0 = (int)(reinterpret_cast<uintptr_t>(seg) & 3u);
+            const int b0 = dw * 4 - a0;                           // first byte of this dword, relative to the segment
+            const int lr = g_lr[il];
+            float dxr[S];
 #pragma unroll
-        for (int b = 0; b < S; ++b) dxr[b] = g_dr[il * S + b];
-        uint8_t* orow = outp + ((int64_t)(i0 + il) * P.oW + j0) * CH;
-        for (int xc = lane; xc < ncolc; xc += 64) {
-            const int jl = xc / CH;
-            const int c = xc - jl * CH;
-            const int lc = g_lc[jl];
-            float e[S * S], v[S * S];
+            for (int b = 0; b < S; ++b) dxr[b] = g_dr[il * S + b];
+            uint32_t packed = 0;
 #pragma unroll
-            for (int a = 0; a < S; ++a) {                 // column offset major (numpy meshgrid 'xy', :95-98)
-                const float dy = g_dc[jl * S + a];
+            for (int u = 0; u < 4; ++u) {
+                const int xc = min(max(b0 + u, 0), ncolc - 1);    // clamped; invalid bytes are not stored
+                const int jl = xc / CH;
+                const int c = xc - jl * CH;
+                const int lc = g_lc[jl];
+                float e[S * S], v[S * S];
 #pragma unroll
-                for (int b = 0; b < S; ++b) {
-                    const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                    const float dx = dxr[b];
-                    v[a * S + b] = (float)(d >> 24);
-                    const float h0 = s3::u8_over_255((float)(d & 0xFFu));
-                    if (KIND == LERF_KIND_GAUSS) {
-                        const float h1 = s3::u8_over_255((float)((d >> 8) & 0xFFu));
-                        const float h2 = s3::u8_over_255((float)((d >> 16) & 0xFFu));
-                        e[a * S + b] = s3::gauss_form(h0, h1, h2, ms, dx, dy);
-                    } else {
-                        const float alpha = s3::lin_alpha_of(h0, ms);
-                        e[a * S + b] = s3::lin_factor(alpha, dx, s3::dist_class_f(dx)) *
-                                       s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
+                for (int a = 0; a < S; ++a) {                     // column offset major (numpy meshgrid 'xy', :95-98)
+                    const float dy = g_dc[jl * S + a];
+#pragma unroll
+                    for (int b = 0; b < S; ++b) {
+                        const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                        const float dx = dxr[b];
+                        v[a * S + b] = (float)(d >> 24);
+                        const float k0 = (float)(d & 0xFFu);
+                        if (KIND == LERF_KIND_GAUSS) {
+                            e[a * S + b] = s3::gauss_form_u8(k0, (float)((d >> 8) & 0xFFu), (float)((d >> 16) & 0xFFu),
+                                                             ms255, dx, dy);
+                        } else {
+                            const float alpha = s3::lin_alpha_u8(k0, ms255);
+                            e[a * S + b] = s3::lin_factor(alpha, dx, s3::dist_class_f(dx)) *
+                                           s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
+                        }
                     }
                 }
+                packed |= (uint32_t)s3::to_u8(s3::finish<KIND == LERF_KIND_GAUSS, S * S, true>(e, v)) << (8 * u);
             }
-            orow[xc] = s3::to_u8(s3::finish<KIND == LERF_KIND_GAUSS, S * S>(e, v));
+            if (b0 >= 0 && b0 + 3 < ncolc) {
+                *reinterpret_cast<uint32_t*>(seg + b0) = packed;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (b0 + u >= 0 && b0 + u < ncolc) seg[b0 + u] = (uint8_t)(packed >> (8 * u));
+            }
         }
     }
+#ifdef LERF_STAMPS
+    __syncthreads();
+    LERF_STAMP(12);
+#endif
 }
 
 }  // namespace fused
@@ -527,6 +710,7 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     P.pack = (const uint8_t*)a.luts->fused_pack;
     P.left_r = a.left_r; P.dis_r = a.dis_r; P.left_c = a.left_c; P.dis_c = a.dis_c;
     P.max_sigma = a.max_sigma;
+    P.stamps = (unsigned long long*)a.workspace;
     for (int l = 0; l < 6; ++l) {
         const char mc = "sct"[l >> 1];
         fused::Off3 o0 = fused::tile_offsets<D::FP>(mc, l & 1), o1 = fused::tile_offsets<D::FP>(mc, (l & 1) + 2);

@@ -239,16 +239,25 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 v[a * MAXS + b] = inside ? Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : 0.0f;   // zero pad (:208)
                 int64_t ho = rcl * hy + ccl * hx + c * hc;                                                    // edge pad (:172-174)
                 float dx = (float)dis_r[i * S + b], dy = (float)dis_c[j * S + a];
+                // uint8 in / uint8 out: the production arithmetic of the fused kernel (bit-identical results);
+                // float outputs keep the exact float32 parameter formation of the reference
+                constexpr bool U8H = sizeof(TH) == 1 && sizeof(TO) == 1;
+                const float ms255 = (float)max_sigma * (1.0f / 255.0f);
                 if (KIND == LERF_KIND_GAUSS) {
-                    e[a * MAXS + b] = s3::gauss_form(Loader<TH>::hyper(h0 + ho), Loader<TH>::hyper(h1 + ho),
-                                                     Loader<TH>::hyper(h2 + ho), (float)max_sigma, dx, dy);
+                    if (U8H)
+                        e[a * MAXS + b] = s3::gauss_form_u8((float)h0[ho], (float)h1[ho], (float)h2[ho], ms255, dx, dy);
+                    else
+                        e[a * MAXS + b] = s3::gauss_form(Loader<TH>::hyper(h0 + ho), Loader<TH>::hyper(h1 + ho),
+                                                         Loader<TH>::hyper(h2 + ho), (float)max_sigma, dx, dy);
                 } else {
-                    float alpha = s3::lin_alpha_of(Loader<TH>::hyper(h0 + ho), (float)max_sigma);
+                    float alpha = U8H ? s3::lin_alpha_u8((float)h0[ho], ms255)
+                                      : s3::lin_alpha_of(Loader<TH>::hyper(h0 + ho), (float)max_sigma);
                     e[a * MAXS + b] = s3::lin_factor(alpha, dx, s3::dist_class_f(dx)) * s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
                 }
             }
         }
-        Storer<TO>::put(out + i * oy + j * ox + c * oc, s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS>(e, v));
+        Storer<TO>::put(out + i * oy + j * ox + c * oc,
+                        s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1>(e, v));
         return;
     }
     if (ST > 0) {

@@ -35,6 +35,24 @@ __device__ __forceinline__ float gauss_form(float h0, float h1, float h2, float 
     return __builtin_fmaf(ty, ty, e);
 }
 
+// Same form from uint8 hyper numerators k0,k1,k2 (h = k/255).  The reference's float32 chain
+// fl(2*fl(k/255)-1), fl(max_sigma*fl(k/255)) is followed to within one ulp with one operation per
+// parameter; the float32 products below carry the same relative error, so nothing is lost.
+// ms255 = max_sigma * (1/255).
+__device__ __forceinline__ float gauss_form_u8(float k0, float k1, float k2, float ms255, float dx, float dy) {
+#pragma clang fp contract(off)
+    const float rho = __builtin_fmaf(k0, 2.0f / 255.0f, -1.0f);
+    const float tx = (k1 * ms255) * dx, ty = (k2 * ms255) * dy;
+    float e = tx * tx;
+    e = __builtin_fmaf(-2.0f * rho, tx * ty, e);
+    return __builtin_fmaf(ty, ty, e);
+}
+
+__device__ __forceinline__ float lin_alpha_u8(float k0, float ms255) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(k0, 2.0f * ms255, -ms255 * 255.0f);
+}
+
 // exp(-(e - emin)/2): the largest weight of a support is exactly 1
 __device__ __forceinline__ float gauss_weight(float e, float emin) {
 #pragma clang fp contract(off)
@@ -58,7 +76,7 @@ __device__ __forceinline__ float lin_factor(float alpha, float x, int cls) {
 }
 
 // normalised weighted sum over N taps; e[] are quadratic forms (GAUSS) or weights
-template <bool GAUSS, int N>
+template <bool GAUSS, int N, bool FAST = false>
 __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]) {
 #pragma clang fp contract(off)
     float num = 0.0f, den = 0.0f;
@@ -78,6 +96,12 @@ __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]
             num = __builtin_fmaf(e[k], v[k], num);
             den += e[k];
         }
+    }
+    if (FAST) {
+        // uint8 outputs: reciprocal + one Newton step instead of the IEEE division sequence
+        float r = __builtin_amdgcn_rcpf(den);
+        r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+        return num * r;
     }
     return num / den;
 }

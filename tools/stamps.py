@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the tile-fused kernel (diagnostic build with
+in-kernel s_memtime stamps; shares only the source with the shipped library).
+
+    make -C lerf-pytorch_amd/csrc stamps && python tools/stamps.py
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["LERF_HIP_LIB"] = os.path.join(ROOT, "lerf-pytorch_amd", "liblerf_hip_stamps.so")
+
+import numpy as np
+import torch
+import lerf_pytorch_amd as L
+from lerf_pytorch_amd import ops
+import bench
+
+NAMES = ["in+lut0", "s1:s", "copy", "s1:c", "copy", "s1:t", "bin+slots", "s2 copies", "s2 lookups", "(s2 total)",
+         "finalise", "geometry", "stage3"]
+
+
+def main():
+    eng = L.LerfEngine.shipped("lerf-g")
+    geo = eng.sr_geometry((bench.H, bench.W), 2)
+    for kind in ("noise", "natural"):
+        x = torch.from_numpy(bench.synth_frames(kind, 1, 7)).cuda()
+        tiles = ((bench.H + 63) // 64) * ((bench.W + 63) // 64)
+        ws = torch.zeros(max(tiles * 16 * 8, 4 * bench.H * bench.W * 3), dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            ops.sr_fused_u8(x, eng.luts, geo, "gauss", 10.0, workspace=ws)
+        torch.cuda.synchronize()
+        st = ws[:tiles * 16 * 8].view(torch.int64).reshape(tiles, 16).cpu().numpy().astype(np.float64)
+        d = {}
+        d["in+lut0"] = st[:, 1] - st[:, 0]
+        d["s1:s"] = st[:, 2] - st[:, 1]
+        d["copy1"] = st[:, 3] - st[:, 2]
+        d["s1:c"] = st[:, 4] - st[:, 3]
+        d["copy2"] = st[:, 5] - st[:, 4]
+        d["s1:t"] = st[:, 6] - st[:, 5]
+        d["bin+slots"] = st[:, 7] - st[:, 6]
+        d["s2 copies"] = st[:, 8]
+        d["s2 lookups"] = st[:, 9]
+        d["s2 total"] = st[:, 10] - st[:, 7]
+        d["finalise+geo"] = st[:, 11] - st[:, 10]
+        d["stage3"] = st[:, 12] - st[:, 11]
+        d["TOTAL"] = st[:, 12] - st[:, 0]
+        print("== %s: cycles per tile (mean over %d tiles; s_memtime ticks = shader cycles at 100MHz*? see guide)" % (kind, tiles))
+        tot = d["TOTAL"].mean()
+        for k, v in d.items():
+            print("  %-14s %10.0f  %5.1f%%" % (k, v.mean(), 100 * v.mean() / tot))
+
+
+if __name__ == "__main__":
+    main()
