@@ -248,6 +248,25 @@ __device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src
 // ---------------------------------------------------------------------------
 // stage 3 helpers
 // ---------------------------------------------------------------------------
+// first i in [0,n) with a[i] >= key (a is non-decreasing), all 64 lanes of a wave cooperating:
+// 64-way splits, so a table of 8k entries needs three dependent loads instead of thirteen
+__device__ __forceinline__ int wave_lower_bound(const int* __restrict__ a, int n, int key, int lane) {
+    int lo = 0, hi = n;
+    while (hi - lo > 64) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + lane * step;
+        const bool less = idx < hi && a[idx] < key;
+        const int cnt = __popcll(__ballot(less));          // monotone: the first cnt probes are < key
+        const int nlo = cnt > 0 ? lo + (cnt - 1) * step + 1 : lo;
+        const int nhi = cnt < 64 ? min(hi, lo + cnt * step) : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    const int idx = lo + lane;
+    const bool less = idx < hi && a[idx] < key;
+    return lo + __popcll(__ballot(less));
+}
+
 __device__ __forceinline__ int lower_bound_i(const int* __restrict__ a, int n, int key) {
     int lo = 0, hi = n;      // first i with a[i] >= key
     while (lo < hi) {
@@ -595,26 +614,31 @@ sr_fused_kernel(Params P) {
     float* g_dr = reinterpret_cast<float*>(g_lr + D::GEO_ROWS);
     int* g_lc = reinterpret_cast<int*>(g_dr + D::GEO_ROWS * S);
     float* g_dc = reinterpret_cast<float*>(g_lc + D::GEO_ROWS);
-    if (tid == 0) {
-        ctl[16] = tyi == 0 ? 0 : lower_bound_i(P.left_r, P.oH, ty0 - D::R3);
-        ctl[17] = tyi == P.tiles_y - 1 ? P.oH : lower_bound_i(P.left_r, P.oH, ty0 + TH - D::R3);
-        ctl[18] = txi == 0 ? 0 : lower_bound_i(P.left_c, P.oW, tx0 - D::R3);
-        ctl[19] = txi == P.tiles_x - 1 ? P.oW : lower_bound_i(P.left_c, P.oW, tx0 + TW - D::R3);
-        const unsigned ndw0 = (unsigned)(((ctl[19] - ctl[18]) * CH + 6) >> 2);
-        ctl[20] = (int)(unsigned)((0x100000000ull + ndw0 - 1) / (ndw0 ? ndw0 : 1));
+    if (wave < 4) {
+        // four wave-parallel searches for the owned output rows / columns
+        const bool rows = wave < 2;
+        const int* tab = rows ? P.left_r : P.left_c;
+        const int n = rows ? P.oH : P.oW;
+        const int ti = rows ? tyi : txi, tn = rows ? P.tiles_y : P.tiles_x, t0 = rows ? ty0 : tx0;
+        int r;
+        if (!(wave & 1)) r = ti == 0 ? 0 : wave_lower_bound(tab, n, t0 - D::R3, lane);
+        else r = ti == tn - 1 ? n : wave_lower_bound(tab, n, t0 + (rows ? TH : TW) - D::R3, lane);
+        if (lane == 0) ctl[16 + wave] = r;
     }
     __syncthreads();
     const int i0 = ctl[16], i1 = ctl[17], j0 = ctl[18], j1 = ctl[19];
     const int nrow = i1 - i0, ncol = j1 - j0;
+    // LeRF-G: distances are staged pre-multiplied by (max_sigma/255)*sqrt(0.5 log2 e)  (lerf_stage3.h)
+    const float gscale = KIND == LERF_KIND_GAUSS ? s3::gauss_scale(P.max_sigma) : 1.0f;
     for (int e = tid; e < nrow; e += NT) {
         g_lr[e] = P.left_r[i0 + e] - hy0;
 #pragma unroll
-        for (int b = 0; b < S; ++b) g_dr[e * S + b] = P.dis_r[(i0 + e) * S + b];
+        for (int b = 0; b < S; ++b) g_dr[e * S + b] = P.dis_r[(i0 + e) * S + b] * gscale;
     }
     for (int e = tid; e < ncol; e += NT) {
         g_lc[e] = P.left_c[j0 + e] - hx0;
 #pragma unroll
-        for (int a = 0; a < S; ++a) g_dc[e * S + a] = P.dis_c[(j0 + e) * S + a];
+        for (int a = 0; a < S; ++a) g_dc[e * S + a] = P.dis_c[(j0 + e) * S + a] * gscale;
     }
     __syncthreads();
 
@@ -623,7 +647,7 @@ sr_fused_kernel(Params P) {
     {
         const int ncolc = ncol * CH;
         const int ndw = (ncolc + 6) >> 2;                         // dwords that can touch a row segment
-        const unsigned magic = (unsigned)ctl[20];                 // ceil(2^32 / ndw)
+        const unsigned magic = (unsigned)((0x100000000ull + (unsigned)ndw - 1) / (unsigned)(ndw > 0 ? ndw : 1));
         const float ms255 = P.max_sigma * (1.0f / 255.0f);
         const int64_t rowpitch = (int64_t)P.oW * CH;
         uint8_t* seg0 = outp + ((int64_t)i0 * P.oW + j0) * CH;
@@ -656,8 +680,7 @@ sr_fused_kernel(Params P) {
                         v[a * S + b] = (float)(d >> 24);
                         const float k0 = (float)(d & 0xFFu);
                         if (KIND == LERF_KIND_GAUSS) {
-                            e[a * S + b] = s3::gauss_form_u8(k0, (float)((d >> 8) & 0xFFu), (float)((d >> 16) & 0xFFu),
-                                                             ms255, dx, dy);
+                            e[a * S + b] = s3::gauss_form_u8(k0, (float)((d >> 8) & 0xFFu), (float)((d >> 16) & 0xFFu), dx, dy);
                         } else {
                             const float alpha = s3::lin_alpha_u8(k0, ms255);
                             e[a * S + b] = s3::lin_factor(alpha, dx, s3::dist_class_f(dx)) *
@@ -665,7 +688,7 @@ sr_fused_kernel(Params P) {
                         }
                     }
                 }
-                packed |= (uint32_t)s3::to_u8(s3::finish<KIND == LERF_KIND_GAUSS, S * S, true>(e, v)) << (8 * u);
+                packed |= (uint32_t)s3::to_u8(s3::finish<KIND == LERF_KIND_GAUSS, S * S, true, true>(e, v)) << (8 * u);
             }
             if (b0 >= 0 && b0 + 3 < ncolc) {
                 *reinterpret_cast<uint32_t*>(seg + b0) = packed;

@@ -245,7 +245,9 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 const float ms255 = (float)max_sigma * (1.0f / 255.0f);
                 if (KIND == LERF_KIND_GAUSS) {
                     if (U8H)
-                        e[a * MAXS + b] = s3::gauss_form_u8((float)h0[ho], (float)h1[ho], (float)h2[ho], ms255, dx, dy);
+                        e[a * MAXS + b] = s3::gauss_form_u8((float)h0[ho], (float)h1[ho], (float)h2[ho],
+                                                            dx * s3::gauss_scale((float)max_sigma),
+                                                            dy * s3::gauss_scale((float)max_sigma));
                     else
                         e[a * MAXS + b] = s3::gauss_form(Loader<TH>::hyper(h0 + ho), Loader<TH>::hyper(h1 + ho),
                                                          Loader<TH>::hyper(h2 + ho), (float)max_sigma, dx, dy);
@@ -257,7 +259,8 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
             }
         }
         Storer<TO>::put(out + i * oy + j * ox + c * oc,
-                        s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1>(e, v));
+                        s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1,
+                                   sizeof(TH) == 1 && sizeof(TO) == 1>(e, v));
         return;
     }
     if (ST > 0) {

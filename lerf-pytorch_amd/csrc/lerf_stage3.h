@@ -35,17 +35,31 @@ __device__ __forceinline__ float gauss_form(float h0, float h1, float h2, float 
     return __builtin_fmaf(ty, ty, e);
 }
 
-// Same form from uint8 hyper numerators k0,k1,k2 (h = k/255).  The reference's float32 chain
-// fl(2*fl(k/255)-1), fl(max_sigma*fl(k/255)) is followed to within one ulp with one operation per
-// parameter; the float32 products below carry the same relative error, so nothing is lost.
-// ms255 = max_sigma * (1/255).
-__device__ __forceinline__ float gauss_form_u8(float k0, float k1, float k2, float ms255, float dx, float dy) {
+// uint8 production arithmetic (uint8 in -> uint8 out, both the direct and the fused kernel):
+// the quadratic form is evaluated pre-scaled by 0.5*log2(e) so that weight = exp2(emin' - e').
+//   dxs = dx * (max_sigma/255) * sqrt(0.5*log2 e)   (per row tap; gauss_scale())
+//   dys = dy * (max_sigma/255) * sqrt(0.5*log2 e)   (per column tap)
+//   e'  = (k1 dxs)^2 + (k2 dys)^2 - 2 rho (k1 dxs)(k2 dys),  -2 rho = 2 - 4 k0/255
+// The reference forms rho, sigma in float32 from h = fl(k/255) (resize_right2d_numpy.py:168-170);
+// one fused operation per parameter follows that chain to within an ulp, the same size as the
+// rounding of the float32 products that consume it.
+__device__ __forceinline__ float gauss_scale(float max_sigma) {
 #pragma clang fp contract(off)
-    const float rho = __builtin_fmaf(k0, 2.0f / 255.0f, -1.0f);
-    const float tx = (k1 * ms255) * dx, ty = (k2 * ms255) * dy;
-    float e = tx * tx;
-    e = __builtin_fmaf(-2.0f * rho, tx * ty, e);
-    return __builtin_fmaf(ty, ty, e);
+    return (max_sigma * (1.0f / 255.0f)) * 0.84932180028801904272f;        // sqrt(0.5 * log2(e))
+}
+
+__device__ __forceinline__ float gauss_form_u8(float k0, float k1, float k2, float dxs, float dys) {
+#pragma clang fp contract(off)
+    const float m2rho = __builtin_fmaf(k0, -4.0f / 255.0f, 2.0f);
+    const float tx = k1 * dxs, ty = k2 * dys;
+    float e = __builtin_fmaf(ty, ty, tx * tx);
+    return __builtin_fmaf(m2rho, tx * ty, e);
+}
+
+// exp2(emin' - e') for pre-scaled forms
+__device__ __forceinline__ float gauss_weight_scaled(float e, float emin) {
+#pragma clang fp contract(off)
+    return __builtin_amdgcn_exp2f(emin - e);
 }
 
 __device__ __forceinline__ float lin_alpha_u8(float k0, float ms255) {
@@ -76,7 +90,7 @@ __device__ __forceinline__ float lin_factor(float alpha, float x, int cls) {
 }
 
 // normalised weighted sum over N taps; e[] are quadratic forms (GAUSS) or weights
-template <bool GAUSS, int N, bool FAST = false>
+template <bool GAUSS, int N, bool FAST = false, bool SCALED = false>
 __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]) {
 #pragma clang fp contract(off)
     float num = 0.0f, den = 0.0f;
@@ -86,7 +100,7 @@ __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]
         for (int k = 1; k < N; ++k) emin = fminf(emin, e[k]);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const float w = gauss_weight(e[k], emin);
+            const float w = SCALED ? gauss_weight_scaled(e[k], emin) : gauss_weight(e[k], emin);
             num = __builtin_fmaf(w, v[k], num);
             den += w;
         }
