@@ -1,0 +1,124 @@
+"""Multi-GPU partitioning of the SR path: horizontal LR strips, one per rank,
+with a halo exchange of raw uint8 input rows between neighbouring ranks
+(`torch.distributed`; backend "nccl" is RCCL over xGMI on MI355X, "gloo" in the
+CPU tests).  There is no reduction anywhere in this workload: each output
+pixel depends on a bounded LR neighbourhood, so the only
+exchange is 3 + 3 + S/2 rows per side and frame.
+
+Independent frames need no communication at all -- `bench.py` scales that way
+("weak"); strips serve one large frame whose latency matters.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+STAGE1_RADIUS = 3      # modes c,t reach 3 px, rotated 4 ways (eval_lut_sr.py:63-81, 548-553)
+STAGE2_RADIUS = 3
+
+
+def halo_rows(support: int) -> int:
+    """input halo per side: stage 1 + stage 2 + stage 3 radii (7 for S=2, 8 for S=4)."""
+    return STAGE1_RADIUS + STAGE2_RADIUS + support // 2
+
+
+class StripPlan:
+    """Row partition of an H x W frame over `world` ranks for a given SR geometry.
+
+    left_r: the global first-source-row table (SrGeometry.host['left_r'] or the oracle's
+    sr_axis_tables()[0]); ownership rule = the fused kernel's tile rule: an output row belongs
+    to the strip that contains left_r[i] + S/2.
+    """
+
+    def __init__(self, H: int, world: int, rank: int, support: int, left_r):
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError("bad rank/world")
+        if H < world:
+            raise ValueError("fewer rows than ranks")
+        self.H, self.world, self.rank, self.S = int(H), int(world), int(rank), int(support)
+        self.halo = halo_rows(self.S)
+        self.y0 = rank * H // world                 # owned LR rows [y0, y1)
+        self.y1 = (rank + 1) * H // world
+        self.ylo = max(self.y0 - self.halo, 0)      # rows held locally after the exchange
+        self.yhi = min(self.y1 + self.halo, H)
+        key = np.asarray(left_r, dtype=np.int64) + self.S // 2
+        self.i0 = 0 if rank == 0 else int(np.searchsorted(key, self.y0, side="left"))
+        self.i1 = len(key) if rank == world - 1 else int(np.searchsorted(key, self.y1, side="left"))
+        self.need_top = self.y0 - self.ylo          # rows to receive from rank-1
+        self.need_bot = self.yhi - self.y1          # rows to receive from rank+1
+
+    def owned(self):
+        return self.y0, self.y1
+
+    def out_rows(self):
+        return self.i0, self.i1
+
+    def check_support(self, left_r):
+        """every source row of every owned output row is held locally"""
+        lr = np.asarray(left_r)[self.i0:self.i1]
+        if len(lr) == 0:
+            return True
+        lo = lr.min() - (STAGE1_RADIUS + STAGE2_RADIUS)
+        hi = lr.max() + self.S - 1 + (STAGE1_RADIUS + STAGE2_RADIUS)
+        return max(lo, 0) >= self.ylo and min(hi, self.H - 1) < self.yhi
+
+
+def exchange_halos(own_rows, plan: StripPlan, group=None):
+    """own_rows: uint8 tensor [y1-y0, W, C] (or [N, y1-y0, W, C]) of this rank's rows.
+    Returns the tensor extended to rows [ylo, yhi) after one send/recv pair per neighbour.
+    Works with any torch.distributed backend; a world of 1 is a no-op."""
+    import torch
+    import torch.distributed as dist
+
+    batched = own_rows.dim() == 4
+    x = own_rows if batched else own_rows.unsqueeze(0)
+    N, h, W, C = x.shape
+    assert h == plan.y1 - plan.y0
+    if plan.world == 1:
+        return own_rows
+    # neighbours' strips may be shorter than the halo only if H/world < halo: not supported
+    if (plan.H // plan.world) < plan.halo:
+        raise ValueError("strips thinner than the halo (%d rows) are not supported" % plan.halo)
+    top = torch.empty((N, plan.need_top, W, C), dtype=x.dtype, device=x.device)
+    bot = torch.empty((N, plan.need_bot, W, C), dtype=x.dtype, device=x.device)
+    ops = []
+    r = plan.rank
+    if r > 0:                                   # exchange with the strip above
+        ops.append(dist.P2POp(dist.isend, x[:, :plan.halo].contiguous(), r - 1, group))
+        ops.append(dist.P2POp(dist.irecv, top, r - 1, group))
+    if r < plan.world - 1:                      # exchange with the strip below
+        ops.append(dist.P2POp(dist.isend, x[:, h - plan.halo:].contiguous(), r + 1, group))
+        ops.append(dist.P2POp(dist.irecv, bot, r + 1, group))
+    for w in dist.batch_isend_irecv(ops):       # one ncclGroupStart/End on RCCL
+        w.wait()
+    out = torch.cat([top, x, bot], dim=1)
+    return out if batched else out[0]
+
+
+def sr_strip(engine, ext_rows, plan: StripPlan, geo):
+    """This rank's output rows [i0, i1) from its extended strip (rows [ylo, yhi)).
+    `geo` = the GLOBAL SrGeometry of the frame; its row tables are rebased to the strip."""
+    from . import ops
+    local = geo.row_slice(plan.ylo, plan.yhi - plan.ylo, plan.i0, plan.i1)
+    return ops.sr_fused_u8(ext_rows, engine.luts, local, engine.kind, engine.max_sigma)
+
+
+def sr_frame_strips(engine, own_rows, H, scale, group=None, gather=False):
+    """SR of one H x W frame distributed over the process group by LR strips.
+    own_rows: this rank's rows [y0,y1) (uint8 [y1-y0,W,C] on the GPU).  Returns this rank's
+    output rows, or the whole frame on every rank if gather=True."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    W = own_rows.shape[-2]
+    geo = engine.sr_geometry((H, W), scale)
+    plan = StripPlan(H, world, rank, engine.support, geo.host["left_r"])
+    ext = exchange_halos(own_rows, plan, group)
+    out = sr_strip(engine, ext, plan, geo)
+    if not gather or world == 1:
+        return out
+    counts = [StripPlan(H, world, r, engine.support, geo.host["left_r"]).out_rows() for r in range(world)]
+    bufs = [torch.empty((b - a,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device) for a, b in counts]
+    dist.all_gather(bufs, out.contiguous(), group=group)
+    return torch.cat(bufs, dim=0)

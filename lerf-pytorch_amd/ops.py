@@ -38,14 +38,36 @@ class SrGeometry:
         lr, dr64, dr32, pr = _lib.sr_axis_tables(H, self.out_hw[0], sh, self.S)
         lc, dc64, dc32, pc = _lib.sr_axis_tables(W, self.out_hw[1], sw, self.S)
         self.pad_vec = ((0, 0), pr, pc)                                     # :129
-        self.host = dict(left_r=lr, dis_r=dr64, left_c=lc, dis_c=dc64)
+        self.host = dict(left_r=lr, dis_r=dr64, dis_r32=dr32, left_c=lc, dis_c=dc64, dis_c32=dc32)
+        self._upload()
+
+    def _upload(self):
+        torch = _torch()
+        h = self.host
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-        self.t = dict(left_r=up(lr), dis_r=up(dr32), left_c=up(lc), dis_c=up(dc32), dis_r64=up(dr64), dis_c64=up(dc64))
+        self.t = dict(left_r=up(h["left_r"]), dis_r=up(h["dis_r32"]), left_c=up(h["left_c"]), dis_c=up(h["dis_c32"]),
+                      dis_r64=up(h["dis_r"]), dis_c64=up(h["dis_c"]))
         g = _lib.SrGeo()
         g.S, g.out_h, g.out_w = self.S, self.out_hw[0], self.out_hw[1]
         for k in ("left_r", "dis_r", "left_c", "dis_c", "dis_r64", "dis_c64"):
             setattr(g, k, self.t[k].data_ptr())
         self.struct = g
+
+    def row_slice(self, lr_row0, lr_rows, out_row0, out_row1):
+        """Geometry of a horizontal strip: the LR rows [lr_row0, lr_row0 + lr_rows) held locally
+        (owned rows plus halo) produce the global output rows [out_row0, out_row1).  The row tables
+        are the global ones, rebased to the strip -- the kernels never see the strip as a frame of
+        its own, so non-integer scales partition exactly like integer ones."""
+        g = object.__new__(SrGeometry)
+        g.in_hw = (int(lr_rows), self.in_hw[1])
+        g.out_hw = (int(out_row1 - out_row0), self.out_hw[1])
+        g.scales, g.S, g.device, g.pad_vec = self.scales, self.S, self.device, self.pad_vec
+        h = self.host
+        g.host = dict(left_r=(h["left_r"][out_row0:out_row1] - lr_row0).astype(np.int32),
+                      dis_r=h["dis_r"][out_row0:out_row1], dis_r32=h["dis_r32"][out_row0:out_row1],
+                      left_c=h["left_c"], dis_c=h["dis_c"], dis_c32=h["dis_c32"])
+        g._upload()
+        return g
 
     def ref(self):
         return C.byref(self.struct)

@@ -1,0 +1,82 @@
+"""CPU tests of the multi-GPU strip partition (gloo, world_size 2): halo exchange
+delivers exactly the rows each rank needs, and stitching per-strip results
+reproduces the full frame.  The per-strip compute here is the ORACLE (the
+checker) -- the product compute path needs a GPU and is covered by
+tests/test_gpu_parity.py::test_strip_partition_single_gpu."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import lerf_pytorch_amd  # noqa: F401
+from lerf_pytorch_amd import dist as ldist
+
+
+@pytest.mark.parametrize("H,world,S,scale", [(64, 2, 2, 2.0), (90, 4, 2, 1.5), (80, 3, 4, 3.0), (1080, 8, 2, 2.0),
+                                             (2160, 8, 2, 2.0), (77, 2, 2, 2.4)])
+def test_plan_covers_rows_and_support(oracle, H, world, S, scale):
+    left, _, _, _ = oracle.sr_axis_tables(H, oracle.out_size(H, scale), scale, S)
+    outs = []
+    lr_rows = []
+    for r in range(world):
+        p = ldist.StripPlan(H, world, r, S, left)
+        assert p.halo == 3 + 3 + S // 2
+        assert p.check_support(left)
+        outs.append(p.out_rows())
+        lr_rows.append(p.owned())
+    assert lr_rows[0][0] == 0 and lr_rows[-1][1] == H
+    assert all(lr_rows[i][1] == lr_rows[i + 1][0] for i in range(world - 1))
+    assert outs[0][0] == 0 and outs[-1][1] == len(left)
+    assert all(outs[i][1] == outs[i + 1][0] for i in range(world - 1))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, scale, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import lerf_oracle as O
+    from conftest import ASSETS
+    rng = np.random.default_rng(42)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)        # same frame on every rank
+    left, _, _, _ = O.sr_axis_tables(H, O.out_size(H, scale), scale, 2)
+    plan = ldist.StripPlan(H, world, rank, 2, left)
+    own = torch.from_numpy(img[plan.y0:plan.y1].copy())
+    ext = ldist.exchange_halos(own, plan)
+    ok_halo = np.array_equal(ext.numpy(), img[plan.ylo:plan.yhi])
+    # batched exchange
+    ext2 = ldist.exchange_halos(torch.stack([own, own]), plan)
+    ok_halo = ok_halo and np.array_equal(ext2[1].numpy(), img[plan.ylo:plan.yhi])
+    # per-strip compute with the checker: the strip as its own frame (valid for integer scale), cropped
+    luts = O.load_luts(os.path.join(ASSETS, "lerf-g"))
+    o8 = O.sr_pipeline(ext.numpy(), luts, scale, scale)
+    s = int(scale)
+    mine = o8[plan.i0 - plan.ylo * s:plan.i1 - plan.ylo * s]     # global output rows [i0, i1)
+    np.save(os.path.join(tmp, "out_%d.npy" % rank), mine)
+    np.save(os.path.join(tmp, "ok_%d.npy" % rank), np.array([ok_halo, plan.check_support(left)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_halo_exchange_and_stitch(tmp_path, oracle, luts_g):
+    H, W, scale, world = 40, 24, 2.0, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, H, W, scale, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(42)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    full = oracle.sr_pipeline(img, luts_g, scale, scale)
+    parts = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)]
+    for r in range(world):
+        assert np.load(tmp_path / ("ok_%d.npy" % r)).all()
+    assert np.array_equal(np.concatenate(parts, axis=0), full)

@@ -314,3 +314,38 @@ def test_error_behaviour(torch, eng_g):
         ops.SrGeometry((8, 8), [0.5, 0.5], None, 2)
     with pytest.raises(ValueError):
         ops.lut_stages(torch.zeros((8, 8, 3), dtype=torch.float32, device="cuda"), eng_g.luts)
+
+
+@pytest.mark.parametrize("H,W,scale,world", [(200, 96, 2, 4), (150, 64, 1.5, 3), (128, 70, 3, 2), (97, 64, 2.4, 2)])
+def test_strip_partition_single_gpu(torch, eng_g, H, W, scale, world):
+    """multi-GPU strip partition, ranks emulated one after the other on one GPU: every rank computes
+    its output rows from its LR rows + 7-row halo with the global geometry rebased to the strip;
+    the stitched result must equal the full-frame result bit for bit (any scale, not just integer)."""
+    from lerf_pytorch_amd import dist as ldist
+    rng = np.random.default_rng(H + W)
+    x = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda()
+    full = eng_g.sr(x, scale)
+    geo = eng_g.sr_geometry((H, W), scale)
+    parts = []
+    for r in range(world):
+        plan = ldist.StripPlan(H, world, r, eng_g.support, geo.host["left_r"])
+        assert plan.check_support(geo.host["left_r"])
+        parts.append(ldist.sr_strip(eng_g, x[plan.ylo:plan.yhi].contiguous(), plan, geo))
+    assert torch.equal(torch.cat(parts, dim=0), full)
+
+
+def test_torch_custom_ops(torch, eng_g):
+    from lerf_pytorch_amd import torch_ops
+    h = torch_ops.register_luts(eng_g.luts)
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.integers(0, 256, (48, 40, 3), dtype=np.uint8)).cuda()
+    out = torch.ops.lerf.sr_fused(x, h, 2.0, 2.0, 2, 10.0)
+    assert torch.equal(out, eng_g.sr(x, 2))
+    feat, hq = torch.ops.lerf.lut_stages(x, h)
+    f2, h2 = eng_g.stages(x)
+    assert torch.equal(feat, f2) and torch.equal(hq, h2)
+    fe = feat.permute(2, 0, 1).float().unsqueeze(0)
+    hy = (hq.float() / 255).permute(3, 2, 0, 1).unsqueeze(1)
+    o = torch.ops.lerf.resize_gauss(fe, hy[0], hy[1], hy[2], 2.0, 2.0, 2, 10.0)
+    assert o.shape == (1, 3, 96, 80)
+    assert (o[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).int() - out.int()).abs().max() <= 1
