@@ -258,6 +258,8 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
     f.img = img; f.in_sn = in_sn; f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts;
     f.S = geo->S; f.oH = geo->out_h; f.oW = geo->out_w;
     f.left_r = geo->left_r; f.dis_r = geo->dis_r; f.left_c = geo->left_c; f.dis_c = geo->dis_c;
+    f.dis_r64 = (geo->dis_r64 && geo->dis_c64) ? geo->dis_r64 : nullptr;      // both or neither: tie guard
+    f.dis_c64 = (geo->dis_r64 && geo->dis_c64) ? geo->dis_c64 : nullptr;
     f.kind = kind; f.max_sigma = (float)max_sigma; f.out = out; f.out_sn = out_sn; f.workspace = workspace;
     if (fused_supported(f)) {
         int rc = launch_sr_fused(f, as_stream(stream));

@@ -82,6 +82,7 @@ struct Params {
     int H, W, oH, oW, tiles_y, tiles_x;
     const uint8_t* pack;             // fused LUT pack (see lerf_fused_lutpack_*)
     const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
+    const double* dis_r64; const double* dis_c64;      // tie guard (may be NULL: guard off)
     float max_sigma;
     int s2off[6][6];                 // stage-2 LUT l: feat-tile byte offsets of pixels b,c,d for rotations par, par+2
     unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
@@ -663,6 +664,7 @@ sr_fused_kernel(Params P) {
 #pragma unroll
             for (int b = 0; b < S; ++b) dxr[b] = g_dr[il * S + b];
             uint32_t packed = 0;
+            unsigned tiemask = 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int xc = min(max(b0 + u, 0), ncolc - 1);    // clamped; invalid bytes are not stored
@@ -688,7 +690,33 @@ sr_fused_kernel(Params P) {
                         }
                     }
                 }
-                packed |= (uint32_t)s3::to_u8(s3::finish<KIND == LERF_KIND_GAUSS, S * S, true, true>(e, v)) << (8 * u);
+                const float xf = s3::finish<KIND == LERF_KIND_GAUSS, S * S, true, true>(e, v);
+                bool tie;
+                packed |= s3::to_u8_tie(xf, &tie) << (8 * u);
+                if (tie) tiemask |= 1u << u;
+            }
+            if (tiemask != 0 && P.dis_r64 != nullptr) {
+                // rare: re-evaluate in float64 exactly as the reference does (lerf_stage3.h, tie guard)
+#pragma unroll 1
+                for (int u = 0; u < 4; ++u) {
+                    if (!((tiemask >> u) & 1u)) continue;
+                    const int xc = min(max(b0 + u, 0), ncolc - 1);
+                    const int jl = xc / CH;
+                    const int c = xc - jl * CH;
+                    const int lc = g_lc[jl];
+                    uint32_t dd[S * S];
+                    double dx64[S], dy64[S];
+#pragma unroll
+                    for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il) * S + b];
+#pragma unroll
+                    for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
+#pragma unroll
+                    for (int a = 0; a < S; ++a)
+#pragma unroll
+                        for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                    const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
+                    packed = (packed & ~(0xFFu << (8 * u))) | (r8 << (8 * u));
+                }
             }
             if (b0 >= 0 && b0 + 3 < ncolc) {
                 *reinterpret_cast<uint32_t*>(seg + b0) = packed;
@@ -732,6 +760,7 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     P.tiles_x = (a.W + fused::TW - 1) / fused::TW;
     P.pack = (const uint8_t*)a.luts->fused_pack;
     P.left_r = a.left_r; P.dis_r = a.dis_r; P.left_c = a.left_c; P.dis_c = a.dis_c;
+    P.dis_r64 = a.dis_r64; P.dis_c64 = a.dis_c64;
     P.max_sigma = a.max_sigma;
     P.stamps = (unsigned long long*)a.workspace;
     for (int l = 0; l < 6; ++l) {

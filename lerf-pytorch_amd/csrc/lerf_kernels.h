@@ -56,6 +56,7 @@ struct FusedArgs {
     const lerf_luts_t* luts;
     int S, oH, oW;
     const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
+    const double* dis_r64; const double* dis_c64;
     int kind; float max_sigma;
     uint8_t* out; int64_t out_sn;
     void* workspace;

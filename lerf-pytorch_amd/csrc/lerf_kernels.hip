@@ -215,6 +215,7 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
               int H, int W, int C, int S_rt, int oH, int oW,
               const int* __restrict__ left_r, const A* __restrict__ dis_r,
               const int* __restrict__ left_c, const A* __restrict__ dis_c,
+              const double* __restrict__ dis_r64, const double* __restrict__ dis_c64,
               A max_sigma, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
     const int S = ST > 0 ? ST : S_rt;
     constexpr int MAXS = ST > 0 ? ST : LERF_MAX_SUPPORT;
@@ -229,6 +230,7 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
     if (ST > 0 && sizeof(A) == 4) {
         // float32 production path: same arithmetic as the tile-fused kernel (lerf_stage3.h)
         float e[MAXS * MAXS], v[MAXS * MAXS];
+        uint32_t dd[MAXS * MAXS];      // (k0,k1,k2,val) per tap for the tie guard (uint8 in / uint8 out only)
 #pragma unroll
         for (int a = 0; a < MAXS; ++a) {
 #pragma unroll
@@ -237,6 +239,12 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
                 bool inside = (rr == rcl) && (cc == ccl);
                 v[a * MAXS + b] = inside ? Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : 0.0f;   // zero pad (:208)
+                if (sizeof(TH) == 1 && sizeof(TO) == 1) {
+                    const int64_t hh = rcl * hy + ccl * hx + c * hc;
+                    dd[a * MAXS + b] = (uint32_t)h0[hh] | ((KIND == LERF_KIND_GAUSS ? (uint32_t)h1[hh] : 0u) << 8) |
+                                       ((KIND == LERF_KIND_GAUSS ? (uint32_t)h2[hh] : 0u) << 16) |
+                                       ((uint32_t)v[a * MAXS + b] << 24);
+                }
                 int64_t ho = rcl * hy + ccl * hx + c * hc;                                                    // edge pad (:172-174)
                 float dx = (float)dis_r[i * S + b], dy = (float)dis_c[j * S + a];
                 // uint8 in / uint8 out: the production arithmetic of the fused kernel (bit-identical results);
@@ -258,9 +266,19 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 }
             }
         }
-        Storer<TO>::put(out + i * oy + j * ox + c * oc,
-                        s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1,
-                                   sizeof(TH) == 1 && sizeof(TO) == 1>(e, v));
+        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1,
+                                    sizeof(TH) == 1 && sizeof(TO) == 1>(e, v);
+        if (sizeof(TH) == 1 && sizeof(TO) == 1 && dis_r64 != nullptr && s3::near_tie(xf)) {
+            double dx64[MAXS], dy64[MAXS];
+#pragma unroll
+            for (int b = 0; b < MAXS; ++b) dx64[b] = dis_r64[i * S + b];
+#pragma unroll
+            for (int a = 0; a < MAXS; ++a) dy64[a] = dis_c64[j * S + a];
+            Storer<TO>::put(out + i * oy + j * ox + c * oc,
+                            (float)s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, MAXS>(dd, dx64, dy64, (float)max_sigma)));
+            return;
+        }
+        Storer<TO>::put(out + i * oy + j * ox + c * oc, xf);
         return;
     }
     if (ST > 0) {
@@ -336,6 +354,7 @@ static int resize_dispatch_S(const ResizeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((resize_kernel<TI, TH, TO, A, KIND, ST>), grid, block, 0, st, (const TI*)a.feat,     \
                        a.fy, a.fx, a.fc, (const TH*)a.h[0], (const TH*)a.h[1], (const TH*)a.h[2], a.hy,     \
                        a.hx, a.hc, a.H, a.W, a.C, a.S, a.oH, a.oW, a.left_r, dr, a.left_c, dc,              \
+                       (a.dis_r64 && a.dis_c64) ? a.dis_r64 : nullptr, (a.dis_r64 && a.dis_c64) ? a.dis_c64 : nullptr, \
                        (A)a.max_sigma, (TO*)a.out, a.oy, a.ox, a.oc)
     if (a.S == 2) LERF_RS(2);
     else if (a.S == 4) LERF_RS(4);

@@ -24,8 +24,11 @@ NAMES = ["in+lut0", "s1:s", "copy", "s1:c", "copy", "s1:t", "bin+slots", "s2 cop
 def main():
     eng = L.LerfEngine.shipped("lerf-g")
     geo = eng.sr_geometry((bench.H, bench.W), 2)
-    for kind in ("noise", "natural"):
-        x = torch.from_numpy(bench.synth_frames(kind, 1, 7)).cuda()
+    for kind in ("noise", "natural", "constant"):
+        if kind == "constant":
+            x = torch.full((1, bench.H, bench.W, 3), 128, dtype=torch.uint8, device="cuda")
+        else:
+            x = torch.from_numpy(bench.synth_frames(kind, 1, 7)).cuda()
         tiles = ((bench.H + 63) // 64) * ((bench.W + 63) // 64)
         ws = torch.zeros(max(tiles * 16 * 8, 4 * bench.H * bench.W * 3), dtype=torch.uint8, device="cuda")
         for _ in range(2):
