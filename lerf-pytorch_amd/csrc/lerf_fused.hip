@@ -223,6 +223,10 @@ template <int DPc, int SP>
 __device__ __forceinline__ int center_addr(int p, int y0g, int x0g, int sy0g, int sx0g, int H, int W, bool* inside) {
     int ry = p / DPc;
     int r3 = p - ry * DPc;
+    if (H < 0) {                      // interior tile (caller passes H = -1): nothing to clamp
+        if (inside) *inside = true;
+        return (ry + (y0g - sy0g)) * SP + r3 + (x0g - sx0g) * CH;
+    }
     int rx = r3 / CH;
     int c = r3 - rx * CH;
     int gy = y0g + ry, gx = x0g + rx;
@@ -306,6 +310,10 @@ sr_fused_kernel(Params P) {
 
     uint8_t* Bt = smem + D::OFF_B;
     int* ctl = reinterpret_cast<int*>(smem + D::OFF_CTL);
+    // interior tile: the whole input region lies inside the frame, so no coordinate is ever clamped and the
+    // centre addresses reduce to a multiply-add (center_addr's H < 0 path); ~80 % of the tiles of a 1080p frame
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= P.H && ix0 + D::IX <= P.W;
+    const int Hc = interior ? -1 : P.H, Wc = P.W;
 
     LERF_STAMP(0);
 #ifdef LERF_STAMPS
@@ -333,19 +341,19 @@ sr_fused_kernel(Params P) {
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
         __syncthreads();
         LERF_STAMP(1);
-        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
+        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         LERF_STAMP(2);
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 1 * LUT_PAD, tid);
         __syncthreads();
         LERF_STAMP(3);
-        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
+        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         LERF_STAMP(4);
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 2 * LUT_PAD, tid);
         __syncthreads();
         LERF_STAMP(5);
-        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, H, W, div1, 0, tid);
+        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         LERF_STAMP(6);
     }
@@ -362,7 +370,7 @@ sr_fused_kernel(Params P) {
 #define LERF_L2(IDX, MODE, PAR, PH)                                                                        \
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, s2 + (IDX) * LUT_PAD, tid);                          \
         __syncthreads();                                                                                   \
-        byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, H, W, div2, 127, tid); \
+        byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, Hc, Wc, div2, 127, tid); \
         __syncthreads();
         LERF_L2(0, 's', 0, 0)
         LERF_L2(1, 's', 1, 1)
@@ -379,7 +387,7 @@ sr_fused_kernel(Params P) {
             tmp[k] = 0;
             if (p < D::NH) {
                 bool inside;
-                int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, &inside);
+                int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, &inside);
                 tmp[k] = (uint32_t)hq8[p] | ((inside ? (uint32_t)Bt[a] : 0u) << 24);
             }
         }
@@ -406,7 +414,7 @@ sr_fused_kernel(Params P) {
             for (int k = 0; k < KH; ++k) {
                 const int p = wave * PW + k * 64 + lane;
                 int q = 4;
-                if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, H, W, nullptr)] >> 6;
+                if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr)] >> 6;
                 qpack |= (uint32_t)(q & 3) << (2 * k);
                 c0 += __popcll(__ballot(q == 0));
                 c1 += __popcll(__ballot(q == 1));
@@ -471,7 +479,7 @@ sr_fused_kernel(Params P) {
         for (int k = 0; k < MAXR; ++k) {
             const uint32_t p = lst[k * NT + tid];
             uint32_t a = 0xFFFFu;
-            if (p != 0xFFFFu) a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, H, W, nullptr);
+            if (p != 0xFFFFu) a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr);
             if (k & 1) slot2[k >> 1] |= a << 16; else slot2[k >> 1] = a;
             accA[k] = 0;
             if (!(k & 1)) accB2[k >> 1] = 0;
@@ -603,7 +611,7 @@ sr_fused_kernel(Params P) {
                 uint32_t h1 = (uint32_t)rne_div_clip255(n1, div2);
                 uint32_t h2 = (uint32_t)rne_div_clip255(n2, div2);
                 bool inside;
-                int a = center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, H, W, &inside);
+                int a = center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, &inside);
                 uint32_t fv = inside ? (uint32_t)Bt[a] : 0u;      // zero-padded image outside the frame (:208)
                 Dt[p] = h0 | (h1 << 8) | (h2 << 16) | (fv << 24);
             }

@@ -22,6 +22,22 @@ run("natural-like", bench.synth_frames("natural", B, 1))
 run("constant 128", np.full((B, 1080, 1920, 3), 128, np.uint8))
 g = np.tile((np.arange(1920) * 255 // 1919).astype(np.uint8)[None, None, :, None], (B, 1080, 1, 3))
 run("horizontal ramp", np.ascontiguousarray(g))
+from PIL import Image
+def photo():
+    names = ["baby", "bird", "butterfly", "head", "woman"]
+    ims = [np.array(Image.open(os.path.join(ROOT, "tests/data/Set5/HR", n + ".png"))) for n in names]
+    canvas = np.zeros((1080, 1920, 3), np.uint8)
+    y = 0; k = 0
+    while y < 1080:
+        x = 0; rowh = 0
+        while x < 1920:
+            im = ims[k % 5]; k += 1
+            h = min(im.shape[0], 1080 - y); w = min(im.shape[1], 1920 - x)
+            canvas[y:y + h, x:x + w] = im[:h, :w]; x += w; rowh = max(rowh, h)
+        y += rowh
+    return canvas
+ph = photo()
+run("Set5 HR mosaic (real photos)", np.ascontiguousarray(np.stack([np.roll(ph, 37 * i, axis=1) for i in range(B)])))
 rng = np.random.default_rng(0)
 run("noise in [96,160)", rng.integers(96, 160, (B, 1080, 1920, 3), dtype=np.uint8))
 run("noise, multiples of 16", (rng.integers(0, 16, (B, 1080, 1920, 3)) * 16).astype(np.uint8))
