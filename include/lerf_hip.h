@@ -176,6 +176,19 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
               int H, int W, int C, const lerf_warp_geo_t* geo,
               int kind, double max_sigma, const lerf_mplane_t* out, void* stream);
 
+/* Stages 1+2 by the tile-fused kernel (modes "sct"/"sct", C = 3, luts->fused_pack set), `n` frames:
+ * packed[(y*W + x)*3 + c] = hq0 | hq1<<8 | hq2<<16 | feat<<24  (hq1, hq2 = 0 for LeRF-L).
+ * Same values as lerf_lut_stages_u8, ~4x faster; feeds lerf_warp_packed / lerf_unpack_stages. */
+int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
+                          const lerf_luts_t* luts, uint32_t* packed, int64_t packed_sn, void* stream);
+
+/* packed dwords -> feat uint8 [n_pxch] and hq uint8 [n_pxch][oC] (either may be NULL) */
+int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, void* stream);
+
+/* lerf_warp (gauss / linear) reading the packed stage outputs of one HWC frame; out: uint8 or float32 */
+int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_warp_geo_t* geo,
+                     int kind, double max_sigma, const lerf_mplane_t* out, void* stream);
+
 /* Whole SR path of eltr._worker (resample/eval_lut_sr.py:541-665) in one
  * launch per frame batch: uint8 HWC in -> uint8 HWC out, feat and hyper never
  * leave the chip.  `n` frames with batch strides in_sn / out_sn (elements).

@@ -26,6 +26,7 @@ EXPORTS = [
     "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
     "lerf_lut_stages_u8",
     "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_u8",
+    "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed",
 ]
 
 
@@ -97,6 +98,11 @@ def lib():
                               C.c_int, C.c_double, C.POINTER(Plane), C.c_void_p]
     L.lerf_warp.argtypes = [C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo),
                             C.c_int, C.c_double, C.POINTER(Plane), C.c_void_p]
+    L.lerf_stages_packed_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
+                                        C.c_void_p, C.c_int64, C.c_void_p]
+    L.lerf_unpack_stages.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lerf_warp_packed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo), C.c_int, C.c_double,
+                                   C.POINTER(Plane), C.c_void_p]
     L.lerf_sr_fused_workspace_bytes.restype = C.c_size_t
     L.lerf_sr_fused_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.lerf_sr_fused_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts),

@@ -241,6 +241,37 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int 
     return rc != LERF_OK ? rc : check_launch();
 }
 
+int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts,
+                          uint32_t* packed, int64_t packed_sn, void* stream) {
+    if (!img || !luts || !packed || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    FusedArgs f{};
+    f.img = img; f.in_sn = in_sn; f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts;
+    f.S = 2; f.oH = H; f.oW = W; f.kind = luts->oC == 3 ? LERF_KIND_GAUSS : LERF_KIND_LINEAR;
+    f.emit = packed; f.emit_sn = packed_sn;
+    if (!fused_stages_supported(f)) return LERF_EUNSUPPORTED;
+    int rc = launch_stages_fused(f, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
+int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, void* stream) {
+    if (!packed || n_pxch < 1 || (!feat && !hq)) return LERF_EINVAL;
+    int rc = launch_unpack_stages(packed, n_pxch, oC, feat, hq, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
+int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_warp_geo_t* geo, int kind, double max_sigma,
+                     const lerf_mplane_t* out, void* stream) {
+    if (!packed || !geo || !out || !out->ptr || H < 1 || W < 1 || C < 1 || geo->out_h < 1 || geo->out_w < 1)
+        return LERF_EINVAL;
+    WarpGeo g;
+    g.S = geo->S; g.oH = geo->out_h; g.oW = geo->out_w;
+    memcpy(g.minv, geo->minv, sizeof(g.minv));
+    g.pad_r_lo = geo->pad_r_lo; g.pad_r_hi = geo->pad_r_hi; g.pad_c_lo = geo->pad_c_lo; g.pad_c_hi = geo->pad_c_hi;
+    int rc = launch_warp_packed(packed, H, W, C, g, kind, (float)max_sigma, out->ptr, out->dtype, out->sy, out->sx,
+                                out->sc, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {
     // room for the unfused fallback (feat + 3 hyper planes per frame); the tile-fused kernel needs none
     if (H < 1 || W < 1 || C < 1 || n < 1) return 0;

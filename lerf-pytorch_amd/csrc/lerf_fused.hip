@@ -85,6 +85,7 @@ struct Params {
     const double* dis_r64; const double* dis_c64;      // tie guard (may be NULL: guard off)
     float max_sigma;
     int s2off[6][6];                 // stage-2 LUT l: feat-tile byte offsets of pixels b,c,d for rotations par, par+2
+    uint32_t* emit; int64_t emit_sn;   // EMIT kernels: packed stage outputs, frame stride in dwords
     unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
 };
 
@@ -284,7 +285,9 @@ __device__ __forceinline__ int lower_bound_i(const int* __restrict__ a, int n, i
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
-template <int S, int KIND>
+// EMIT = false: the whole SR path.  EMIT = true: stages 1+2 only; the tile's own 64x64 block of
+// (hq0,hq1,hq2,feat) dwords goes to P.emit ([H][W][3] uint32) for the warp kernels / the stage API.
+template <int S, int KIND, bool EMIT>
 __global__ void __launch_bounds__(NT)
 sr_fused_kernel(Params P) {
     using D = Dims<S>;
@@ -618,6 +621,18 @@ sr_fused_kernel(Params P) {
         }
     }
 
+    if (EMIT) {
+        __syncthreads();
+        uint32_t* eo = P.emit + frame * P.emit_sn;
+        const int rows = min(TH, H - ty0), cols3 = min(TW, W - tx0) * CH;
+        for (int il = wave; il < rows; il += NW) {
+            const uint32_t* srow = Dt + (il + D::R3) * D::HP + D::R3 * CH;
+            uint32_t* drow = eo + ((int64_t)(ty0 + il) * W + tx0) * CH;
+            for (int x = lane; x < cols3; x += 64) drow[x] = srow[x];
+        }
+        return;
+    }
+
     // ---- stage 3 geometry of the owned output block into LDS
     int* g_lr = reinterpret_cast<int*>(smem + D::OFF_GEO);
     float* g_dr = reinterpret_cast<float*>(g_lr + D::GEO_ROWS);
@@ -758,7 +773,7 @@ bool fused_supported(const FusedArgs& a) {
     return true;
 }
 
-template <int S, int KIND>
+template <int S, int KIND, bool EMIT = false>
 static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     using D = fused::Dims<S>;
     fused::Params P;
@@ -770,7 +785,7 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     P.left_r = a.left_r; P.dis_r = a.dis_r; P.left_c = a.left_c; P.dis_c = a.dis_c;
     P.dis_r64 = a.dis_r64; P.dis_c64 = a.dis_c64;
     P.max_sigma = a.max_sigma;
-    P.stamps = (unsigned long long*)a.workspace;
+    P.stamps = EMIT ? nullptr : (unsigned long long*)a.workspace;
     for (int l = 0; l < 6; ++l) {
         const char mc = "sct"[l >> 1];
         fused::Off3 o0 = fused::tile_offsets<D::FP>(mc, l & 1), o1 = fused::tile_offsets<D::FP>(mc, (l & 1) + 2);
@@ -779,7 +794,8 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
             P.s2off[l][3 + i] = o1.o[i];
         }
     }
-    auto kern = fused::sr_fused_kernel<S, KIND>;
+    P.emit = (uint32_t*)a.emit; P.emit_sn = a.emit_sn;
+    auto kern = fused::sr_fused_kernel<S, KIND, EMIT>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             D::LDS_BYTES) != hipSuccess)
         return LERF_ELAUNCH;
@@ -787,6 +803,20 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     if (blocks > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(fused::NT), D::LDS_BYTES, st, P);
     return LERF_OK;
+}
+
+// stages 1+2 only: packed (hq0,hq1,hq2,feat) dwords per pixel-channel
+bool fused_stages_supported(const FusedArgs& a) {
+    const lerf_luts_t* L = a.luts;
+    if (!L || !L->fused_pack || a.C != 3) return false;
+    if (L->n_modes1 != 3 || L->n_modes2 != 3) return false;
+    return memcmp(L->modes1, "sct", 3) == 0 && memcmp(L->modes2, "sct", 3) == 0;
+}
+
+int launch_stages_fused(const FusedArgs& a, hipStream_t st) {
+    if (a.luts->oC == 3) return launch_fused_t<2, LERF_KIND_GAUSS, true>(a, st);
+    if (a.luts->oC == 1) return launch_fused_t<2, LERF_KIND_LINEAR, true>(a, st);
+    return LERF_EUNSUPPORTED;
 }
 
 int launch_sr_fused(const FusedArgs& a, hipStream_t st) {

@@ -473,4 +473,99 @@ int launch_warp(const WarpArgs& a, hipStream_t st) {
     return LERF_EUNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------
+// packed stage outputs (tile-fused stages kernel): dword = hq0 | hq1<<8 | hq2<<16 | feat<<24
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+unpack_stages_kernel(const uint32_t* __restrict__ packed, int64_t n, int oC, uint8_t* __restrict__ feat,
+                     uint8_t* __restrict__ hq) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = packed[i];
+    if (feat) feat[i] = (uint8_t)(d >> 24);
+    if (hq)
+        for (int k = 0; k < oC; ++k) hq[i * oC + k] = (uint8_t)(d >> (8 * k));
+}
+
+int launch_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, hipStream_t st) {
+    if (oC != 1 && oC != 3) return LERF_EUNSUPPORTED;
+    hipLaunchKernelGGL(unpack_stages_kernel, dim3((unsigned)((n_pxch + 255) / 256)), dim3(256), 0, st, packed, n_pxch, oC,
+                       feat, hq);
+    return LERF_OK;
+}
+
+// A7/A8 on packed stage outputs: one dword load per tap (the warp harness path,
+// resample/eval_lut_warp.py:100-222 with stages 1+2 from the fused kernel)
+template <typename TO, int KIND>
+__global__ void __launch_bounds__(256)
+warp_packed_kernel(const uint32_t* __restrict__ packed, int H, int W, int C, WarpGeo g, float max_sigma,
+                   TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+    int xc = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (xc >= g.oW * C) return;
+    int j = xc / C;
+    int c = xc - j * C;
+    const int S = g.S;
+    double gr, gc;
+    project_point(g.minv, i, j, H, W, &gr, &gc);
+    int lr = left_boundary(gr, S) + g.pad_r_lo;
+    int lc = left_boundary(gc, S) + g.pad_c_lo;
+    gr += (double)g.pad_r_lo;
+    gc += (double)g.pad_c_lo;
+    float emin = 0, num = 0, den = 0;
+    for (int pass = (KIND == LERF_KIND_GAUSS ? 0 : 1); pass < 2; ++pass) {
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b < S; ++b) {
+                int pr = clampi(lr + b, 0, H - 1), pc = clampi(lc + a, 0, W - 1);       // :396-398
+                double dxd = gr - (double)pr, dyd = gc - (double)pc;
+                float dx = (float)dxd, dy = (float)dyd;
+                int sr = pr - g.pad_r_lo, sc_ = pc - g.pad_c_lo;
+                int rcl = clampi(sr, 0, H - 1), ccl = clampi(sc_, 0, W - 1);
+                bool inside = (sr == rcl) && (sc_ == ccl);
+                const uint32_t d = packed[((int64_t)rcl * W + ccl) * C + c];
+                float w;
+                if (KIND == LERF_KIND_GAUSS) {
+                    float e = s3::gauss_form(s3::u8_over_255((float)(d & 0xFFu)), s3::u8_over_255((float)((d >> 8) & 0xFFu)),
+                                             s3::u8_over_255((float)((d >> 16) & 0xFFu)), max_sigma, dx, dy);
+                    if (pass == 0) {
+                        emin = (a == 0 && b == 0) ? e : fminf(e, emin);
+                        continue;
+                    }
+                    w = s3::gauss_weight(e, emin);
+                } else {
+                    float alpha = s3::lin_alpha_of(s3::u8_over_255((float)(d & 0xFFu)), max_sigma);
+                    w = s3::lin_factor(alpha, dx, dist_class(dxd)) * s3::lin_factor(alpha, dy, dist_class(dyd));
+                }
+                float val = inside ? (float)(d >> 24) : 0.0f;
+                num += w * val;
+                den += w;
+            }
+    }
+    float res = num / den;
+    if (KIND == LERF_KIND_GAUSS && emin * 0.5f > 745.2f) res = __builtin_nanf("");
+    Storer<TO>::put(out + i * oy + j * ox + c * oc, res);
+}
+
+int launch_warp_packed(const uint32_t* packed, int H, int W, int C, const WarpGeo& geo, int kind, float max_sigma,
+                       void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, hipStream_t st) {
+    if (geo.S < 1 || geo.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
+    dim3 block(256), grid((geo.oW * C + 255) / 256, geo.oH);
+#define LERF_WPK(TO, KIND)                                                                                         \
+    hipLaunchKernelGGL((warp_packed_kernel<TO, KIND>), grid, block, 0, st, packed, H, W, C, geo, max_sigma, (TO*)out, \
+                       oy, ox, oc)
+    if (kind == LERF_KIND_GAUSS) {
+        if (out_dtype == LERF_U8) LERF_WPK(uint8_t, LERF_KIND_GAUSS);
+        else if (out_dtype == LERF_F32) LERF_WPK(float, LERF_KIND_GAUSS);
+        else return LERF_EUNSUPPORTED;
+    } else if (kind == LERF_KIND_LINEAR) {
+        if (out_dtype == LERF_U8) LERF_WPK(uint8_t, LERF_KIND_LINEAR);
+        else if (out_dtype == LERF_F32) LERF_WPK(float, LERF_KIND_LINEAR);
+        else return LERF_EUNSUPPORTED;
+    } else {
+        return LERF_EUNSUPPORTED;
+    }
+#undef LERF_WPK
+    return LERF_OK;
+}
+
 }  // namespace lerf

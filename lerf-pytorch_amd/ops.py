@@ -151,6 +151,43 @@ def lut_stages(img_u8_hwc, luts):
     return feat, hq
 
 
+def stages_packed(img_u8, luts):
+    """uint8 [H,W,3] / [N,H,W,3] -> int32 [.., H,W,3] packed (hq0 | hq1<<8 | hq2<<16 | feat<<24) by the tile-fused
+    stages kernel.  Raises LerfError(unsupported) for configurations it does not cover."""
+    torch = _torch()
+    if img_u8.dtype != torch.uint8:
+        raise ValueError("img must be uint8")
+    squeeze = img_u8.dim() == 3
+    img = (img_u8.unsqueeze(0) if squeeze else img_u8).contiguous()
+    N, H, W, Cn = img.shape
+    packed = torch.empty((N, H, W, Cn), dtype=torch.int32, device=img.device)
+    _lib.check(_lib.lib().lerf_stages_packed_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(),
+                                                packed.data_ptr(), packed.stride(0), _lib.current_stream()),
+               "lerf_stages_packed_u8")
+    return packed[0] if squeeze else packed
+
+
+def unpack_stages(packed, oC):
+    torch = _torch()
+    feat = torch.empty(tuple(packed.shape), dtype=torch.uint8, device=packed.device)
+    hq = torch.empty(tuple(packed.shape) + (oC,), dtype=torch.uint8, device=packed.device)
+    p = packed.contiguous()
+    _lib.check(_lib.lib().lerf_unpack_stages(p.data_ptr(), p.numel(), int(oC), feat.data_ptr(), hq.data_ptr(),
+                                             _lib.current_stream()), "lerf_unpack_stages")
+    return feat, hq
+
+
+def warp_packed(packed_hwc, geo: "WarpGeometry", kind="gauss", max_sigma=10.0, out="u8"):
+    torch = _torch()
+    p = packed_hwc.contiguous()
+    H, W, Cn = p.shape
+    o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=p.device)
+    po = _planes_hwc(o)
+    _lib.check(_lib.lib().lerf_warp_packed(p.data_ptr(), H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
+                                           C.byref(po), _lib.current_stream()), "lerf_warp_packed")
+    return o
+
+
 # --------------------------------------------------------------------------- A5/A6/A8
 def _hyper_planes(hyper, layout, nh):
     arr = (_lib.Plane * 3)()

@@ -52,9 +52,15 @@ class LerfEngine:
         return self._sr_geo[key]
 
     # -- stages 1+2
+    def _fused_stages_ok(self, x):
+        return x.shape[-1] == 3 and self.luts.struct.fused_pack is not None
+
     def stages(self, img):
         x, as_np = self._dev(img)
-        feat, hq = ops.lut_stages(x, self.luts)
+        if self._fused_stages_ok(x):
+            feat, hq = ops.unpack_stages(ops.stages_packed(x, self.luts), self.luts.oC)
+        else:
+            feat, hq = ops.lut_stages(x, self.luts)
         return (feat.cpu().numpy(), hq.cpu().numpy()) if as_np else (feat, hq)
 
     # -- SR
@@ -90,8 +96,11 @@ class LerfEngine:
         x, as_np = self._dev(img)
         H, W, Cn = x.shape
         geo = ops.WarpGeometry((H, W), matrix, out_hw, self.support)
-        feat, hq = ops.lut_stages(x, self.luts)
-        o = ops.warp_hwc_u8(feat, hq, geo, self.kind, self.max_sigma, out=out)
+        if self._fused_stages_ok(x) and out in ("u8", "f32"):
+            o = ops.warp_packed(ops.stages_packed(x, self.luts), geo, self.kind, self.max_sigma, out=out)
+        else:
+            feat, hq = ops.lut_stages(x, self.luts)
+            o = ops.warp_hwc_u8(feat, hq, geo, self.kind, self.max_sigma, out=out)
         mask = None
         if return_mask:
             white = torch.zeros((H, W, Cn), dtype=torch.uint8, device=x.device)

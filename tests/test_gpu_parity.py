@@ -364,3 +364,36 @@ def test_full_frame_bytes_equal_cpu_oracle(torch, eng_g, luts_g):
     d = np.abs(out.astype(int) - ref.astype(int))
     assert d.max() <= 1
     assert (d != 0).sum() == 0, "%d of %d bytes differ" % ((d != 0).sum(), d.size)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 3), (5, 7, 3), (64, 64, 3), (65, 130, 3), (200, 75, 3)])
+def test_direct_and_fused_stage_kernels_agree(torch, eng_g, eng_l, shape):
+    """lerf_lut_stages_u8 (direct kernels, global-memory LUT gathers) and lerf_stages_packed_u8 (tile-fused,
+    LDS-resident LUT pieces) are independent implementations of stages 1+2: they must agree bit for bit."""
+    from lerf_pytorch_amd import ops
+    rng = np.random.default_rng(sum(shape) + 1)
+    x = torch.from_numpy(rng.integers(0, 256, shape, dtype=np.uint8)).cuda()
+    for eng in (eng_g, eng_l):
+        f1, h1 = ops.lut_stages(x, eng.luts)
+        f2, h2 = ops.unpack_stages(ops.stages_packed(x, eng.luts), eng.luts.oC)
+        assert torch.equal(f1, f2) and torch.equal(h1, h2)
+    # batched frames
+    xb = torch.from_numpy(rng.integers(0, 256, (3,) + shape, dtype=np.uint8)).cuda()
+    pb = ops.stages_packed(xb, eng_g.luts)
+    for b in range(3):
+        assert torch.equal(pb[b], ops.stages_packed(xb[b], eng_g.luts))
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_warp_packed_equals_direct_warp(torch, eng_g, p):
+    from lerf_pytorch_amd import ops
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["warp"]
+    r = ref["lerf-g/%s/woman" % p]
+    lr = torch.from_numpy(np.array(Image.open(os.path.join(DATA, "warp", p, "woman.png")))).cuda()
+    geo = ops.WarpGeometry(lr.shape[:2], np.array(r["matrix"]), (344, 228), 2)
+    feat, hq = ops.lut_stages(lr, eng_g.luts)
+    a = ops.warp_hwc_u8(feat, hq, geo, "gauss", 10.0, out="f32")
+    b = ops.warp_packed(ops.stages_packed(lr, eng_g.luts), geo, "gauss", 10.0, out="f32")
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    ok = ~torch.isnan(a)
+    assert float((a[ok] - b[ok]).abs().max()) <= 1e-3
