@@ -195,7 +195,7 @@ def main():
         "metric": "Mpix/s LeRF-G x2 SR (2K->4K)", "value": round(value, 2), "unit": "Mpix/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strips else "weak",
-        "vs_baseline": None, "dtype": "u8 io, i32 LUT stages, f32 resampling", "data": "synthetic",
+        "vs_baseline": None, "dtype": "i32+f32 (u8 io)", "data": "synthetic",
         "config": {"workload": "LeRF-G LUT x2 SR, 1920x1080->3840x2160 RGB uint8, S=2, max_sigma=10 (BASELINE configs[1])",
                    "frames_per_step_per_gpu": B, "input": args.input, "path": "unfused-3-launch" if args.unfused else "sr_fused_u8",
                    "parallelism": ("LR strips per frame over %d GPUs, RCCL halo exchange (7 rows per side)" % n_gpus) if strips

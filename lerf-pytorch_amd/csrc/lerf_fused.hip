@@ -742,7 +742,8 @@ sr_fused_kernel(Params P) {
                 }
             }
             if (b0 >= 0 && b0 + 3 < ncolc) {
-                *reinterpret_cast<uint32_t*>(seg + b0) = packed;
+                // streaming store: the output is never re-read here, keep the LUT pack resident in L2 instead
+                __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(seg + b0));
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
