@@ -583,12 +583,12 @@ sr_fused_kernel(Params P) {
 #pragma unroll
                             for (int n = 0; n < 5; ++n) {
                                 a += __umul24(w0[n], d0[n] & 0x00FF00FFu);
-                                bb += __umul24(w0[n], (k & 1) ? ((d0[n] << 8) & 0x00FF0000u) : ((d0[n] >> 8) & 0xFFu));
+                                bb += __umul24(w0[n], (k & 1) ? ((d0[n] >> 8) & 0x00FF0000u) : (d0[n] >> 24));
                             }
 #pragma unroll
                             for (int n = 0; n < 5; ++n) {
                                 a += __umul24(w1[n], d1[n] & 0x00FF00FFu);
-                                bb += __umul24(w1[n], (k & 1) ? ((d1[n] << 8) & 0x00FF0000u) : ((d1[n] >> 8) & 0xFFu));
+                                bb += __umul24(w1[n], (k & 1) ? ((d1[n] >> 8) & 0x00FF0000u) : (d1[n] >> 24));
                             }
                             accA[k] = a;
                             accB2[k >> 1] = bb;
@@ -831,7 +831,7 @@ int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
 }
 
 // fused LUT pack: [n1 x LUT_PAD int8 stage-1 LUTs][stage-2 LUTs], stage 2 as
-//   oC == 3: 6 x LUT_PAD uint32 (biased bytes e0+128 | e1+128 << 8 | e2+128 << 16), order s_r0, s_r1, c_r0, ...
+//   oC == 3: 6 x LUT_PAD uint32 (biased bytes e0+128 | e2+128 << 16 | e1+128 << 24), order s_r0, s_r1, c_r0, ...
 //   oC == 1: 6 x LUT_PAD int8
 size_t fused_lutpack_bytes(int oC) {
     return (size_t)3 * fused::LUT_PAD + (size_t)6 * fused::LUT_PAD * (oC == 3 ? 4 : 1);
@@ -846,7 +846,9 @@ __global__ void pack_dwords_kernel(const int8_t* __restrict__ src, uint32_t* __r
     if (i >= fused::LUT_PAD) return;
     uint32_t d = 0;
     if (i < LERF_LUT_ENTRIES)
-        for (int k = 0; k < 3; ++k) d |= (uint32_t)((int)src[i * 3 + k] + 128) << (8 * k);
+        // e0 -> byte 0, e2 -> byte 2 (one mask gives the 16-bit-spaced pair), e1 -> byte 3 (one shift, no mask)
+        d = (uint32_t)((int)src[i * 3 + 0] + 128) | ((uint32_t)((int)src[i * 3 + 2] + 128) << 16) |
+            ((uint32_t)((int)src[i * 3 + 1] + 128) << 24);
     dst[i] = d;
 }
 

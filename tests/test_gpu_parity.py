@@ -397,3 +397,26 @@ def test_warp_packed_equals_direct_warp(torch, eng_g, p):
     assert torch.equal(torch.isnan(a), torch.isnan(b))
     ok = ~torch.isnan(a)
     assert float((a[ok] - b[ok]).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("H,W,scale,S", [
+    (1, 1, 2, 2), (2, 3, 2, 2), (7, 5, 3, 2), (63, 65, 2, 2), (64, 64, 1, 2), (64, 128, 4, 2), (65, 64, 2.5, 2),
+    (33, 200, (1.5, 2.0), 2), (130, 70, (1.0, 3.0), 2), (100, 90, 2, 4), (40, 300, 1.25, 4), (129, 129, 4, 4)])
+def test_fused_equals_unfused_and_oracle_shape_sweep(torch, oracle, luts_g, luts_l, eng_g, eng_l, H, W, scale, S):
+    """edge shapes: single pixels, tiles cut by the frame, scale 1 and 4, anisotropic scales, odd row pitches,
+    S = 2 and 4, both models.  fused == unfused bit for bit, and == the float64 oracle on the small ones."""
+    import lerf_pytorch_amd as L
+    rng = np.random.default_rng(H * 1000 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    sc = scale if isinstance(scale, tuple) else (scale, scale)
+    for model, luts in (("lerf-g", luts_g), ("lerf-l", luts_l)):
+        if model == "lerf-l" and S != 2:
+            continue
+        eng = (eng_g if model == "lerf-g" else eng_l) if S == 2 else L.LerfEngine(eng_g.luts, support=S)
+        a = eng.sr(img, sc, fused=True)
+        b = eng.sr(img, sc, fused=False)
+        assert a.shape == (oracle.out_size(H, sc[0]), oracle.out_size(W, sc[1]), 3)
+        assert np.array_equal(a, b)
+        if H * W <= 130 * 70:
+            ref = oracle.sr_pipeline(img, luts, sc[0], sc[1], S=S, linear=(model == "lerf-l"))
+            assert np.array_equal(a, ref)
