@@ -273,14 +273,6 @@ __device__ __forceinline__ int wave_lower_bound(const int* __restrict__ a, int n
     return lo + __popcll(__ballot(less));
 }
 
-__device__ __forceinline__ int lower_bound_i(const int* __restrict__ a, int n, int key) {
-    int lo = 0, hi = n;      // first i with a[i] >= key
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 
 // ---------------------------------------------------------------------------
 // the kernel
