@@ -165,7 +165,7 @@ def main():
     # secondary distribution (same shapes), short run, rank 0 only
     other = "natural" if args.input == "noise" else "noise"
     other_mpix = None
-    if rank == 0 and not strips:
+    if rank == 0 and world == 1:
         xo = torch.from_numpy(np.ascontiguousarray(np.tile(host[other], (B // 2 + 1, 1, 1, 1))[:B])).cuda()
         step(xo, out)
         torch.cuda.synchronize()
