@@ -45,7 +45,15 @@ enum {
 };
 
 enum { LERF_U8 = 0, LERF_F32 = 1, LERF_F64 = 2, LERF_I16 = 3 };
-enum { LERF_KIND_GAUSS = 0, LERF_KIND_LINEAR = 1, LERF_KIND_NEAREST = 2 };
+enum {
+    LERF_KIND_GAUSS = 0,     /* steering Gaussian, 3 hyper maps  (LeRF-G) */
+    LERF_KIND_LINEAR = 1,    /* amplified linear, 1 hyper map    (LeRF-L) */
+    LERF_KIND_NEAREST = 2,   /* box2d                              (resize_right/interp_methods.py:67-70, 83-85) */
+    LERF_KIND_CUBIC = 3,     /* cubic2d   (:35-43, 73-75)   -- fixed kernels: lerf_warp only, no hyper maps */
+    LERF_KIND_BILINEAR = 4,  /* linear2d  (:60-64, 78-80) */
+    LERF_KIND_LANCZOS2 = 5,  /* lanczos2d (:46-50, 88-90) */
+    LERF_KIND_LANCZOS3 = 6   /* lanczos3d (:53-57, 93-95) */
+};
 
 typedef struct {
     const void* ptr;      /* device pointer */
@@ -168,7 +176,8 @@ int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
 
 /* Stage 3, homography: SteeringGaussianWarp2dNumpy.warp (:516-577),
  * AmplifiedLinearWarp2dNumpy.warp (:597-636), NearestWarp2dNumpy (:460-467,
- * 409-449) and the Torch twins (resize_right2d_torch.py:346-487).
+ * 409-449), the fixed-kernel baselines Bicubic/Bilinear/Lanczos2/Lanczos3Warp2dNumpy
+ * (:451-494) and the Torch twins (resize_right2d_torch.py:346-487).
  * Pixels whose weights all vanish are NaN in float outputs (the reference's
  * 0/0) and 0 in uint8 outputs.  If `mask_out` (uint8 [out_h][out_w]) is
  * non-NULL and kind == NEAREST, it receives out == 255 per pixel. */

@@ -18,8 +18,9 @@ LERF_MAX_MODES = 5
 LERF_LUT_ENTRIES = 83521
 LERF_MAX_SUPPORT = 8
 LERF_U8, LERF_F32, LERF_F64, LERF_I16 = 0, 1, 2, 3
-KIND_GAUSS, KIND_LINEAR, KIND_NEAREST = 0, 1, 2
-KINDS = {"gauss": KIND_GAUSS, "linear": KIND_LINEAR, "nearest": KIND_NEAREST}
+KIND_GAUSS, KIND_LINEAR, KIND_NEAREST, KIND_CUBIC, KIND_BILINEAR, KIND_LANCZOS2, KIND_LANCZOS3 = range(7)
+KINDS = {"gauss": KIND_GAUSS, "linear": KIND_LINEAR, "nearest": KIND_NEAREST, "cubic": KIND_CUBIC,
+         "bilinear": KIND_BILINEAR, "lanczos2": KIND_LANCZOS2, "lanczos3": KIND_LANCZOS3}
 
 EXPORTS = [
     "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables",

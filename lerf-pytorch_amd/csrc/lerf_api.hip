@@ -218,7 +218,7 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int 
               int kind, double max_sigma, const lerf_mplane_t* out, void* stream) {
     if (!plane_ok(feat) || !geo || !out || !out->ptr || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
     int nh = kind == LERF_KIND_GAUSS ? 3 : (kind == LERF_KIND_LINEAR ? 1 : 0);
-    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR && kind != LERF_KIND_NEAREST) return LERF_EUNSUPPORTED;
+    if (kind < LERF_KIND_GAUSS || kind > LERF_KIND_LANCZOS3) return LERF_EUNSUPPORTED;
     if (nh > 0 && !hyper) return LERF_EINVAL;
     for (int k = 0; k < nh; ++k)
         if (!hyper[k].ptr || hyper[k].dtype != hyper[0].dtype || hyper[k].sy != hyper[0].sy ||

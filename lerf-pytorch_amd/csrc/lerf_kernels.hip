@@ -383,6 +383,26 @@ int launch_resize(const ResizeArgs& a, hipStream_t st) {
     return LERF_EUNSUPPORTED;
 }
 
+// fixed interpolation kernels of resize_right/interp_methods.py:35-70 (the reference's non-learned warps,
+// resize_right2d_numpy.py:451-494); evaluated in float64 like the reference, eps = float32 eps
+__device__ __forceinline__ double fixed_kernel_1d(int kind, double x) {
+#pragma clang fp contract(off)
+    const double pi = 3.141592653589793;
+    const double eps = (double)kEps32;
+    if (kind == LERF_KIND_CUBIC) {                                        // :35-43
+        const double a = fabs(x), a2 = a * a, a3 = a * a * a;
+        return (1.5 * a3 - 2.5 * a2 + 1.0) * (a <= 1.0 ? 1.0 : 0.0) +
+               (-0.5 * a3 + 2.5 * a2 - 4.0 * a + 2.0) * ((1.0 < a && a <= 2.0) ? 1.0 : 0.0);
+    }
+    if (kind == LERF_KIND_LANCZOS2)                                       // :46-50
+        return ((sin(pi * x) * sin(pi * x / 2) + eps) / ((pi * pi * (x * x) / 2) + eps)) * (fabs(x) < 2.0 ? 1.0 : 0.0);
+    if (kind == LERF_KIND_LANCZOS3)                                       // :53-57
+        return ((sin(pi * x) * sin(pi * x / 3) + eps) / ((pi * pi * (x * x) / 3) + eps)) * (fabs(x) < 3.0 ? 1.0 : 0.0);
+    if (kind == LERF_KIND_BILINEAR)                                       // :60-64
+        return (x + 1.0) * ((-1.0 <= x && x < 0.0) ? 1.0 : 0.0) + (1.0 - x) * ((0.0 <= x && x <= 1.0) ? 1.0 : 0.0);
+    return ((-1.0 <= x && x < 0.0) ? 1.0 : 0.0) + ((0.0 <= x && x <= 1.0) ? 1.0 : 0.0);   // box :67-70
+}
+
 // ---------------------------------------------------------------------------
 // A7/A8: homographic warp, geometry per output pixel in float64
 // ---------------------------------------------------------------------------
@@ -432,8 +452,10 @@ warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                     A alpha = (A)((float)max_sigma * (p0 * 2.0f - 1.0f));
                     // class decisions on the float64 distances
                     w = lin_factor<A>(alpha, dx, dist_class(dxd)) * lin_factor<A>(alpha, dy, dist_class(dyd));
-                } else {
+                } else if (KIND == LERF_KIND_NEAREST) {
                     w = (dist_class(dxd) != 0 && dist_class(dyd) != 0) ? (A)1 : (A)0;     // box2d
+                } else {
+                    w = (A)(fixed_kernel_1d(KIND, dxd) * fixed_kernel_1d(KIND, dyd));     // cubic2d / linear2d / lanczos
                 }
                 A val = inside ? (A)Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : (A)0;
                 num += w * val;
@@ -455,6 +477,10 @@ static int warp_dispatch_kind(const WarpArgs& a, hipStream_t st) {
     if (a.kind == LERF_KIND_GAUSS) LERF_WP(LERF_KIND_GAUSS);
     else if (a.kind == LERF_KIND_LINEAR) LERF_WP(LERF_KIND_LINEAR);
     else if (a.kind == LERF_KIND_NEAREST) LERF_WP(LERF_KIND_NEAREST);
+    else if (a.kind == LERF_KIND_CUBIC) LERF_WP(LERF_KIND_CUBIC);
+    else if (a.kind == LERF_KIND_BILINEAR) LERF_WP(LERF_KIND_BILINEAR);
+    else if (a.kind == LERF_KIND_LANCZOS2) LERF_WP(LERF_KIND_LANCZOS2);
+    else if (a.kind == LERF_KIND_LANCZOS3) LERF_WP(LERF_KIND_LANCZOS3);
     else return LERF_EUNSUPPORTED;
 #undef LERF_WP
     return LERF_OK;
@@ -462,11 +488,12 @@ static int warp_dispatch_kind(const WarpArgs& a, hipStream_t st) {
 
 int launch_warp(const WarpArgs& a, hipStream_t st) {
     if (a.geo.S < 1 || a.geo.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
-    if (a.in_dtype == LERF_U8 && (a.h_dtype == LERF_U8 || a.kind == LERF_KIND_NEAREST)) {
+    const bool fixed = a.kind >= LERF_KIND_NEAREST;     // no hyper-parameter maps
+    if (a.in_dtype == LERF_U8 && (a.h_dtype == LERF_U8 || fixed)) {
         if (a.out_dtype == LERF_U8) return warp_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
         if (a.out_dtype == LERF_F32) return warp_dispatch_kind<uint8_t, uint8_t, float, float>(a, st);
         if (a.out_dtype == LERF_F64) return warp_dispatch_kind<uint8_t, uint8_t, double, double>(a, st);
-    } else if (a.in_dtype == LERF_F32 && (a.h_dtype == LERF_F32 || a.kind == LERF_KIND_NEAREST)) {
+    } else if (a.in_dtype == LERF_F32 && (a.h_dtype == LERF_F32 || fixed)) {
         if (a.out_dtype == LERF_F32) return warp_dispatch_kind<float, float, float, float>(a, st);
         if (a.out_dtype == LERF_F64) return warp_dispatch_kind<float, float, double, double>(a, st);
     }

@@ -246,7 +246,7 @@ def warp_hwc_u8(feat_u8, hq_u8, geo: WarpGeometry, kind="gauss", max_sigma=10.0,
     torch = _torch()
     feat = feat_u8.contiguous()
     H, W, Cn = feat.shape
-    nh = {"gauss": 3, "linear": 1, "nearest": 0}[kind]
+    nh = {"gauss": 3, "linear": 1}.get(kind, 0)
     o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=feat.device)
     pf = _planes_hwc(feat)
     if nh:
@@ -263,7 +263,7 @@ def warp_hwc_u8(feat_u8, hq_u8, geo: WarpGeometry, kind="gauss", max_sigma=10.0,
 def warp_planar(feat, hypers, geo: WarpGeometry, kind="gauss", max_sigma=10.0, out="f32"):
     torch = _torch()
     feat = feat.contiguous().float()
-    nh = {"gauss": 3, "linear": 1, "nearest": 0}[kind]
+    nh = {"gauss": 3, "linear": 1}.get(kind, 0)
     N, H, W = feat.shape
     o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
     pf = _planes_chw(feat)

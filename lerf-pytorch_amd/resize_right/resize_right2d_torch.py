@@ -143,3 +143,37 @@ class AmplifiedLinearWarp2dTorch(Warp2dTorch):
 
     def warp(self, input, alpha):
         return self._run("linear", input, [alpha], self.max_sigma)
+
+
+# fixed-kernel baselines of the reference (resize_right2d_numpy.py:451-494, resize_right2d_torch.py:372-388);
+# weights from resize_right/interp_methods.py evaluated in float64 on the device
+class BicubicWarp2dTorch(Warp2dTorch):
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+    def warp(self, input):
+        return self._run("cubic", input, [], 1.0)
+
+
+class BilinearWarp2dTorch(Warp2dTorch):
+    def __init__(self, support_sz=2, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+    def warp(self, input):
+        return self._run("bilinear", input, [], 1.0)
+
+
+class Lanczos2Warp2dTorch(Warp2dTorch):
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+    def warp(self, input):
+        return self._run("lanczos2", input, [], 1.0)
+
+
+class Lanczos3Warp2dTorch(Warp2dTorch):
+    def __init__(self, support_sz=6, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+    def warp(self, input):
+        return self._run("lanczos3", input, [], 1.0)

@@ -316,6 +316,23 @@ def warp_geometry(matrix, in_hw, out_hw, S):
     return dict(gx=gx + plx, gy=gy + ply, lx=lx + plx, ly=ly + ply, pad=(plx, phx, ply, phy))
 
 
+def fixed_kernel(kind, x):
+    """cubic / lanczos2 / lanczos3 / bilinear 1-D kernels (resize_right/interp_methods.py:35-64)."""
+    x = np.asarray(x, dtype=np.float64)
+    pi = math.pi
+    if kind == "cubic":
+        a = np.abs(x)
+        a2, a3 = a ** 2, a ** 3
+        return (1.5 * a3 - 2.5 * a2 + 1.) * (a <= 1.) + (-0.5 * a3 + 2.5 * a2 - 4. * a + 2.) * ((1. < a) & (a <= 2.))
+    if kind == "lanczos2":
+        return ((np.sin(pi * x) * np.sin(pi * x / 2) + EPS32) / ((pi ** 2 * x ** 2 / 2) + EPS32)) * (np.abs(x) < 2)
+    if kind == "lanczos3":
+        return ((np.sin(pi * x) * np.sin(pi * x / 3) + EPS32) / ((pi ** 2 * x ** 2 / 3) + EPS32)) * (np.abs(x) < 3)
+    if kind == "bilinear":
+        return (x + 1) * ((-1 <= x) & (x < 0)) + (1 - x) * ((0 <= x) & (x <= 1))
+    raise ValueError(kind)
+
+
 def _warp_core(feat, params, matrix, out_hw, S, kind, max_sigma):
     feat = np.asarray(feat, dtype=np.float32)
     C, H, W = feat.shape
@@ -337,10 +354,12 @@ def _warp_core(feat, params, matrix, out_hw, S, kind, max_sigma):
                 w = _gauss_w(tmp_p[0][:, fx, fy], tmp_p[1][:, fx, fy], tmp_p[2][:, fx, fy], dx[None], dy[None])
             elif kind == "linear":
                 w = _lin_w(tmp_p[0][:, fx, fy], dx[None], dy[None])
-            else:   # nearest / box  (interp_methods.py:67-70)
+            elif kind == "nearest":   # box  (interp_methods.py:67-70)
                 bx = ((-1 <= dx) & (dx < 0)).astype(np.float64) + ((0 <= dx) & (dx <= 1)).astype(np.float64)
                 by = ((-1 <= dy) & (dy < 0)).astype(np.float64) + ((0 <= dy) & (dy <= 1)).astype(np.float64)
                 w = np.broadcast_to((bx * by)[None], (C, oH, oW))
+            else:                     # fixed kernels (interp_methods.py:35-64, 73-95)
+                w = np.broadcast_to((fixed_kernel(kind, dx) * fixed_kernel(kind, dy))[None], (C, oH, oW))
             num += w * tmp_in[:, fx, fy]
             den += w
     with np.errstate(divide="ignore", invalid="ignore"):

@@ -216,6 +216,25 @@ def g4_warp():
     print("G4", len(out))
 
 
+def g7_fixed_warp():
+    """fixed-kernel warps (BicubicWarp2dNumpy ... Lanczos3Warp2dNumpy) on the G4 inputs, 60x70 out"""
+    from resize_right.resize_right2d_numpy import (BicubicWarp2dNumpy, BilinearWarp2dNumpy, Lanczos2Warp2dNumpy,
+                                                   Lanczos3Warp2dNumpy)
+    g4 = np.load(os.path.join(OUT, "g4_warp.npz"))
+    out = {}
+    for p in ("isc", "osc"):
+        feat = g4["%s/feat" % p].astype(np.float32)
+        M = g4["%s/matrix" % p]
+        for name, cls in (("cubic", BicubicWarp2dNumpy), ("bilinear", BilinearWarp2dNumpy),
+                          ("lanczos2", Lanczos2Warp2dNumpy), ("lanczos3", Lanczos3Warp2dNumpy)):
+            w = cls()
+            w.set_shape([3, 52, 52], M, [3, 60, 70])
+            out["%s/%s" % (p, name)] = w.warp(feat)
+            out["%s/%s/pad" % (p, name)] = np.array([w.pad_vec[1][0], w.pad_vec[1][1], w.pad_vec[2][0], w.pad_vec[2][1]])
+    np.savez_compressed(os.path.join(OUT, "g7_fixed_warp.npz"), **out)
+    print("G7", len(out))
+
+
 def g5_set5():
     res = {"sr": {}, "warp": {}}
     names = ["baby", "bird", "butterfly", "head", "woman"]
@@ -301,7 +320,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -310,5 +329,7 @@ if __name__ == "__main__":
         g4_warp()
     if "g6" in which:
         g6_torch()
+    if "g7" in which:
+        g7_fixed_warp()
     if "g5" in which:
         g5_set5()

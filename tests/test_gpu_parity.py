@@ -420,3 +420,17 @@ def test_fused_equals_unfused_and_oracle_shape_sweep(torch, oracle, luts_g, luts
         if H * W <= 130 * 70:
             ref = oracle.sr_pipeline(img, luts, sc[0], sc[1], S=S, linear=(model == "lerf-l"))
             assert np.array_equal(a, ref)
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_fixed_kernel_warp_classes_vs_golden(golden, p):
+    """the reference's non-learned warps (resize_right2d_numpy.py:451-494) through the same warp kernel"""
+    from lerf_pytorch_amd.resize_right import resize_right2d_numpy as rn
+    g4, g7 = golden("g4_warp.npz"), golden("g7_fixed_warp.npz")
+    feat = g4["%s/feat" % p].astype(np.float32)
+    for name, cls in (("cubic", rn.BicubicWarp2dNumpy), ("bilinear", rn.BilinearWarp2dNumpy),
+                      ("lanczos2", rn.Lanczos2Warp2dNumpy), ("lanczos3", rn.Lanczos3Warp2dNumpy)):
+        w = cls()
+        w.set_shape([3, 52, 52], g4["%s/matrix" % p], [3, 60, 70])
+        assert [w.pad_vec[1][0], w.pad_vec[1][1], w.pad_vec[2][0], w.pad_vec[2][1]] == list(g7["%s/%s/pad" % (p, name)])
+        np.testing.assert_allclose(w.warp(feat), g7["%s/%s" % (p, name)], rtol=0, atol=1e-9, equal_nan=True)

@@ -153,3 +153,12 @@ def test_set5_warp_known_answers(oracle, luts_g, p):
         assert abs(m - r["mpsnr"]) < 1e-3
         ms.append(m)
     assert "%.2f" % np.mean(ms) == "%.2f" % published[p]
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+@pytest.mark.parametrize("kind,S", [("cubic", 4), ("bilinear", 2), ("lanczos2", 4), ("lanczos3", 6)])
+def test_fixed_kernel_warps(oracle, golden, p, kind, S):
+    g4, g7 = golden("g4_warp.npz"), golden("g7_fixed_warp.npz")
+    feat = g4["%s/feat" % p].astype(np.float32)
+    out = oracle.warp_params_f32(feat, None, None, None, g4["%s/matrix" % p], (60, 70), S, 1, kind)
+    np.testing.assert_allclose(out, g7["%s/%s" % (p, kind)], rtol=0, atol=1e-9, equal_nan=True)
