@@ -114,3 +114,41 @@ def test_lut_loader_shapes():
         assert sorted(d) == sorted(["s1_%sr0" % m for m in "sct"] + ["s2_%sr%d" % (m, r) for m in "sct" for r in (0, 1)])
         assert d["s1_sr0"].shape == (83521, 1) and d["s2_tr1"].shape == (83521, oC)
         assert all(v.dtype == np.int8 for v in d.values())
+
+
+# ---- property tests (hypothesis): host geometry == oracle for arbitrary sizes / scales / supports
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=150, deadline=None)
+@given(n_in=st.integers(1, 3000), scale=st.one_of(st.sampled_from([1.0, 1.5, 2.0, 2.4, 3.0, 4.0]),
+                                                   st.floats(1.0, 8.0, allow_nan=False, allow_infinity=False)),
+       S=st.integers(1, 8))
+def test_sr_tables_property(n_in, scale, S):
+    from oracle import lerf_oracle as O
+    n_out = O.out_size(n_in, scale)
+    assert _lib.out_size(n_in, scale) == n_out
+    left, d64, d32, pads = _lib.sr_axis_tables(n_in, n_out, scale, S)
+    ol, od, plo, phi = O.sr_axis_tables(n_in, n_out, scale, S)
+    assert np.array_equal(left, ol) and np.array_equal(d64, od) and pads == (plo, phi)
+    assert np.all(np.diff(left) >= 0)                       # monotone: what the tile / strip ownership search relies on
+    cls = lambda x: np.where((x >= -1) & (x < 0), 1, np.where((x >= 0) & (x <= 1), 2, 0))
+    assert np.array_equal(cls(d64), cls(d32.astype(np.float64)))
+
+
+@settings(max_examples=60, deadline=None)
+@given(H=st.integers(16, 400), world=st.integers(1, 8), S=st.sampled_from([2, 4]),
+       scale=st.sampled_from([1.0, 1.5, 2.0, 2.4, 3.0, 4.0]))
+def test_strip_plan_property(H, world, S, scale):
+    from oracle import lerf_oracle as O
+    from lerf_pytorch_amd import dist as ldist
+    if H < world * ldist.halo_rows(S):
+        return
+    left, _, _, _ = O.sr_axis_tables(H, O.out_size(H, scale), scale, S)
+    prev = 0
+    for r in range(world):
+        p = ldist.StripPlan(H, world, r, S, left)
+        assert p.check_support(left)
+        assert p.out_rows()[0] == prev
+        prev = p.out_rows()[1]
+    assert prev == len(left)
