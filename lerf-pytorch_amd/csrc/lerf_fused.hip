@@ -314,16 +314,26 @@ sr_fused_kernel(Params P) {
 #ifdef LERF_STAMPS
     if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
 #endif
-    // ---- input tile with clamped coordinates (np.pad(..., 'edge') in every rotated frame)
+    // ---- input tile with clamped coordinates (np.pad(..., 'edge') in every rotated frame);
+    //      every load of a thread is issued before its first LDS store (one L2/HBM latency, not 18)
     {
         uint8_t* Ct = smem + D::OFF_C;
-        for (int p = tid; p < D::NI; p += NT) {
+        constexpr int KI = (D::NI + NT - 1) / NT;
+        uint8_t v[KI];
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int p = min(tid + k * NT, D::NI - 1);
             int ry = p / D::IP;
             int r3 = p - ry * D::IP;
             int rx = r3 / CH;
             int c = r3 - rx * CH;
             int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
-            Ct[p] = img[((int64_t)gy * W + gx) * CH + c];
+            v[k] = img[((int64_t)gy * W + gx) * CH + c];
+        }
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int p = tid + k * NT;
+            if (p < D::NI) Ct[p] = v[k];
         }
     }
 
