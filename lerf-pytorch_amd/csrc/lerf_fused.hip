@@ -69,7 +69,7 @@ struct Dims {
     static constexpr int OFF_D = OFF_X;
     static constexpr int OFF_GEO = OFF_D + up16(NH * 4);
     static constexpr int GEO_ROWS = 320;                          // max owned output rows / cols per tile (scale <= 4.9)
-    static constexpr int SZ_GEO = 2 * GEO_ROWS * (4 + 4 * S);
+    static constexpr int SZ_GEO = 2 * GEO_ROWS * (4 + 4 * S) + (GEO_ROWS + 16) * 4;   // + row-group table
     static constexpr int END3 = OFF_GEO + SZ_GEO;
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int LDS_BYTES = cmax(END1, cmax(END2, END3)) + 512;  // + small control block
@@ -669,7 +669,143 @@ sr_fused_kernel(Params P) {
     __syncthreads();
 
     LERF_STAMP(11);
-    // ---- stage 3: one task = one 4-byte-aligned dword of an output row segment (coalesced dword stores)
+    // ---- stage 3.  S = 2: consecutive output rows that start at the same source row (2 rows at x2, 3 at x3 ...)
+    //      form a row group and share their taps: one task = (row group, one 4-byte-aligned output dword column);
+    //      the tap loads, the u8 -> f32 conversions and the column terms are done once per group.
+    if constexpr (S == 2) {
+        constexpr int GMAX = 5;                                   // rows per group (scale <= 4.1 is enforced by the host)
+        int* g_grp = reinterpret_cast<int*>(g_dc + D::GEO_ROWS * S);
+        const int ncolc = ncol * CH;
+        const int ndw = (ncolc + 6) >> 2;
+        const int64_t rowpitch = (int64_t)P.oW * CH;
+        uint8_t* seg0 = outp + ((int64_t)i0 * P.oW + j0) * CH;
+        const bool rows_align = (rowpitch & 3) == 0;              // dword columns line up across the rows of a group
+        if (wave == 0) {
+            int ng = 0;
+            for (int base = 0; base < nrow; base += 64) {
+                const int il = base + lane;
+                bool start = false;
+                if (il < nrow)
+                    start = il == 0 || !rows_align || g_lr[il] != g_lr[il - 1] || (il >= GMAX && g_lr[il - GMAX] == g_lr[il]);
+                const unsigned long long m = __ballot(start);
+                if (start) g_grp[ng + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = il;
+                ng += __popcll(m);
+            }
+            if (lane == 0) {
+                g_grp[ng] = nrow;
+                ctl[21] = ng;
+            }
+        }
+        __syncthreads();
+        const int ngrp = ctl[21];
+        const unsigned magic = (unsigned)((0x100000000ull + (unsigned)ndw - 1) / (unsigned)(ndw > 0 ? ndw : 1));
+        const float ms255 = P.max_sigma * (1.0f / 255.0f);
+        const int ntask = ngrp * ndw;
+        for (int t = tid; t < ntask; t += NT) {
+            const int g = (int)__umulhi((unsigned)t, magic);
+            const int dw = t - g * ndw;
+            const int il0 = g_grp[g];
+            const int gs = g_grp[g + 1] - il0;
+            uint8_t* seg = seg0 + il0 * rowpitch;
+            const int a0 = (int)(reinterpret_cast<uintptr_t>(seg) & 3u);
+            const int b0 = dw * 4 - a0;
+            const int lr = g_lr[il0];
+            uint32_t packed[GMAX];
+            unsigned tiemask = 0;                                 // bit r*4+u
+#pragma unroll
+            for (int r = 0; r < GMAX; ++r) packed[r] = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int xc = min(max(b0 + u, 0), ncolc - 1);
+                const int jl = xc / CH;
+                const int c = xc - jl * CH;
+                const int lc = g_lc[jl];
+                // shared by the rows of the group: per tap (a = column offset, b = row offset)
+                float p0[4], k1[4], ty[4], v[4];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const float dy = g_dc[jl * 2 + a];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                        v[a * 2 + b] = (float)(d >> 24);
+                        const float k0 = (float)(d & 0xFFu);
+                        if (KIND == LERF_KIND_GAUSS) {
+                            p0[a * 2 + b] = s3::gauss_m2rho_u8(k0);
+                            k1[a * 2 + b] = (float)((d >> 8) & 0xFFu);
+                            ty[a * 2 + b] = s3::gauss_t_u8((float)((d >> 16) & 0xFFu), dy);
+                        } else {
+                            const float alpha = s3::lin_alpha_u8(k0, ms255);
+                            p0[a * 2 + b] = alpha;
+                            ty[a * 2 + b] = s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
+                            k1[a * 2 + b] = 0.0f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < GMAX; ++r) {
+                    if (r < gs) {
+                        float e[4];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                const float dx = g_dr[(il0 + r) * 2 + b];
+                                if (KIND == LERF_KIND_GAUSS)
+                                    e[a * 2 + b] = s3::gauss_form_parts(p0[a * 2 + b], s3::gauss_t_u8(k1[a * 2 + b], dx), ty[a * 2 + b]);
+                                else
+                                    e[a * 2 + b] = s3::lin_factor(p0[a * 2 + b], dx, s3::dist_class_f(dx)) * ty[a * 2 + b];
+                            }
+                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, 4, true, true>(e, v);
+                        bool tie;
+                        packed[r] |= s3::to_u8_tie(xf, &tie) << (8 * u);
+                        if (tie) tiemask |= 1u << (r * 4 + u);
+                    }
+                }
+            }
+            if (tiemask != 0 && P.dis_r64 != nullptr) {
+                // rare: re-evaluate in float64 exactly as the reference does (lerf_stage3.h, tie guard)
+#pragma unroll 1
+                for (int q = 0; q < GMAX * 4; ++q) {
+                    if (!((tiemask >> q) & 1u)) continue;
+                    const int r = q >> 2, u = q & 3;
+                    const int xc = min(max(b0 + u, 0), ncolc - 1);
+                    const int jl = xc / CH;
+                    const int c = xc - jl * CH;
+                    const int lc = g_lc[jl];
+                    uint32_t dd[4];
+                    double dx64[2], dy64[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il0 + r) * 2 + b];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * 2 + a];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) dd[a * 2 + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                    const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, 2>(dd, dx64, dy64, P.max_sigma));
+#pragma unroll
+                    for (int rr = 0; rr < GMAX; ++rr)
+                        if (rr == r) packed[rr] = (packed[rr] & ~(0xFFu << (8 * u))) | (r8 << (8 * u));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < GMAX; ++r) {
+                if (r < gs) {
+                    uint8_t* sr = seg + r * rowpitch;
+                    if (b0 >= 0 && b0 + 3 < ncolc) {
+                        // streaming store: the output is never re-read here, keep the LUT pack resident in L2 instead
+                        __builtin_nontemporal_store(packed[r], reinterpret_cast<uint32_t*>(sr + b0));
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (b0 + u >= 0 && b0 + u < ncolc) sr[b0 + u] = (uint8_t)(packed[r] >> (8 * u));
+                    }
+                }
+            }
+        }
+    } else
+    // ---- stage 3, general support: one task = one 4-byte-aligned dword of an output row segment
     {
         const int ncolc = ncol * CH;
         const int ndw = (ncolc + 6) >> 2;                         // dwords that can touch a row segment

@@ -48,12 +48,22 @@ __device__ __forceinline__ float gauss_scale(float max_sigma) {
     return (max_sigma * (1.0f / 255.0f)) * 0.84932180028801904272f;        // sqrt(0.5 * log2(e))
 }
 
-__device__ __forceinline__ float gauss_form_u8(float k0, float k1, float k2, float dxs, float dys) {
+// the pieces of gauss_form_u8, so that callers can hoist what several outputs share (bit-identical results)
+__device__ __forceinline__ float gauss_m2rho_u8(float k0) {
 #pragma clang fp contract(off)
-    const float m2rho = __builtin_fmaf(k0, -4.0f / 255.0f, 2.0f);
-    const float tx = k1 * dxs, ty = k2 * dys;
+    return __builtin_fmaf(k0, -4.0f / 255.0f, 2.0f);
+}
+__device__ __forceinline__ float gauss_t_u8(float k, float ds) {
+#pragma clang fp contract(off)
+    return k * ds;
+}
+__device__ __forceinline__ float gauss_form_parts(float m2rho, float tx, float ty) {
+#pragma clang fp contract(off)
     float e = __builtin_fmaf(ty, ty, tx * tx);
     return __builtin_fmaf(m2rho, tx * ty, e);
+}
+__device__ __forceinline__ float gauss_form_u8(float k0, float k1, float k2, float dxs, float dys) {
+    return gauss_form_parts(gauss_m2rho_u8(k0), gauss_t_u8(k1, dxs), gauss_t_u8(k2, dys));
 }
 
 // exp2(emin' - e') for pre-scaled forms
