@@ -124,7 +124,8 @@ __host__ __device__ constexpr Off3 tile_offsets(char mode, int rot) {
 // STRIDE_SCALE = bytes per LUT entry, folded into the strides so idx[] are byte offsets.
 // ---------------------------------------------------------------------------
 template <int STRIDE_SCALE>
-__device__ __forceinline__ void simplex_walk(unsigned ka, int basea, int vb, int vc, int vd, int (&idx)[5], unsigned (&w)[5]) {
+__device__ __forceinline__ void simplex_walk(unsigned ka, int basea, int vb, int vc, int vd, int (&idx)[5], unsigned (&w)[5],
+                                             unsigned (&f)[4]) {
     unsigned k0 = ka;
     unsigned k1 = ((unsigned)(vb & 15) << 16) | (unsigned)(kStrideB * STRIDE_SCALE);
     unsigned k2 = ((unsigned)(vc & 15) << 16) | (unsigned)(kStrideC * STRIDE_SCALE);
@@ -137,6 +138,7 @@ __device__ __forceinline__ void simplex_walk(unsigned ka, int basea, int vb, int
     ce_desc(k1, k3);
     ce_desc(k1, k2);
     const unsigned f0 = k0 >> 16, f1 = k1 >> 16, f2 = k2 >> 16, f3 = k3 >> 16;
+    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
     idx[1] = idx[0] + (int)(k0 & 0xFFFFu);
     idx[2] = idx[1] + (int)(k1 & 0xFFFFu);
     idx[3] = idx[2] + (int)(k2 & 0xFFFFu);
@@ -199,9 +201,9 @@ __device__ __forceinline__ int byte_lookups(const int8_t* lut, const uint8_t* sr
     const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)kStrideA;
     const int basea = (int)__umul24((unsigned)(va >> 4), kStrideA);
     int idx[NROT][5];
-    unsigned w[NROT][5];
+    unsigned w[NROT][5], f[NROT][4];
 #pragma unroll
-    for (int i = 0; i < NROT; ++i) simplex_walk<1>(ka, basea, vb[i], vc[i], vd[i], idx[i], w[i]);
+    for (int i = 0; i < NROT; ++i) simplex_walk<1>(ka, basea, vb[i], vc[i], vd[i], idx[i], w[i], f[i]);
     // stage C: all LUT gathers in flight together
     int e[NROT][5];
 #pragma unroll
@@ -209,13 +211,16 @@ __device__ __forceinline__ int byte_lookups(const int8_t* lut, const uint8_t* sr
 #pragma unroll
         for (int n = 0; n < 5; ++n) e[i][n] = (int)lut[idx[i][n]];
     __builtin_amdgcn_sched_barrier(0);
-    // stage D: MACs
-    int acc = 0;
+    // stage D: sum_n w_n P_n = 16 P_0 + sum_n f_n (P_{n+1} - P_n)   (w_0 = 16 - f_0, w_n = f_{n-1} - f_n, w_4 = f_3):
+    //          four multiply-adds and four subtractions per lookup instead of five weights + five multiply-adds
+    int acc = 0, sum0 = 0;
 #pragma unroll
-    for (int i = 0; i < NROT; ++i)
+    for (int i = 0; i < NROT; ++i) {
+        sum0 += e[i][0];
 #pragma unroll
-        for (int n = 0; n < 5; ++n) acc += __mul24((int)w[i][n], e[i][n]);
-    return acc;
+        for (int n = 0; n < 4; ++n) acc += __mul24((int)f[i][n], e[i][n + 1] - e[i][n]);
+    }
+    return acc + kQ * sum0;
 }
 
 // position p of a region (pitch DPc px-ch per row, origin (y0g,x0g) in the frame) ->
@@ -569,9 +574,9 @@ sr_fused_kernel(Params P) {
                             const int basea = (int)__umul24((unsigned)((va >> 4) - 4 * q), kStrideA * 4);
                             const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)(kStrideA * 4);
                             int i0x[5], i1x[5];
-                            unsigned w0[5], w1[5];
-                            simplex_walk<4>(ka, basea, vb0, vc0, vd0, i0x, w0);
-                            simplex_walk<4>(ka, basea, vb1, vc1, vd1, i1x, w1);
+                            unsigned w0[5], w1[5], fu0[4], fu1[4];
+                            simplex_walk<4>(ka, basea, vb0, vc0, vd0, i0x, w0, fu0);
+                            simplex_walk<4>(ka, basea, vb1, vc1, vd1, i1x, w1, fu1);
                             // stage C: ten dword gathers in flight together
                             const uint8_t* qb = smem + D::OFF_X;
                             uint32_t d0[5], d1[5];
