@@ -62,7 +62,7 @@ struct Dims {
     static constexpr int OFF_ACC = OFF_C + up16(NI);
     static constexpr int END1 = OFF_ACC + up16(NF * 2);
     // stage 2 quarter path
-    static constexpr int SZ_Q = up16(QENTRIES * 4);
+    static constexpr int SZ_Q = 24 * NT * 4;                    // 24 dwords per thread >= QENTRIES dwords
     static constexpr int OFF_LST = OFF_X + SZ_Q;
     static constexpr int END2 = OFF_LST + MAXR * NT * 2;
     // stage 3
@@ -514,24 +514,31 @@ sr_fused_kernel(Params P) {
             nph = nq * 6;
         }
         __syncthreads();
-        // explicit scalars (a struct/array here ends up in scratch): 6 x uint4 per thread cover the 6142 uint4
-        static_assert((QENTRIES * 4 + 15) / 16 > 5 * NT && (QENTRIES * 4 + 15) / 16 <= 6 * NT, "piece = 6 uint4 per thread");
-        constexpr int PTAIL = (QENTRIES * 4 + 15) / 16 - 5 * NT;
-        uint4 pr0, pr1, pr2, pr3, pr4, pr5;
-        pr0 = pr1 = pr2 = pr3 = pr4 = pr5 = make_uint4(0, 0, 0, 0);
-#define LERF_PRE_LOAD(SRC)                                                     \
-        do {                                                                   \
-            const uint4* s_ = reinterpret_cast<const uint4*>(SRC);             \
-            pr0 = s_[tid]; pr1 = s_[tid + NT]; pr2 = s_[tid + 2 * NT];         \
-            pr3 = s_[tid + 3 * NT]; pr4 = s_[tid + 4 * NT];                    \
-            if (tid < PTAIL) pr5 = s_[tid + 5 * NT];                           \
+        // The piece travels as 24 dwords per thread: dword i*1024 + tid.  They are stored with ds_write_addtid_b32
+        // (address = M0 + offset + 4*lane, no address VGPR: 128 B/clk/CU against 79 for ds_write_b128), M0 = the
+        // wave's 256-byte column of the piece; the 16-bit offset reaches 16 rows, so two M0 values cover the 24.
+        static_assert(QENTRIES <= 24 * NT && QENTRIES > 23 * NT, "piece = 24 dwords per thread");
+        uint32_t pd[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) pd[i] = 0;
+#define LERF_PRE_LOAD(SRC)                                                                         \
+        do {                                                                                       \
+            const uint32_t* s_ = reinterpret_cast<const uint32_t*>(SRC);                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) pd[i_] = s_[tid + i_ * NT];          \
         } while (0)
-#define LERF_PRE_STORE(DST)                                                    \
-        do {                                                                   \
-            uint4* d_ = reinterpret_cast<uint4*>(DST);                         \
-            d_[tid] = pr0; d_[tid + NT] = pr1; d_[tid + 2 * NT] = pr2;         \
-            d_[tid + 3 * NT] = pr3; d_[tid + 4 * NT] = pr4;                    \
-            if (tid < PTAIL) d_[tid + 5 * NT] = pr5;                           \
+#define LERF_ADDTID(V, OFF) asm volatile("ds_write_addtid_b32 %0 offset:" #OFF :: "v"(V) : "memory")
+#define LERF_PRE_STORE(DST_OFFSET)                                                                 \
+        do {                                                                                       \
+            const uint32_t m0a_ = __builtin_amdgcn_readfirstlane((uint32_t)(DST_OFFSET) + (uint32_t)wave * 256u); \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(m0a_) : "memory");                    \
+            LERF_ADDTID(pd[0], 0); LERF_ADDTID(pd[1], 4096); LERF_ADDTID(pd[2], 8192); LERF_ADDTID(pd[3], 12288); \
+            LERF_ADDTID(pd[4], 16384); LERF_ADDTID(pd[5], 20480); LERF_ADDTID(pd[6], 24576); LERF_ADDTID(pd[7], 28672); \
+            LERF_ADDTID(pd[8], 32768); LERF_ADDTID(pd[9], 36864); LERF_ADDTID(pd[10], 40960); LERF_ADDTID(pd[11], 45056); \
+            LERF_ADDTID(pd[12], 49152); LERF_ADDTID(pd[13], 53248); LERF_ADDTID(pd[14], 57344); LERF_ADDTID(pd[15], 61440); \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(m0a_ + 65536u) : "memory");           \
+            LERF_ADDTID(pd[16], 0); LERF_ADDTID(pd[17], 4096); LERF_ADDTID(pd[18], 8192); LERF_ADDTID(pd[19], 12288); \
+            LERF_ADDTID(pd[20], 16384); LERF_ADDTID(pd[21], 20480); LERF_ADDTID(pd[22], 24576); LERF_ADDTID(pd[23], 28672); \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
         } while (0)
         if (nph > 0) LERF_PRE_LOAD(s2 + (size_t)__builtin_amdgcn_readfirstlane(ctl[24]) * QSTRIDE);
         for (int ph = 0; ph < nph; ++ph) {
@@ -541,7 +548,7 @@ sr_fused_kernel(Params P) {
                 const int q = __builtin_amdgcn_readfirstlane(ctl[24 + qi]);
                 const unsigned long long t_copy = LERF_NOW();
                 (void)t_copy;
-                LERF_PRE_STORE(smem + D::OFF_X);
+                LERF_PRE_STORE(D::OFF_X);
                 Off3 o0, o1;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
