@@ -45,6 +45,7 @@ constexpr int R1 = 3, R2 = 3;      // stage radii for modes s,c,t
 constexpr int LUT_PAD = 83584;     // padded entries per LUT in the pack (16-B multiple)
 constexpr int QSTRIDE = 4 * kStrideA;        // entries between quarter origins
 constexpr int QENTRIES = 5 * kStrideA;       // entries a quarter piece holds
+constexpr int QPIECE_BYTES = 24 * NT * 4;     // one stage-2 quarter piece in the pack / in LDS: 96 KiB (24565 dwords used)
 constexpr int MAXR = 17;           // max slot rounds: ceil(NH/1024) + 4 (S=4: 13872/1024 -> 14 + 3)
 
 template <int S>
@@ -62,7 +63,7 @@ struct Dims {
     static constexpr int OFF_ACC = OFF_C + up16(NI);
     static constexpr int END1 = OFF_ACC + up16(NF * 2);
     // stage 2 quarter path
-    static constexpr int SZ_Q = 24 * NT * 4;                    // 24 dwords per thread >= QENTRIES dwords
+    static constexpr int SZ_Q = QPIECE_BYTES;
     static constexpr int OFF_LST = OFF_X + SZ_Q;
     static constexpr int END2 = OFF_LST + MAXR * NT * 2;
     // stage 3
@@ -514,33 +515,37 @@ sr_fused_kernel(Params P) {
             nph = nq * 6;
         }
         __syncthreads();
-        // The piece travels as 24 dwords per thread: dword i*1024 + tid.  They are stored with ds_write_addtid_b32
-        // (address = M0 + offset + 4*lane, no address VGPR: 128 B/clk/CU against 79 for ds_write_b128), M0 = the
-        // wave's 256-byte column of the piece; the 16-bit offset reaches 16 rows, so two M0 values cover the 24.
-        static_assert(QENTRIES <= 24 * NT && QENTRIES > 23 * NT, "piece = 24 dwords per thread");
-        uint32_t pd[24];
-#pragma unroll
-        for (int i = 0; i < 24; ++i) pd[i] = 0;
+        // The piece travels as 6 x 16 bytes per thread (wave w, iteration i: 1-KiB block B = 16 i + w of the piece,
+        // lane L its bytes 16 L..16 L+15) and is stored with ds_write_addtid_b32 (address = M0 + offset + 4*lane, no
+        // address VGPR: 128 B/clk/CU against 79 for ds_write_b128).  addtid puts component c of all lanes at
+        // block + 256 c + 4 L, so the pack holds every block pre-permuted (global dword 4L+c = logical dword 64c+L)
+        // and LDS ends up in natural order.  M0 = the wave's block column; the 16-bit offset reaches 4 iterations.
+        static_assert(QENTRIES * 4 <= QPIECE_BYTES, "piece = 6 x uint4 per thread");
+        uint4 pr0, pr1, pr2, pr3, pr4, pr5;
+        pr0 = pr1 = pr2 = pr3 = pr4 = pr5 = make_uint4(0, 0, 0, 0);
 #define LERF_PRE_LOAD(SRC)                                                                         \
         do {                                                                                       \
-            const uint32_t* s_ = reinterpret_cast<const uint32_t*>(SRC);                           \
-            _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) pd[i_] = s_[tid + i_ * NT];          \
+            const uint4* s_ = reinterpret_cast<const uint4*>(SRC) + (wave * 64 + lane);            \
+            pr0 = s_[0]; pr1 = s_[NT]; pr2 = s_[2 * NT]; pr3 = s_[3 * NT]; pr4 = s_[4 * NT]; pr5 = s_[5 * NT]; \
         } while (0)
 #define LERF_ADDTID(V, OFF) asm volatile("ds_write_addtid_b32 %0 offset:" #OFF :: "v"(V) : "memory")
+#define LERF_ADDTID4(R, OFF0, OFF1, OFF2, OFF3) \
+        LERF_ADDTID(R.x, OFF0); LERF_ADDTID(R.y, OFF1); LERF_ADDTID(R.z, OFF2); LERF_ADDTID(R.w, OFF3)
 #define LERF_PRE_STORE(DST_OFFSET)                                                                 \
         do {                                                                                       \
-            const uint32_t m0a_ = __builtin_amdgcn_readfirstlane((uint32_t)(DST_OFFSET) + (uint32_t)wave * 256u); \
+            const uint32_t m0a_ = __builtin_amdgcn_readfirstlane((uint32_t)(DST_OFFSET) + (uint32_t)wave * 1024u); \
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(m0a_) : "memory");                    \
-            LERF_ADDTID(pd[0], 0); LERF_ADDTID(pd[1], 4096); LERF_ADDTID(pd[2], 8192); LERF_ADDTID(pd[3], 12288); \
-            LERF_ADDTID(pd[4], 16384); LERF_ADDTID(pd[5], 20480); LERF_ADDTID(pd[6], 24576); LERF_ADDTID(pd[7], 28672); \
-            LERF_ADDTID(pd[8], 32768); LERF_ADDTID(pd[9], 36864); LERF_ADDTID(pd[10], 40960); LERF_ADDTID(pd[11], 45056); \
-            LERF_ADDTID(pd[12], 49152); LERF_ADDTID(pd[13], 53248); LERF_ADDTID(pd[14], 57344); LERF_ADDTID(pd[15], 61440); \
+            LERF_ADDTID4(pr0, 0, 256, 512, 768);                                                   \
+            LERF_ADDTID4(pr1, 16384, 16640, 16896, 17152);                                         \
+            LERF_ADDTID4(pr2, 32768, 33024, 33280, 33536);                                         \
+            LERF_ADDTID4(pr3, 49152, 49408, 49664, 49920);                                         \
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(m0a_ + 65536u) : "memory");           \
-            LERF_ADDTID(pd[16], 0); LERF_ADDTID(pd[17], 4096); LERF_ADDTID(pd[18], 8192); LERF_ADDTID(pd[19], 12288); \
-            LERF_ADDTID(pd[20], 16384); LERF_ADDTID(pd[21], 20480); LERF_ADDTID(pd[22], 24576); LERF_ADDTID(pd[23], 28672); \
+            LERF_ADDTID4(pr4, 0, 256, 512, 768);                                                   \
+            LERF_ADDTID4(pr5, 16384, 16640, 16896, 17152);                                         \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
         } while (0)
-        if (nph > 0) LERF_PRE_LOAD(s2 + (size_t)__builtin_amdgcn_readfirstlane(ctl[24]) * QSTRIDE);
+        const uint8_t* s2q = P.pack + 3 * LUT_PAD;          // [LUT l][quarter q][QPIECE_BYTES], blocks pre-permuted
+        if (nph > 0) LERF_PRE_LOAD(s2q + (size_t)__builtin_amdgcn_readfirstlane(ctl[24]) * QPIECE_BYTES);
         for (int ph = 0; ph < nph; ++ph) {
             {
                 const int qi = ph / 6;
@@ -562,7 +567,7 @@ sr_fused_kernel(Params P) {
                     const int qi2 = (ph + 1) / 6;
                     const int l2 = (ph + 1) - qi2 * 6;
                     const int q2 = __builtin_amdgcn_readfirstlane(ctl[24 + qi2]);
-                    LERF_PRE_LOAD(s2 + (size_t)l2 * LUT_PAD + q2 * QSTRIDE);
+                    LERF_PRE_LOAD(s2q + ((size_t)l2 * 4 + q2) * QPIECE_BYTES);
                 }
                 LERF_STAMP_ADD(8, t_copy);
                 const unsigned long long t_look = LERF_NOW();
@@ -984,7 +989,25 @@ int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
 //   oC == 3: 6 x LUT_PAD uint32 (biased bytes e0+128 | e2+128 << 16 | e1+128 << 24), order s_r0, s_r1, c_r0, ...
 //   oC == 1: 6 x LUT_PAD int8
 size_t fused_lutpack_bytes(int oC) {
-    return (size_t)3 * fused::LUT_PAD + (size_t)6 * fused::LUT_PAD * (oC == 3 ? 4 : 1);
+    return (size_t)3 * fused::LUT_PAD + (oC == 3 ? (size_t)6 * 4 * fused::QPIECE_BYTES : (size_t)6 * fused::LUT_PAD);
+}
+
+// stage-2 LUT (3 channels) -> 4 quarter pieces of biased-byte dwords (e0+128 | e2+128 << 16 | e1+128 << 24);
+// quarter q = LUT entries [q*QSTRIDE, q*QSTRIDE + QENTRIES); every 1-KiB block pre-permuted for the
+// 16-byte-load / ds_write_addtid_b32 transfer: block dword 4L+c holds logical dword 64c+L.
+__global__ void pack_s2_quarters_kernel(const int8_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;      // dword inside a piece
+    const int q = blockIdx.y;
+    if (p >= fused::QPIECE_BYTES / 4) return;
+    const int B = p >> 8, r = p & 255, L = r >> 2, c = r & 3;
+    const int J = B * 256 + c * 64 + L;
+    uint32_t d = 0;
+    if (J < fused::QENTRIES) {
+        const int i = q * fused::QSTRIDE + J;
+        d = (uint32_t)((int)src[i * 3 + 0] + 128) | ((uint32_t)((int)src[i * 3 + 2] + 128) << 16) |
+            ((uint32_t)((int)src[i * 3 + 1] + 128) << 24);
+    }
+    dst[(size_t)q * (fused::QPIECE_BYTES / 4) + p] = d;
 }
 
 __global__ void pack_bytes_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst) {
@@ -1017,8 +1040,8 @@ int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st) {
             if (!L->s2[m][r]) return LERF_EINVAL;
             int l = m * 2 + r;
             if (L->oC == 3)
-                hipLaunchKernelGGL(pack_dwords_kernel, grid, block, 0, st, L->s2[m][r],
-                                   (uint32_t*)(s2 + (size_t)l * fused::LUT_PAD * 4));
+                hipLaunchKernelGGL(pack_s2_quarters_kernel, dim3((fused::QPIECE_BYTES / 4 + 255) / 256, 4), block, 0, st,
+                                   L->s2[m][r], (uint32_t*)(s2 + (size_t)l * 4 * fused::QPIECE_BYTES));
             else
                 hipLaunchKernelGGL(pack_bytes_kernel, grid, block, 0, st, L->s2[m][r],
                                    (int8_t*)(s2 + (size_t)l * fused::LUT_PAD));
