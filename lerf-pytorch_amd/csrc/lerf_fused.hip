@@ -68,7 +68,11 @@ struct Dims {
     static constexpr int END2 = OFF_LST + MAXR * NT * 2;
     // stage 3
     static constexpr int OFF_D = OFF_X;
-    static constexpr int OFF_GEO = OFF_D + up16(NH * 4);
+    // S = 2: the tile geometry is staged at kernel start (its table look-ups overlap the input load) into a
+    // region of its own; S = 4 has no room for that and stages it right before stage 3, over the dead LUT area
+    static constexpr bool GEO_EARLY = (S == 2);
+    static constexpr int cmax0(int a, int b) { return a > b ? a : b; }
+    static constexpr int OFF_GEO = GEO_EARLY ? cmax0(END1, END2) : OFF_D + up16(NH * 4);
     static constexpr int GEO_ROWS = 320;                          // max owned output rows / cols per tile (scale <= 4.9)
     static constexpr int SZ_GEO = 2 * GEO_ROWS * (4 + 4 * S) + (GEO_ROWS + 16) * 4;   // + row-group table
     static constexpr int END3 = OFF_GEO + SZ_GEO;
@@ -316,6 +320,39 @@ sr_fused_kernel(Params P) {
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= P.H && ix0 + D::IX <= P.W;
     const int Hc = interior ? -1 : P.H, Wc = P.W;
 
+    int* g_lr = reinterpret_cast<int*>(smem + D::OFF_GEO);
+    float* g_dr = reinterpret_cast<float*>(g_lr + D::GEO_ROWS);
+    int* g_lc = reinterpret_cast<int*>(g_dr + D::GEO_ROWS * S);
+    float* g_dc = reinterpret_cast<float*>(g_lc + D::GEO_ROWS);
+    // owned output rows / columns: four wave-parallel searches in the global tables
+    auto geo_search = [&]() {
+        if (wave < 4) {
+            const bool rows = wave < 2;
+            const int* tab = rows ? P.left_r : P.left_c;
+            const int n = rows ? P.oH : P.oW;
+            const int ti = rows ? tyi : txi, tn = rows ? P.tiles_y : P.tiles_x, t0 = rows ? ty0 : tx0;
+            int r;
+            if (!(wave & 1)) r = ti == 0 ? 0 : wave_lower_bound(tab, n, t0 - D::R3, lane);
+            else r = ti == tn - 1 ? n : wave_lower_bound(tab, n, t0 + (rows ? TH : TW) - D::R3, lane);
+            if (lane == 0) ctl[16 + wave] = r;
+        }
+    };
+    // tables of the owned block into LDS; LeRF-G distances pre-multiplied by (max_sigma/255)*sqrt(0.5 log2 e)
+    auto geo_stage = [&]() {
+        const int gi0 = ctl[16], gi1 = ctl[17], gj0 = ctl[18], gj1 = ctl[19];
+        const float gscale = KIND == LERF_KIND_GAUSS ? s3::gauss_scale(P.max_sigma) : 1.0f;
+        for (int e = tid; e < gi1 - gi0; e += NT) {
+            g_lr[e] = P.left_r[gi0 + e] - hy0;
+#pragma unroll
+            for (int b = 0; b < S; ++b) g_dr[e * S + b] = P.dis_r[(gi0 + e) * S + b] * gscale;
+        }
+        for (int e = tid; e < gj1 - gj0; e += NT) {
+            g_lc[e] = P.left_c[gj0 + e] - hx0;
+#pragma unroll
+            for (int a = 0; a < S; ++a) g_dc[e * S + a] = P.dis_c[(gj0 + e) * S + a] * gscale;
+        }
+    };
+
     LERF_STAMP(0);
 #ifdef LERF_STAMPS
     if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
@@ -336,6 +373,7 @@ sr_fused_kernel(Params P) {
             int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
             v[k] = img[((int64_t)gy * W + gx) * CH + c];
         }
+        if (D::GEO_EARLY && !EMIT) geo_search();           // table look-ups while the tile loads are in flight
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
             const int p = tid + k * NT;
@@ -351,17 +389,37 @@ sr_fused_kernel(Params P) {
         const int div1 = kQ * 3;
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
         __syncthreads();
+        if (D::GEO_EARLY && !EMIT) geo_stage();            // search results are in ctl; its loads hide behind phase s
         LERF_STAMP(1);
+        // the next LUT rides in registers behind the lookups (explicit scalars: an array/struct that lives
+        // across the position loop ends up in scratch)
+        constexpr int L1N = (LERF_LUT_ENTRIES + 15) / 16, L1TAIL = L1N - 5 * NT;
+        static_assert(L1TAIL > 0 && L1TAIL <= NT, "stage-1 LUT = 5 full uint4 rounds + a tail");
+        uint4 n0, n1, n2, n3, n4, n5 = make_uint4(0, 0, 0, 0);
+#define LERF_S1_LOAD(SRC)                                                                          \
+        do {                                                                                       \
+            const uint4* s_ = reinterpret_cast<const uint4*>(SRC);                                 \
+            n0 = s_[tid]; n1 = s_[tid + NT]; n2 = s_[tid + 2 * NT]; n3 = s_[tid + 3 * NT]; n4 = s_[tid + 4 * NT]; \
+            if (tid < L1TAIL) n5 = s_[tid + 5 * NT];                                               \
+        } while (0)
+#define LERF_S1_STORE()                                                                            \
+        do {                                                                                       \
+            uint4* d_ = reinterpret_cast<uint4*>(smem + D::OFF_LUT);                               \
+            d_[tid] = n0; d_[tid + NT] = n1; d_[tid + 2 * NT] = n2; d_[tid + 3 * NT] = n3; d_[tid + 4 * NT] = n4; \
+            if (tid < L1TAIL) d_[tid + 5 * NT] = n5;                                               \
+        } while (0)
+        LERF_S1_LOAD(P.pack + 1 * LUT_PAD);
         byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         LERF_STAMP(2);
-        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 1 * LUT_PAD, tid);
+        LERF_S1_STORE();
         __syncthreads();
         LERF_STAMP(3);
+        LERF_S1_LOAD(P.pack + 2 * LUT_PAD);
         byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         LERF_STAMP(4);
-        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 2 * LUT_PAD, tid);
+        LERF_S1_STORE();
         __syncthreads();
         LERF_STAMP(5);
         byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
@@ -652,38 +710,15 @@ sr_fused_kernel(Params P) {
         return;
     }
 
-    // ---- stage 3 geometry of the owned output block into LDS
-    int* g_lr = reinterpret_cast<int*>(smem + D::OFF_GEO);
-    float* g_dr = reinterpret_cast<float*>(g_lr + D::GEO_ROWS);
-    int* g_lc = reinterpret_cast<int*>(g_dr + D::GEO_ROWS * S);
-    float* g_dc = reinterpret_cast<float*>(g_lc + D::GEO_ROWS);
-    if (wave < 4) {
-        // four wave-parallel searches for the owned output rows / columns
-        const bool rows = wave < 2;
-        const int* tab = rows ? P.left_r : P.left_c;
-        const int n = rows ? P.oH : P.oW;
-        const int ti = rows ? tyi : txi, tn = rows ? P.tiles_y : P.tiles_x, t0 = rows ? ty0 : tx0;
-        int r;
-        if (!(wave & 1)) r = ti == 0 ? 0 : wave_lower_bound(tab, n, t0 - D::R3, lane);
-        else r = ti == tn - 1 ? n : wave_lower_bound(tab, n, t0 + (rows ? TH : TW) - D::R3, lane);
-        if (lane == 0) ctl[16 + wave] = r;
+    // ---- stage 3 geometry of the owned output block (staged here for S = 4; S = 2 did it at kernel start)
+    if (!D::GEO_EARLY) {
+        geo_search();
+        __syncthreads();
+        geo_stage();
     }
     __syncthreads();
     const int i0 = ctl[16], i1 = ctl[17], j0 = ctl[18], j1 = ctl[19];
     const int nrow = i1 - i0, ncol = j1 - j0;
-    // LeRF-G: distances are staged pre-multiplied by (max_sigma/255)*sqrt(0.5 log2 e)  (lerf_stage3.h)
-    const float gscale = KIND == LERF_KIND_GAUSS ? s3::gauss_scale(P.max_sigma) : 1.0f;
-    for (int e = tid; e < nrow; e += NT) {
-        g_lr[e] = P.left_r[i0 + e] - hy0;
-#pragma unroll
-        for (int b = 0; b < S; ++b) g_dr[e * S + b] = P.dis_r[(i0 + e) * S + b] * gscale;
-    }
-    for (int e = tid; e < ncol; e += NT) {
-        g_lc[e] = P.left_c[j0 + e] - hx0;
-#pragma unroll
-        for (int a = 0; a < S; ++a) g_dc[e * S + a] = P.dis_c[(j0 + e) * S + a] * gscale;
-    }
-    __syncthreads();
 
     LERF_STAMP(11);
     // ---- stage 3.  S = 2: consecutive output rows that start at the same source row (2 rows at x2, 3 at x3 ...)
