@@ -498,24 +498,45 @@ sr_fused_kernel(Params P) {
             }
         }
         __syncthreads();
-        if (tid < 4) {
-            int tot = 0;
-            for (int w = 0; w < NW; ++w) tot += ctl[32 + w * 4 + tid];
-            ctl[tid] = tot;
-        }
-        __syncthreads();
-        if (tid < 4) {
-            int base = 0;
-            for (int qq = 0; qq < tid; ++qq) base += (ctl[qq] + NT - 1) / NT * NT;
-            ctl[8 + tid] = base / NT;                                   // first round of the quarter
-            ctl[12 + tid] = (base + (ctl[tid] + NT - 1) / NT * NT) / NT;  // one past its last round
-            for (int w = 0; w < NW; ++w) {                              // exclusive prefix over waves
-                const int c = ctl[32 + w * 4 + tid];
-                ctl[32 + w * 4 + tid] = base;
-                base += c;
+        if (wave == 0) {
+            // lane = q * 16 + w: scan the 16 wave counts of every quarter inside its 16-lane group
+            static_assert(NW == 16, "one 16-lane group per quarter");
+            const int q = lane >> 4, w = lane & 15;
+            const int c = ctl[32 + w * 4 + q];
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int up = __shfl_up(incl, d, 16);
+                if (w >= d) incl += up;
+            }
+            const int t0 = __shfl(incl, 15), t1 = __shfl(incl, 31), t2 = __shfl(incl, 47), t3 = __shfl(incl, 63);
+            const int r0 = (t0 + NT - 1) / NT, r1 = (t1 + NT - 1) / NT, r2 = (t2 + NT - 1) / NT, r3 = (t3 + NT - 1) / NT;
+            const int first = q == 0 ? 0 : (q == 1 ? r0 : (q == 2 ? r0 + r1 : r0 + r1 + r2));
+            const int mine = q == 0 ? r0 : (q == 1 ? r1 : (q == 2 ? r2 : r3));
+            ctl[32 + w * 4 + q] = first * NT + incl - c;                // exclusive prefix over waves
+            if (w == 0) {
+                ctl[q] = q == 0 ? t0 : (q == 1 ? t1 : (q == 2 ? t2 : t3));
+                ctl[8 + q] = first;                                     // first round of the quarter
+                ctl[12 + q] = first + mine;                             // one past its last round
             }
         }
         __syncthreads();
+        static_assert(QENTRIES * 4 <= QPIECE_BYTES, "piece = 6 x uint4 per thread");
+        uint4 pr0, pr1, pr2, pr3, pr4, pr5;
+        pr0 = pr1 = pr2 = pr3 = pr4 = pr5 = make_uint4(0, 0, 0, 0);
+#define LERF_PRE_LOAD(SRC)                                                                         \
+        do {                                                                                       \
+            const uint4* s_ = reinterpret_cast<const uint4*>(SRC) + (wave * 64 + lane);            \
+            pr0 = s_[0]; pr1 = s_[NT]; pr2 = s_[2 * NT]; pr3 = s_[3 * NT]; pr4 = s_[4 * NT]; pr5 = s_[5 * NT]; \
+        } while (0)
+        const uint8_t* s2q = P.pack + 3 * LUT_PAD;          // [LUT l][quarter q][QPIECE_BYTES], blocks pre-permuted
+        {
+            // first piece (LUT 0 of the first non-empty quarter): in flight during the scatter and the slot set-up
+            const int t0 = __builtin_amdgcn_readfirstlane(ctl[0]), t1 = __builtin_amdgcn_readfirstlane(ctl[1]),
+                      t2 = __builtin_amdgcn_readfirstlane(ctl[2]);
+            const int q0 = t0 > 0 ? 0 : (t1 > 0 ? 1 : (t2 > 0 ? 2 : 3));
+            LERF_PRE_LOAD(s2q + (size_t)q0 * QPIECE_BYTES);
+        }
         {
             int cur0 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 0]);
             int cur1 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 1]);
@@ -556,7 +577,6 @@ sr_fused_kernel(Params P) {
         __syncthreads();
 
         LERF_STAMP(7);
-        const uint32_t* s2 = reinterpret_cast<const uint32_t*>(P.pack + 3 * LUT_PAD);
         // phases = (non-empty quarter) x (6 LUTs).  The next piece is fetched into registers while the
         // current one is being used, so the L2 latency of the piece copies hides behind the lookups.
         int nph = 0;
@@ -578,14 +598,6 @@ sr_fused_kernel(Params P) {
         // address VGPR: 128 B/clk/CU against 79 for ds_write_b128).  addtid puts component c of all lanes at
         // block + 256 c + 4 L, so the pack holds every block pre-permuted (global dword 4L+c = logical dword 64c+L)
         // and LDS ends up in natural order.  M0 = the wave's block column; the 16-bit offset reaches 4 iterations.
-        static_assert(QENTRIES * 4 <= QPIECE_BYTES, "piece = 6 x uint4 per thread");
-        uint4 pr0, pr1, pr2, pr3, pr4, pr5;
-        pr0 = pr1 = pr2 = pr3 = pr4 = pr5 = make_uint4(0, 0, 0, 0);
-#define LERF_PRE_LOAD(SRC)                                                                         \
-        do {                                                                                       \
-            const uint4* s_ = reinterpret_cast<const uint4*>(SRC) + (wave * 64 + lane);            \
-            pr0 = s_[0]; pr1 = s_[NT]; pr2 = s_[2 * NT]; pr3 = s_[3 * NT]; pr4 = s_[4 * NT]; pr5 = s_[5 * NT]; \
-        } while (0)
 #define LERF_ADDTID(V, OFF) asm volatile("ds_write_addtid_b32 %0 offset:" #OFF :: "v"(V) : "memory")
 #define LERF_ADDTID4(R, OFF0, OFF1, OFF2, OFF3) \
         LERF_ADDTID(R.x, OFF0); LERF_ADDTID(R.y, OFF1); LERF_ADDTID(R.z, OFF2); LERF_ADDTID(R.w, OFF3)
@@ -602,8 +614,6 @@ sr_fused_kernel(Params P) {
             LERF_ADDTID4(pr5, 16384, 16640, 16896, 17152);                                         \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
         } while (0)
-        const uint8_t* s2q = P.pack + 3 * LUT_PAD;          // [LUT l][quarter q][QPIECE_BYTES], blocks pre-permuted
-        if (nph > 0) LERF_PRE_LOAD(s2q + (size_t)__builtin_amdgcn_readfirstlane(ctl[24]) * QPIECE_BYTES);
         for (int ph = 0; ph < nph; ++ph) {
             {
                 const int qi = ph / 6;
