@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="frames per step per GPU")
     ap.add_argument("--input", choices=["noise", "natural"], default="noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-input", action="store_true",
+                    help="skip the short secondary-distribution run (profiling: keeps the kernel trace to one workload)")
     ap.add_argument("--unfused", action="store_true", help="time the 3-launch direct path instead")
     ap.add_argument("--mode", choices=["frames", "strips"], default="frames",
                     help="frames: independent frames per GPU (weak scaling, default); strips: every frame is "
@@ -165,7 +167,7 @@ def main():
     # secondary distribution (same shapes), short run, rank 0 only
     other = "natural" if args.input == "noise" else "noise"
     other_mpix = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_other_input:
         xo = torch.from_numpy(np.ascontiguousarray(np.tile(host[other], (B // 2 + 1, 1, 1, 1))[:B])).cuda()
         step(xo, out)
         torch.cuda.synchronize()

@@ -208,6 +208,24 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
                      int kind, double max_sigma,
                      uint8_t* out, int64_t out_sn, void* workspace, void* stream);
 
+/* ---- evaluation metrics of the reference harness, on the device (uint8 HWC RGB, row pitch in elements).
+ * Each call leaves two doubles in `result` (device memory): a sum and a count; no host sync.
+ *
+ * lerf_metric_y_sse_u8: ingredients of PSNR(_rgb2ycbcr(gt)[:,:,0], _rgb2ycbcr(out)[:,:,0], shave)
+ *   (resample/eval_lut_sr.py:741-742, common/utils.py:46-76, 138-151): result[0] = sum over the frame minus a
+ *   `shave`-pixel border of (float32(Y_out) - float32(Y_gt))^2, result[1] = number of pixels summed.
+ * lerf_metric_ssim_y_u8: cal_ssim(y_gt, y_out) (eval_lut_sr.py:743, common/utils.py:177-206; 11x11 Gaussian
+ *   window sigma 1.5, 'valid', float64): result[0] = sum of the SSIM map, result[1] = (H-10)*(W-10).
+ * lerf_metric_masked_sse_u8: ingredients of mPSNR(sr, hr, mask) (resample/eval_lut_warp.py:233,
+ *   common/utils.py:168-175) over n = H*W*C elements: result[0] = sum (mask*(sr-hr)/255)^2 in float32 steps,
+ *   result[1] = sum(mask); mask is 0 / non-zero bytes. */
+int lerf_metric_y_sse_u8(const uint8_t* gt, int64_t gt_sy, const uint8_t* out, int64_t out_sy, int H, int W, int shave,
+                         double* result, void* stream);
+int lerf_metric_ssim_y_u8(const uint8_t* gt, int64_t gt_sy, const uint8_t* out, int64_t out_sy, int H, int W,
+                          double* result, void* stream);
+int lerf_metric_masked_sse_u8(const uint8_t* sr, const uint8_t* hr, const uint8_t* mask, int64_t n, double* result,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

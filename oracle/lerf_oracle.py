@@ -437,6 +437,38 @@ def psnr_y(gt_u8, out_u8, shave):
     return float(20 * np.log10(255.0 / rmse))
 
 
+def ssim_y(gt_u8, out_u8):
+    """cal_ssim on the Y planes (eval_lut_sr.py:735-743, common/utils.py:177-206): 11x11 Gaussian window
+    (cv2.getGaussianKernel(11, 1.5)), 'valid' 2-D convolution, float64; mean of the SSIM map."""
+    if gt_u8.shape != out_u8.shape:
+        ph, pw = out_u8.shape[:2]
+        gt_u8 = gt_u8[:ph, :pw]
+        gh, gw = gt_u8.shape[:2]
+        out_u8 = out_u8[:gh, :gw]
+    x = np.arange(11) - 5.0
+    k = np.exp(-(x * x) / (2 * 1.5 * 1.5))
+    k = k / k.sum()
+    win = np.outer(k, k)
+
+    def conv_valid(a):
+        H, W = a.shape
+        o = np.zeros((H - 10, W - 10))
+        for i in range(11):
+            for j in range(11):
+                o += win[i, j] * a[i:i + H - 10, j:j + W - 10]
+        return o
+
+    a = np.float64(rgb2y(gt_u8))
+    b = np.float64(rgb2y(out_u8))
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    mu1, mu2 = conv_valid(a), conv_valid(b)
+    s11 = conv_valid(a * a) - mu1 * mu1
+    s22 = conv_valid(b * b) - mu2 * mu2
+    s12 = conv_valid(a * b) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+    return float(np.mean(m))
+
+
 def mpsnr(sr_u8, hr_u8, mask):
     """common/utils.py:168-175 (float32 tensors in the reference)."""
     sr = sr_u8.astype(np.float32)

@@ -52,7 +52,7 @@ warnings.filterwarnings("ignore")
 
 import torch  # noqa: E402
 from PIL import Image  # noqa: E402
-from common.utils import PSNR, _rgb2ycbcr, mPSNR  # noqa: E402
+from common.utils import PSNR, _rgb2ycbcr, cal_ssim, mPSNR  # noqa: E402
 from resample.eval_lut_sr import FourSimplexInterpFaster, mode_pad_dict  # noqa: E402
 from resize_right.resize_right2d_numpy import (  # noqa: E402
     AmplifiedLinearResize2dNumpy, AmplifiedLinearWarp2dNumpy, NearestWarp2dNumpy,
@@ -176,8 +176,8 @@ def g23_sr():
 
 def g4_warp():
     out = {}
-    lr = {p: np.array(Image.open(os.path.join(DATA, "warp", p, "woman.png"))) for p in ("isc", "osc")}
-    mats = {p: torch.load(os.path.join(DATA, "warp", p, "woman.pth")).numpy() for p in ("isc", "osc")}
+    lr = {p: np.array(Image.open(os.path.join(DATA, p, "woman.png"))) for p in ("isc", "osc")}
+    mats = {p: torch.load(os.path.join(DATA, p, "woman.pth")).numpy() for p in ("isc", "osc")}
     for p in ("isc", "osc"):
         out["%s/matrix" % p] = mats[p]
         img = lr[p]
@@ -270,9 +270,9 @@ def g5_set5():
                 print(model, scale, n, ps)
         for p in ("isc", "osc"):
             for n in names:
-                lr = np.array(Image.open(os.path.join(DATA, "warp", p, n + ".png")))
+                lr = np.array(Image.open(os.path.join(DATA, p, n + ".png")))
                 gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
-                M = torch.load(os.path.join(DATA, "warp", p, n + ".pth")).numpy()
+                M = torch.load(os.path.join(DATA, p, n + ".pth")).numpy()
                 feat, hq, hyper = ref_stages(lr, lutDict, oC)
                 img_lr = feat.transpose((2, 0, 1))
                 gtc = gt.transpose((2, 0, 1))
@@ -301,6 +301,43 @@ def g5_set5():
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def g8_ssim():
+    """cal_ssim (common/utils.py:177) of the reference on the Set5 SR outputs.  The outputs are produced by the
+    C port of the oracle and accepted only if their md5 equals the md5 of the reference's own output recorded in
+    g5_set5.json (running the reference's numpy LUT stages again would take an hour); the metric itself is the
+    reference function, with cv2.getGaussianKernel replaced by the 3-line numpy stand-in above (cv2 is absent here;
+    SURVEY.md 8c: reproduces the published SSIM column to 4 decimals)."""
+    sys.path.insert(0, REPO)
+    from oracle import c_oracle, lerf_oracle
+    g5 = json.load(open(os.path.join(OUT, "g5_set5.json")))["sr"]
+    res = {}
+    names = ["baby", "bird", "butterfly", "head", "woman"]
+    for model, linear in (("lerf-g", False), ("lerf-l", True)):
+        luts = lerf_oracle.load_luts(os.path.join(ASSETS, model), linear=linear)
+        for scale in (2, 3, 4):
+            vals = []
+            for n in names:
+                lr = np.array(Image.open(os.path.join(DATA, "LR_bicubic/rrLR_X%.2f_%.2f" % (scale, scale), n + ".png")))
+                gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+                o8 = c_oracle.sr_u8(lr, luts, scale, scale, linear=linear)
+                assert md5(o8) == g5["%s/x%d/%s" % (model, scale, n)]["md5_out"], (model, scale, n)
+                g = gt
+                if g.shape != o8.shape:
+                    ph, pw, _ = o8.shape
+                    g = g[:ph, :pw, :]
+                    gh, gw, _ = g.shape
+                    o8 = o8[:gh, :gw, :]
+                y_gt, y_out = _rgb2ycbcr(g)[:, :, 0], _rgb2ycbcr(o8)[:, :, 0]
+                ss = float(cal_ssim(y_gt, y_out))
+                ps = float(PSNR(y_gt, y_out, scale))
+                res["%s/x%d/%s" % (model, scale, n)] = {"ssim": ss, "psnr_y": ps}
+                vals.append((ps, ss))
+            res["%s/x%d/mean" % (model, scale)] = "%.2f/%.4f" % tuple(np.mean(np.array(vals), axis=0))
+            print(model, scale, res["%s/x%d/mean" % (model, scale)])
+    with open(os.path.join(OUT, "g8_ssim.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -320,7 +357,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -333,3 +370,5 @@ if __name__ == "__main__":
         g7_fixed_warp()
     if "g5" in which:
         g5_set5()
+    if "g8" in which:
+        g8_ssim()

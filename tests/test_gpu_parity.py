@@ -261,7 +261,7 @@ def test_set5_warp_md5_and_mpsnr(oracle, luts_g, luts_l, eng_g, eng_l, model, p)
     ms = []
     for n in SET5:
         r = ref["%s/%s/%s" % (model, p, n)]
-        lr = np.array(Image.open(os.path.join(DATA, "warp", p, n + ".png")))
+        lr = np.array(Image.open(os.path.join(DATA, p, n + ".png")))
         gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
         o8, mask = eng.warp(lr, np.array(r["matrix"]), gt.shape[:2])
         assert int(mask.sum()) == r["mask_sum"] and _md5(mask.astype(np.uint8)) == r["md5_mask"]
@@ -389,7 +389,7 @@ def test_warp_packed_equals_direct_warp(torch, eng_g, p):
     from lerf_pytorch_amd import ops
     ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["warp"]
     r = ref["lerf-g/%s/woman" % p]
-    lr = torch.from_numpy(np.array(Image.open(os.path.join(DATA, "warp", p, "woman.png")))).cuda()
+    lr = torch.from_numpy(np.array(Image.open(os.path.join(DATA, p, "woman.png")))).cuda()
     geo = ops.WarpGeometry(lr.shape[:2], np.array(r["matrix"]), (344, 228), 2)
     feat, hq = ops.lut_stages(lr, eng_g.luts)
     a = ops.warp_hwc_u8(feat, hq, geo, "gauss", 10.0, out="f32")

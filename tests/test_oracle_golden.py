@@ -141,7 +141,7 @@ def test_set5_warp_known_answers(oracle, luts_g, p):
     ms = []
     for n in SET5:
         r = ref["lerf-g/%s/%s" % (p, n)]
-        lr = np.array(Image.open(os.path.join(DATA, "warp", p, n + ".png")))
+        lr = np.array(Image.open(os.path.join(DATA, p, n + ".png")))
         gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
         M = np.array(r["matrix"])
         o8 = oracle.warp_pipeline(lr, luts_g, M, gt.shape[:2])
@@ -162,3 +162,22 @@ def test_fixed_kernel_warps(oracle, golden, p, kind, S):
     feat = g4["%s/feat" % p].astype(np.float32)
     out = oracle.warp_params_f32(feat, None, None, None, g4["%s/matrix" % p], (60, 70), S, 1, kind)
     np.testing.assert_allclose(out, g7["%s/%s" % (p, kind)], rtol=0, atol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("model,scale", [("lerf-g", 4), ("lerf-l", 3)])
+def test_ssim_known_answers(oracle, luts_g, luts_l, model, scale):
+    """cal_ssim of the reference (g8_ssim.json) on the md5-pinned Set5 outputs; and the published SSIM column."""
+    from oracle import c_oracle
+    ref = json.load(open(os.path.join(GOLDEN, "g8_ssim.json")))
+    luts, linear = (luts_g, False) if model == "lerf-g" else (luts_l, True)
+    for n in ("butterfly", "woman"):
+        lr = np.array(Image.open(os.path.join(DATA, "LR_bicubic/rrLR_X%.2f_%.2f" % (scale, scale), n + ".png")))
+        gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+        o8 = c_oracle.sr_u8(lr, luts, scale, scale, linear=linear)
+        r = ref["%s/x%d/%s" % (model, scale, n)]
+        assert abs(oracle.ssim_y(gt, o8) - r["ssim"]) < 1e-9
+        assert abs(oracle.psnr_y(gt, o8, scale) - r["psnr_y"]) < 1e-4
+    published = {"lerf-g": ["35.71/0.9475", "32.02/0.8980", "30.15/0.8548"],        # scripts.sh:36-41
+                 "lerf-l": ["34.84/0.9432", "30.72/0.8773", "29.13/0.8270"]}
+    for m in published:
+        assert [ref["%s/x%d/mean" % (m, s)] for s in (2, 3, 4)] == published[m]

@@ -50,7 +50,7 @@ def main():
         for p in ("isc", "osc"):
             ms = []
             for n in NAMES:
-                lr = np.array(Image.open(os.path.join(DATA, "warp", p, n + ".png")))
+                lr = np.array(Image.open(os.path.join(DATA, p, n + ".png")))
                 gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
                 o, mask = eng.warp(lr, np.array(mats["%s/%s/%s" % (model, p, n)]["matrix"]), gt.shape[:2])
                 ms.append(mpsnr(o, gt, mask))

@@ -8,7 +8,7 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 ks = glob.glob(src + "/stats/*/*kernel_stats.csv")[0]
 shutil.copy(ks, os.path.join(dst, label + "_kernel_stats.csv"))
-out = ["rocprofv3 PMC summary (%s), fused kernel sr_fused_kernel<2,0,false>, command: bench.py --steps 5 --warmup 1 --no-cpu-baseline" % label,
+out = ["rocprofv3 PMC summary (%s), fused kernel sr_fused_kernel<2,0,false>, command: bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input" % label,
        "(8 frames 1920x1080->3840x2160 per launch, uniform-noise input; one --pmc pass per counter group; mean over the launches of a run)"]
 vals = {}
 for d in sorted(glob.glob(src + "/pmc_*/")):
