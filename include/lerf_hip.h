@@ -169,7 +169,10 @@ int lerf_lut_stages_u8(const lerf_plane_t* img, int H, int W, int C,
  * (resize_right/resize_right2d_torch.py:154-197, 214-247).
  * feat: uint8 or float32.  hyper[k]: uint8 numerators (h = u8/255) or float32
  * maps in [0,1]; k = rho, sigma_x, sigma_y (gauss) or alpha (linear).
- * out: uint8 (clip(rne)), float32 or float64 (float64 arithmetic). */
+ * out: uint8 (clip(rne)), float32 or float64 (float64 arithmetic).
+ * kind NEAREST / CUBIC / BILINEAR / LANCZOS2 / LANCZOS3: the fixed-kernel resize of Resize2dTorch.resize +
+ * BicubicResize2dTorch (resize_right2d_torch.py:105-138, interp_methods.py:35-95) on the same geometry;
+ * `hyper` is ignored (may be NULL). */
 int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
                 int H, int W, int C, const lerf_sr_geo_t* geo,
                 int kind, double max_sigma, const lerf_mplane_t* out, void* stream);

@@ -193,9 +193,10 @@ int lerf_lut_stages_u8(const lerf_plane_t* img, int H, int W, int C, const lerf_
 
 int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int W, int C, const lerf_sr_geo_t* geo,
                 int kind, double max_sigma, const lerf_mplane_t* out, void* stream) {
-    if (!plane_ok(feat) || !hyper || !geo || !out || !out->ptr || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
-    int nh = kind == LERF_KIND_GAUSS ? 3 : (kind == LERF_KIND_LINEAR ? 1 : 0);
-    if (nh == 0) return LERF_EUNSUPPORTED;
+    if (!plane_ok(feat) || !geo || !out || !out->ptr || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    if (kind < LERF_KIND_GAUSS || kind > LERF_KIND_LANCZOS3) return LERF_EUNSUPPORTED;
+    int nh = kind == LERF_KIND_GAUSS ? 3 : (kind == LERF_KIND_LINEAR ? 1 : 0);   // fixed kernels take no hyper maps
+    if (nh > 0 && !hyper) return LERF_EINVAL;
     for (int k = 0; k < nh; ++k)
         if (!hyper[k].ptr || hyper[k].dtype != hyper[0].dtype || hyper[k].sy != hyper[0].sy ||
             hyper[k].sx != hyper[0].sx || hyper[k].sc != hyper[0].sc)
@@ -203,8 +204,8 @@ int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, in
     if (!geo->left_r || !geo->left_c || geo->out_h < 1 || geo->out_w < 1) return LERF_EINVAL;
     ResizeArgs a{};
     a.feat = feat->ptr; a.in_dtype = feat->dtype; a.fy = feat->sy; a.fx = feat->sx; a.fc = feat->sc;
-    for (int k = 0; k < 3; ++k) a.h[k] = k < nh ? hyper[k].ptr : hyper[0].ptr;
-    a.h_dtype = hyper[0].dtype; a.hy = hyper[0].sy; a.hx = hyper[0].sx; a.hc = hyper[0].sc;
+    for (int k = 0; k < 3; ++k) a.h[k] = nh == 0 ? nullptr : (k < nh ? hyper[k].ptr : hyper[0].ptr);
+    if (nh > 0) { a.h_dtype = hyper[0].dtype; a.hy = hyper[0].sy; a.hx = hyper[0].sx; a.hc = hyper[0].sc; }
     a.H = H; a.W = W; a.C = C; a.S = geo->S; a.oH = geo->out_h; a.oW = geo->out_w;
     a.left_r = geo->left_r; a.dis_r = geo->dis_r; a.left_c = geo->left_c; a.dis_c = geo->dis_c;
     a.dis_r64 = geo->dis_r64; a.dis_c64 = geo->dis_c64;

@@ -370,8 +370,11 @@ static int resize_dispatch_kind(const ResizeArgs& a, hipStream_t st) {
     return LERF_EUNSUPPORTED;
 }
 
+static int launch_resize_fixed(const ResizeArgs& a, hipStream_t st);
+
 int launch_resize(const ResizeArgs& a, hipStream_t st) {
     if (a.S < 1 || a.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
+    if (a.kind >= LERF_KIND_NEAREST && a.kind <= LERF_KIND_LANCZOS3) return launch_resize_fixed(a, st);
     if (a.in_dtype == LERF_U8 && a.h_dtype == LERF_U8) {
         if (a.out_dtype == LERF_U8) return resize_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
         if (a.out_dtype == LERF_F32) return resize_dispatch_kind<uint8_t, uint8_t, float, float>(a, st);
@@ -401,6 +404,67 @@ __device__ __forceinline__ double fixed_kernel_1d(int kind, double x) {
     if (kind == LERF_KIND_BILINEAR)                                       // :60-64
         return (x + 1.0) * ((-1.0 <= x && x < 0.0) ? 1.0 : 0.0) + (1.0 - x) * ((0.0 <= x && x <= 1.0) ? 1.0 : 0.0);
     return ((-1.0 <= x && x < 0.0) ? 1.0 : 0.0) + ((0.0 <= x && x <= 1.0) ? 1.0 : 0.0);   // box :67-70
+}
+
+// ---------------------------------------------------------------------------
+// Fixed-kernel SR: Resize2dTorch.resize + BicubicResize2dTorch (resize_right2d_torch.py:105-138)
+// and its bilinear / lanczos / box siblings on the separable SR geometry.  weight(dx, dy) = k(dx) k(dy), normalised
+// over the S x S patch (the sum factorises into a row sum times a column sum); zero-padded image; S = 1 is not
+// normalised (:119-121).
+// ---------------------------------------------------------------------------
+template <typename TI, typename TO, typename A>
+__global__ void __launch_bounds__(256)
+resize_fixed_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc, int H, int W, int C, int S, int oH, int oW,
+                    const int* __restrict__ left_r, const A* __restrict__ dis_r, const int* __restrict__ left_c,
+                    const A* __restrict__ dis_c, int kind, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+    int xc = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (xc >= oW * C) return;
+    int j = xc / C;
+    int c = xc - j * C;
+    const int lr = left_r[i], lc = left_c[j];
+    A kr[LERF_MAX_SUPPORT], kc[LERF_MAX_SUPPORT], sr = 0, sc = 0;
+    for (int b = 0; b < S; ++b) {
+        kr[b] = (A)fixed_kernel_1d(kind, (double)dis_r[i * S + b]);
+        kc[b] = (A)fixed_kernel_1d(kind, (double)dis_c[j * S + b]);
+        sr += kr[b];
+        sc += kc[b];
+    }
+    A num = 0;
+    for (int a = 0; a < S; ++a) {
+        const int cc = lc + a;
+        if (cc < 0 || cc >= W) continue;
+        A row = 0;
+        for (int b = 0; b < S; ++b) {
+            const int rr = lr + b;
+            if (rr >= 0 && rr < H) row += kr[b] * (A)Loader<TI>::pixel(feat + rr * fy + cc * fx + c * fc);
+        }
+        num += kc[a] * row;
+    }
+    Storer<TO>::put(out + i * oy + j * ox + c * oc, S == 1 ? num : num / (sr * sc));
+}
+
+template <typename TI, typename TO, typename A>
+static int resize_fixed_launch(const ResizeArgs& a, hipStream_t st) {
+    dim3 block(256), grid((a.oW * a.C + 255) / 256, a.oH);
+    const A* dr = sizeof(A) == 4 ? (const A*)a.dis_r : (const A*)a.dis_r64;
+    const A* dc = sizeof(A) == 4 ? (const A*)a.dis_c : (const A*)a.dis_c64;
+    if (!dr || !dc) return LERF_EINVAL;
+    hipLaunchKernelGGL((resize_fixed_kernel<TI, TO, A>), grid, block, 0, st, (const TI*)a.feat, a.fy, a.fx, a.fc, a.H, a.W, a.C,
+                       a.S, a.oH, a.oW, a.left_r, dr, a.left_c, dc, a.kind, (TO*)a.out, a.oy, a.ox, a.oc);
+    return LERF_OK;
+}
+
+static int launch_resize_fixed(const ResizeArgs& a, hipStream_t st) {
+    if (a.in_dtype == LERF_U8) {
+        if (a.out_dtype == LERF_U8) return resize_fixed_launch<uint8_t, uint8_t, float>(a, st);
+        if (a.out_dtype == LERF_F32) return resize_fixed_launch<uint8_t, float, float>(a, st);
+        if (a.out_dtype == LERF_F64) return resize_fixed_launch<uint8_t, double, double>(a, st);
+    } else if (a.in_dtype == LERF_F32) {
+        if (a.out_dtype == LERF_F32) return resize_fixed_launch<float, float, float>(a, st);
+        if (a.out_dtype == LERF_F64) return resize_fixed_launch<float, double, double>(a, st);
+    }
+    return LERF_EUNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------

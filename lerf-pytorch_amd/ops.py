@@ -209,14 +209,17 @@ def resize_hwc_u8(feat_u8, hq_u8, geo: SrGeometry, kind="gauss", max_sigma=10.0,
     """stage 3 on the uint8 stage outputs: feat [H,W,C], hq [H,W,C,oC] -> [oH,oW,C]."""
     torch = _torch()
     feat = feat_u8.contiguous()
-    hq = hq_u8.contiguous()
     H, W, Cn = feat.shape
-    nh = 3 if kind == "gauss" else 1
-    if hq.shape[:3] != feat.shape or hq.shape[3] < nh:
-        raise ValueError("hyper shape mismatch")
+    nh = {"gauss": 3, "linear": 1}.get(kind, 0)          # fixed kernels (cubic, bilinear, ...) take no hyper maps
     o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=feat.device)
     pf = _planes_hwc(feat)
-    ph, _keep = _hyper_planes(hq, "hwck", nh)
+    if nh:
+        hq = hq_u8.contiguous()
+        if hq.shape[:3] != feat.shape or hq.shape[3] < nh:
+            raise ValueError("hyper shape mismatch")
+        ph, _keep = _hyper_planes(hq, "hwck", nh)
+    else:
+        ph = None
     po = _planes_hwc(o)
     _lib.check(_lib.lib().lerf_resize(C.byref(pf), ph, H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
                                       C.byref(po), _lib.current_stream()), "lerf_resize")
@@ -227,15 +230,18 @@ def resize_planar(feat, hypers, geo: SrGeometry, kind="gauss", max_sigma=10.0, o
     """stage 3 on planar float32 maps: feat [N,H,W], hypers = list of [N,H,W] in [0,1] -> [N,oH,oW]."""
     torch = _torch()
     feat = feat.contiguous().float()
-    nh = 3 if kind == "gauss" else 1
-    hypers = [h.contiguous().float() for h in hypers[:nh]]
-    for h in hypers:
-        if h.shape != feat.shape:
-            raise ValueError("hyper maps must have the shape of the input")
+    nh = {"gauss": 3, "linear": 1}.get(kind, 0)
     N, H, W = feat.shape
     o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
     pf = _planes_chw(feat)
-    ph, _keep = _hyper_planes(hypers, "planar", nh)
+    if nh:
+        hypers = [h.contiguous().float() for h in hypers[:nh]]
+        for h in hypers:
+            if h.shape != feat.shape:
+                raise ValueError("hyper maps must have the shape of the input")
+        ph, _keep = _hyper_planes(hypers, "planar", nh)
+    else:
+        ph = None
     po = _planes_chw(o)
     _lib.check(_lib.lib().lerf_resize(C.byref(pf), ph, H, W, N, geo.ref(), KINDS[kind], float(max_sigma),
                                       C.byref(po), _lib.current_stream()), "lerf_resize")

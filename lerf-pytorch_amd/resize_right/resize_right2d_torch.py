@@ -68,6 +68,43 @@ class Resize2dTorch(object):
         return out.reshape(B, Cn, self.geo.out_hw[0], self.geo.out_hw[1])
 
 
+    kind = None                                                # fixed-kernel subclasses name their interp_methods kernel
+
+    def resize(self, input):
+        """default interpolation process (:105-129): weight(dis_x, dis_y) normalised over the patch."""
+        if self.kind is None:
+            raise NotImplementedError("Resize2dTorch.resize needs a subclass with a weight kernel")
+        return self._run(self.kind, input, [], 1.0)
+
+
+class BicubicResize2dTorch(Resize2dTorch):                     # :131-138, interp_methods.cubic2d
+    kind = "cubic"
+
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+
+class BilinearResize2dTorch(Resize2dTorch):                    # interp_methods.linear2d on the same base class
+    kind = "bilinear"
+
+    def __init__(self, support_sz=2, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+
+class Lanczos2Resize2dTorch(Resize2dTorch):                    # interp_methods.lanczos2d
+    kind = "lanczos2"
+
+    def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+
+class Lanczos3Resize2dTorch(Resize2dTorch):                    # interp_methods.lanczos3d
+    kind = "lanczos3"
+
+    def __init__(self, support_sz=6, device="CPU", pad_mode="constant"):
+        super().__init__(support_sz, device, pad_mode)
+
+
 class SteeringGaussianResize2dTorch(Resize2dTorch):
     def __init__(self, support_sz=4, device="GPU", pad_mode="constant", max_sigma=10):
         super().__init__(support_sz, device, pad_mode)

@@ -224,9 +224,10 @@ def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss")
         rho = np.asarray(p0, np.float32) * 2 - 1
         sx = np.asarray(p1, np.float32) * max_sigma
         sy = np.asarray(p2, np.float32) * max_sigma
-    else:
+    elif kind == "linear":
         alpha = (np.asarray(p0, np.float32) * 2 - 1)
         alpha = max_sigma * alpha
+    # else: fixed kernel of interp_methods.py (Resize2dTorch.resize, resize_right2d_torch.py:105-138), no hyper maps
     num = np.zeros((C, oH, oW), np.float64)
     den = np.zeros((C, oH, oW), np.float64)
     # summation order of the reference: column offset major, row offset minor
@@ -243,8 +244,10 @@ def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss")
             if kind == "gauss":
                 w = _gauss_w(rho[:, rcl][:, :, ccl], sx[:, rcl][:, :, ccl],
                              sy[:, rcl][:, :, ccl], dx[None], dy[None])
-            else:
+            elif kind == "linear":
                 w = _lin_w(alpha[:, rcl][:, :, ccl], dx[None], dy[None])
+            else:
+                w = (fixed_kernel(kind, dx) * fixed_kernel(kind, dy))[None]
             val = feat[:, rcl][:, :, ccl].astype(np.float64) * inside[None]
             num += w * val
             den += w

@@ -57,7 +57,7 @@ from resample.eval_lut_sr import FourSimplexInterpFaster, mode_pad_dict  # noqa:
 from resize_right.resize_right2d_numpy import (  # noqa: E402
     AmplifiedLinearResize2dNumpy, AmplifiedLinearWarp2dNumpy, NearestWarp2dNumpy,
     SteeringGaussianResize2dNumpy, SteeringGaussianWarp2dNumpy)
-from resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch  # noqa: E402
+from resize_right.resize_right2d_torch import BicubicResize2dTorch, SteeringGaussianResize2dTorch  # noqa: E402
 
 
 def load_lutdict(model, oC):
@@ -338,6 +338,25 @@ def g8_ssim():
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def g9_bicubic_resize():
+    """BicubicResize2dTorch (resize_right2d_torch.py:131-138) on the CPU, float32.  As shipped the class cannot run
+    (Resize2dTorch.resize uses an attribute `out_sz` that nothing assigns); the generator assigns it on the
+    instance, which is the evident intent (out_shape[2:])."""
+    out = {}
+    for ci, (B, Cn, H, W, s) in enumerate([(2, 1, 24, 20, 2), (1, 3, 12, 16, 4), (1, 1, 20, 18, 2.5), (1, 2, 17, 23, 3), (1, 1, 9, 7, [1.5, 2])]):
+        rng = np.random.default_rng(900 + ci)
+        x = rng.integers(0, 256, (B, Cn, H, W)).astype(np.float32)
+        r = BicubicResize2dTorch(support_sz=4, device="cpu")
+        r.set_shape([B, Cn, H, W], scale_factors=s if isinstance(s, list) else [s, s])
+        r.out_sz = r.out_shape[2:]      # the base-class resize reads self.out_sz, which set_shape never sets (:114)
+        o = r.resize(torch.tensor(x))
+        out["%d/x" % ci] = x.astype(np.uint8)
+        out["%d/out" % ci] = o.numpy()
+        out["%d/scale" % ci] = np.array(s if isinstance(s, list) else [s, s], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g9_bicubic_resize.npz"), **out)
+    print("G9", len(out))
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -357,7 +376,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -372,3 +391,5 @@ if __name__ == "__main__":
         g5_set5()
     if "g8" in which:
         g8_ssim()
+    if "g9" in which:
+        g9_bicubic_resize()

@@ -434,3 +434,51 @@ def test_fixed_kernel_warp_classes_vs_golden(golden, p):
         w.set_shape([3, 52, 52], g4["%s/matrix" % p], [3, 60, 70])
         assert [w.pad_vec[1][0], w.pad_vec[1][1], w.pad_vec[2][0], w.pad_vec[2][1]] == list(g7["%s/%s/pad" % (p, name)])
         np.testing.assert_allclose(w.warp(feat), g7["%s/%s" % (p, name)], rtol=0, atol=1e-9, equal_nan=True)
+
+
+# ---------------------------------------------------------------- fixed-kernel SR
+@pytest.mark.parametrize("kind,S", [("cubic", 4), ("bilinear", 2), ("lanczos2", 4), ("lanczos3", 6)])
+@pytest.mark.parametrize("shape,scale", [((3, 24, 20), (2, 2)), ((2, 17, 23), (3, 3)), ((1, 9, 7), (1.5, 2.4))])
+def test_fixed_kernel_resize_vs_oracle(torch, oracle, kind, S, shape, scale):
+    from lerf_pytorch_amd import ops
+    rng = np.random.default_rng(S * 100 + shape[1])
+    x = rng.integers(0, 256, shape).astype(np.float32)
+    ref = oracle.resize_params_f32(x, None, None, None, scale[0], scale[1], S, 1, kind)
+    geo = ops.SrGeometry(shape[1:], list(scale), None, S)
+    xt = torch.from_numpy(x).cuda()
+    o64 = ops.resize_planar(xt, [], geo, kind, 1.0, out="f64").cpu().numpy()
+    assert np.max(np.abs(o64 - ref)) <= 1e-9
+    o32 = ops.resize_planar(xt, [], geo, kind, 1.0, out="f32").cpu().numpy()
+    assert np.max(np.abs(o32 - ref)) <= F32_OBSERVED
+    # uint8 HWC frames in and out
+    x8 = torch.from_numpy(np.ascontiguousarray(x.astype(np.uint8).transpose(1, 2, 0))).cuda()
+    o8 = ops.resize_hwc_u8(x8, None, geo, kind, 1.0, out="u8").cpu().numpy().transpose(2, 0, 1)
+    want = np.clip(np.round(ref), 0, 255)
+    near_tie = np.abs(ref - np.floor(ref) - 0.5) < 1e-3
+    assert np.all((o8 == want) | near_tie)
+    assert np.max(np.abs(o8.astype(int) - want)) <= 1
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_bicubic_resize2d_torch_class(torch, golden, oracle, ci):
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import BicubicResize2dTorch
+    g = golden("g9_bicubic_resize.npz")
+    x = g["%d/x" % ci].astype(np.float32)
+    s = [float(v) for v in g["%d/scale" % ci]]
+    r = BicubicResize2dTorch(support_sz=4, device=torch.device("cuda"))
+    r.set_shape(list(x.shape), scale_factors=s)
+    o = r.resize(torch.from_numpy(x).cuda())
+    ref = g["%d/out" % ci]
+    assert list(o.shape) == list(ref.shape) and o.dtype == torch.float32
+    assert np.max(np.abs(o.cpu().numpy() - ref)) <= 2e-3            # the reference itself is float32 end to end
+    B, C, H, W = x.shape
+    f64 = oracle.resize_params_f32(x.reshape(B * C, H, W), None, None, None, s[0], s[1], 4, 1, "cubic").reshape(ref.shape)
+    assert np.max(np.abs(o.cpu().numpy() - f64)) <= F32_OBSERVED
+
+
+def test_resize2d_torch_base_class_needs_a_kernel(torch):
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import Resize2dTorch
+    r = Resize2dTorch()
+    r.set_shape([1, 1, 8, 8], scale_factors=2)
+    with pytest.raises(NotImplementedError):
+        r.resize(torch.zeros(1, 1, 8, 8, device="cuda"))

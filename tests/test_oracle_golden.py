@@ -181,3 +181,16 @@ def test_ssim_known_answers(oracle, luts_g, luts_l, model, scale):
                  "lerf-l": ["34.84/0.9432", "30.72/0.8773", "29.13/0.8270"]}
     for m in published:
         assert [ref["%s/x%d/mean" % (m, s)] for s in (2, 3, 4)] == published[m]
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_bicubic_resize_torch_golden(oracle, golden, ci):
+    """BicubicResize2dTorch of the reference (float32 geometry and arithmetic) vs the float64 restatement."""
+    g = golden("g9_bicubic_resize.npz")
+    x = g["%d/x" % ci].astype(np.float32)
+    s = g["%d/scale" % ci]
+    B, C, H, W = x.shape
+    o = oracle.resize_params_f32(x.reshape(B * C, H, W), None, None, None, s[0], s[1], 4, 1, "cubic")
+    ref = g["%d/out" % ci]
+    assert o.reshape(ref.shape).shape == ref.shape
+    assert np.max(np.abs(o.reshape(ref.shape) - ref)) <= 2e-3

@@ -36,5 +36,11 @@ for kind in ("noise", "natural"):
         dt = timeit(lambda: eng.warp(f, np.array(M), (2160, 3840), return_mask=False), n=5)
         o, mask = eng.warp(f, np.array(M), (2160, 3840))
         res.append(("warp lerf-g %s %s (valid %.0f%%)" % (name, kind, 100 * float(mask.float().mean())), 2160 * 3840 / dt / 1e6, dt * 1e3))
+# fixed-kernel baselines on the same 1080p -> 4K uint8 frames ("as fast as interpolation", README.md:45)
+x = torch.from_numpy(bench.synth_frames("noise", 1, 5)).cuda()[0]
+for kind, S in (("bilinear", 2), ("cubic", 4), ("lanczos3", 6)):
+    geo = ops.SrGeometry((bench.H, bench.W), [2.0, 2.0], None, S)
+    dt = timeit(lambda: ops.resize_hwc_u8(x, None, geo, kind, 1.0, out="u8"))
+    res.append(("fixed-kernel %s S=%d x2.0/2.0 noise (direct kernel)" % (kind, S), geo.out_hw[0] * geo.out_hw[1] / dt / 1e6, dt * 1e3))
 for name, mp, ms in res:
     print("%-58s %10.1f Mpix/s   %.3f ms/frame" % (name, mp, ms))
