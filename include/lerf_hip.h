@@ -229,6 +229,21 @@ int lerf_metric_ssim_y_u8(const uint8_t* gt, int64_t gt_sy, const uint8_t* out, 
 int lerf_metric_masked_sse_u8(const uint8_t* sr, const uint8_t* hr, const uint8_t* mask, int64_t n, double* result,
                               void* stream);
 
+/* ---- fine-tuning path: the trainable float32 twin of the LUT pass, SWF2LUT.InterpTorchBatch
+ * (resample/model.py:172-385), forward and backward.
+ * weight: float32 [17^4][oC] LUT parameters (LUT value = clamp(rne(127 w), -127, 127), :177-179);
+ * img: float32 [n_planes][h+bd][w+bd], integer-valued 0..255, already rotated and replicate-padded by the caller
+ * (SWF2LUT.predict, :398-431), n_planes = B*C; out / grad_out: float32 [n_planes][oC][h][w]  (= [B][C*oC][h][w]).
+ * mode: one of "sdyct"; modes c and t read their LSBs at the 'y' pattern pixels exactly like the reference
+ * (:229-232, :240-243).  bd >= the pattern reach (mode_pad_dict: s 1, d 2, y 2, c 3, t 3).
+ * Backward = what autograd derives for the reference code: grad_weight (accumulated with float atomics INTO the
+ * caller's buffer, so zero it or pass the running .grad) and grad_img (same; through the LSB terms only).  Either
+ * gradient pointer may be NULL. */
+int lerf_swf2lut_interp_f32(const float* weight, int oC, char mode, const float* img, int n_planes, int h, int w, int bd,
+                            float* out, void* stream);
+int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const float* img, const float* grad_out,
+                                int n_planes, int h, int w, int bd, float* grad_weight, float* grad_img, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,7 @@ EXPORTS = [
     "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_u8",
     "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed",
     "lerf_metric_y_sse_u8", "lerf_metric_ssim_y_u8", "lerf_metric_masked_sse_u8",
+    "lerf_swf2lut_interp_f32", "lerf_swf2lut_interp_bwd_f32",
 ]
 
 
@@ -113,6 +114,10 @@ def lib():
                                        C.c_void_p, C.c_void_p]
     L.lerf_metric_ssim_y_u8.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lerf_metric_masked_sse_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.lerf_swf2lut_interp_f32.argtypes = [C.c_void_p, C.c_int, C.c_char, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p]
+    L.lerf_swf2lut_interp_bwd_f32.argtypes = [C.c_void_p, C.c_int, C.c_char, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:          # AttributeError here = the .so does not match include/lerf_hip.h
         getattr(L, name)
     if L.lerf_abi_version() != 1:

@@ -1,0 +1,142 @@
+"""The trainable LUT model of the reference, on the MI355X path: mirror of `SWF2LUT` in resample/model.py:130-431
+(`InterpTorchBatch`, `forward`, `predict`) -- LUT fine-tuning, scripts.sh:28-30.
+
+The LUT pass runs in liblerf_hip.so (lerf_swf2lut_interp_f32 / _bwd_f32) behind a torch.autograd.Function whose
+backward is the gradient autograd derives for the reference code: into the LUT parameters (straight-through round,
+clamp gate) and into the input through the LSB terms.  Everything else in `predict` (rot90, replicate pad, the
+straight-through rounding between passes) is the reference's own torch glue.
+
+Like the reference, modes "c" and "t" of this twin read their LSBs at the 'y' pattern pixels (model.py:229-232,
+240-243); the deploy-time numpy pass (eval_lut_sr.FourSimplexInterpFaster) does not.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+mode_pad_dict = {"s": 1, "d": 2, "y": 2, "c": 3, "t": 3, "e": 3, "l": 3, "f": 4, "m": 4, "g": 5, "n": 5}
+
+
+def round_func(input):
+    """Backward-pass differentiable approximation of round (model.py:16-22)."""
+    forward_value = torch.round(input)
+    out = input.clone()
+    out.data = forward_value.data
+    return out
+
+
+def _mode_char(mode):
+    if not isinstance(mode, str) or len(mode) != 1 or mode not in "sdyct":
+        raise ValueError("Mode {} not implemented.".format(mode))          # model.py:246
+    return mode.encode()
+
+
+class _InterpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, img_in, outC, mode, bd):
+        if not (weight.is_cuda and img_in.is_cuda):
+            raise ValueError("SWF2LUT runs on the GPU (there is no CPU path)")
+        w = weight.detach().contiguous().float()
+        x = img_in.detach().contiguous().float()
+        B, Cn, hp, wp = x.shape
+        h, wd = hp - bd, wp - bd
+        if w.shape != (_lib.LERF_LUT_ENTRIES, outC):
+            raise ValueError("weight must be [17^4, outC]")
+        out = torch.empty((B, Cn * outC, h, wd), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().lerf_swf2lut_interp_f32(C.c_void_p(w.data_ptr()), int(outC), _mode_char(mode),
+                                                      C.c_void_p(x.data_ptr()), B * Cn, h, wd, int(bd),
+                                                      C.c_void_p(out.data_ptr()), _lib.current_stream()),
+                   "lerf_swf2lut_interp_f32")
+        ctx.save_for_backward(w, x)
+        ctx.meta = (int(outC), mode, int(bd))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        w, x = ctx.saved_tensors
+        outC, mode, bd = ctx.meta
+        B, Cn, hp, wp = x.shape
+        g = grad_out.contiguous().float()
+        gw = torch.zeros_like(w) if ctx.needs_input_grad[0] else None
+        gx = torch.zeros_like(x) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.lib().lerf_swf2lut_interp_bwd_f32(
+            C.c_void_p(w.data_ptr()), outC, _mode_char(mode), C.c_void_p(x.data_ptr()), C.c_void_p(g.data_ptr()),
+            B * Cn, hp - bd, wp - bd, bd, C.c_void_p(gw.data_ptr() if gw is not None else None),
+            C.c_void_p(gx.data_ptr() if gx is not None else None), _lib.current_stream()), "lerf_swf2lut_interp_bwd_f32")
+        return gw, gx, None, None, None
+
+
+class SWF2LUT(nn.Module):
+    """model.py:130-431.  `opt` carries modes, modes2, stages, norm, interval, expDir (common/option.py:21-35);
+    the LUT files are `<expDir>/<lutName>_s{stage}_{mode}r{r}.npy` with lutName = "LUT" like the reference
+    (`opt.lutName` selects another prefix, e.g. the shipped "LUTft")."""
+
+    def __init__(self, opt, inC=1, outC=3):
+        super(SWF2LUT, self).__init__()
+        self.modes2 = opt.modes2
+        self.modes = opt.modes
+        self.stages = opt.stages
+        self.norm = opt.norm
+        self.interval = opt.interval
+        if self.interval != 4 or self.stages != 2:
+            raise NotImplementedError("only interval=4, stages=2 (the shipped models) are implemented")
+        name = getattr(opt, "lutName", None) or "LUT"
+        self.outC = outC
+        for mode in self.modes2:                                # hyper stage (:140-149)
+            for r in [0, 1]:
+                key = "s{}_{}r{}".format(2, mode, r)
+                arr = np.load(os.path.join(opt.expDir, "{}_{}.npy".format(name, key))).reshape(-1, outC).astype(np.float32) / 127.0
+                self.register_parameter(name="weight_" + key, param=torch.nn.Parameter(torch.Tensor(arr)))
+        for mode in self.modes:                                 # stage 1 (:151-158)
+            key = "s{}_{}r{}".format(1, mode, 0)
+            arr = np.load(os.path.join(opt.expDir, "{}_{}.npy".format(name, key))).reshape(-1, 1).astype(np.float32) / 127.0
+            self.register_parameter(name="weight_" + key, param=torch.nn.Parameter(torch.Tensor(arr)))
+
+    round_func = staticmethod(round_func)
+
+    def InterpTorchBatch(self, weight, outC, mode, img_in, bd):
+        """[B, C, h+bd, w+bd] (integer-valued float32) -> [B, C*outC, h, w] (:172-385)."""
+        _mode_char(mode)
+        return _InterpFn.apply(weight, img_in, outC, mode, bd)
+
+    def forward(self, x, stage, mode, r):
+        key = "s{}_{}r{}".format(str(stage), mode, r)
+        pad = mode_pad_dict[mode]
+        outC = 1 if stage == 1 else self.outC
+        return self.InterpTorchBatch(getattr(self, "weight_" + key), outC, mode, x, pad)
+
+    def predict(self, x, stage=None):
+        x = round_func(x * 255.0)                               # 8-bit input (:400)
+        if stage == 2:                                          # hyper stage (:403-414)
+            pred = 0
+            for mode in self.modes2:
+                pad = mode_pad_dict[mode]
+                for r in [0, 2]:
+                    pred += round_func(torch.rot90(self.forward(F.pad(torch.rot90(x, r, [2, 3]), (0, pad, 0, pad), mode="replicate"),
+                                                                stage=self.stages, mode=mode, r=0), (4 - r) % 4, [2, 3]))
+                for r in [1, 3]:
+                    pred += round_func(torch.rot90(self.forward(F.pad(torch.rot90(x, r, [2, 3]), (0, pad, 0, pad), mode="replicate"),
+                                                                stage=self.stages, mode=mode, r=1), (4 - r) % 4, [2, 3]))
+            avg_factor, bias, norm = len(self.modes2) * 4, self.norm // 2, float(self.norm)
+            x = torch.clamp(round_func((pred / avg_factor) + bias), 0, self.norm) / norm
+        else:                                                   # stage 1 (:415-429)
+            for s in range(self.stages - 1):
+                pred = 0
+                for mode in self.modes:
+                    pad = mode_pad_dict[mode]
+                    for r in [0, 1, 2, 3]:
+                        pred += round_func(torch.rot90(self.forward(F.pad(torch.rot90(x, r, [2, 3]), (0, pad, 0, pad), mode="replicate"),
+                                                                    stage=s + 1, mode=mode, r=0), (4 - r) % 4, [2, 3]))
+                if s + 1 == self.stages - 1:
+                    avg_factor, bias, norm = len(self.modes), 0, 1
+                else:
+                    avg_factor, bias, norm = len(self.modes) * 4, self.norm // 2, float(self.norm)
+                x = torch.clamp(round_func((pred / avg_factor)) + bias, 0, self.norm) / norm
+        return x

@@ -483,6 +483,64 @@ def mpsnr(sr_u8, hr_u8, mask):
     return float(-10 * np.log10(mse))
 
 
+# ----------------------------------------------------------------------------
+# fine-tuning twin: SWF2LUT.InterpTorchBatch (resample/model.py:172-385), forward and the autograd gradients
+# ----------------------------------------------------------------------------
+_SWF_LSB_MODE = {"s": "s", "d": "d", "y": "y", "c": "y", "t": "y"}      # c, t read their LSBs at the 'y' pixels (:229-243)
+_SWF_PATTERN = {"s": ((0, 0), (0, 1), (1, 0), (1, 1)), "d": ((0, 0), (0, 2), (2, 0), (2, 2)),
+                "y": ((0, 0), (1, 1), (1, 2), (2, 1)), "c": ((0, 0), (0, 1), (0, 2), (0, 3)),
+                "t": ((0, 0), (1, 1), (2, 2), (3, 3))}
+
+
+def swf2lut_interp(weight, outC, mode, img_in, bd, grad_out=None):
+    """weight float32 [17^4, outC] (LUT / 127), img_in float32 [B, C, h+bd, w+bd] integer-valued.
+    Returns out [B, C*outC, h, w] float32; with grad_out also (grad_weight, grad_img) as torch autograd derives them
+    for the reference code: round = straight-through, clamp gate on the rounded value, torch.remainder passes the
+    gradient to the LSB source pixels, ties ordered by the reference's case chain (later axis first)."""
+    if mode not in _SWF_PATTERN:
+        raise ValueError("Mode {} not implemented.".format(mode))
+    weight = np.asarray(weight, np.float32)
+    img = np.asarray(img_in, np.float32)
+    B, Cn, hp, wp = img.shape
+    h, w = hp - bd, wp - bd
+    rq = np.round(weight * np.float32(127))
+    lut = np.clip(rq, -127, 127).astype(np.float32)
+    gate = ((rq >= -127) & (rq <= 127))
+    pm, pl = _SWF_PATTERN[mode], _SWF_PATTERN[_SWF_LSB_MODE[mode]]
+    ii = img.astype(np.int64)
+    m = np.stack([ii[:, :, dy:dy + h, dx:dx + w] // Q for dy, dx in pm])            # [4,B,C,h,w]
+    f = np.stack([ii[:, :, dy:dy + h, dx:dx + w] % Q for dy, dx in pl])
+    strides = np.array([L ** 3, L ** 2, L, 1], np.int64).reshape(4, 1, 1, 1, 1)
+    key = f * 4 + np.arange(4).reshape(4, 1, 1, 1, 1)
+    order = np.argsort(-key, axis=0, kind="stable")                                  # axis stepped at sorted position n
+    fs = np.take_along_axis(f, order, axis=0)
+    step = np.take_along_axis(np.broadcast_to(strides, f.shape), order, axis=0)
+    idx = [np.sum(m * strides, axis=0)]
+    for n in range(4):
+        idx.append(idx[-1] + step[n])
+    wts = [Q - fs[0], fs[0] - fs[1], fs[1] - fs[2], fs[2] - fs[3], fs[3]]
+    P = [lut[i] for i in idx]                                                        # each [B,C,h,w,outC]
+    acc = sum(wn[..., None].astype(np.float32) * Pn for wn, Pn in zip(wts, P)) / np.float32(Q)
+    out = np.transpose(acc, (0, 1, 4, 2, 3)).reshape(B, Cn * outC, h, w)
+    if grad_out is None:
+        return out
+    g = np.asarray(grad_out, np.float64).reshape(B, Cn, outC, h, w).transpose(0, 1, 3, 4, 2) / Q      # [B,C,h,w,outC]
+    gw = np.zeros(weight.shape, np.float64)
+    for wn, i in zip(wts, idx):
+        np.add.at(gw, i.reshape(-1), (g * wn[..., None]).reshape(-1, outC) * 127.0)
+    gw *= gate
+    gimg = np.zeros(img.shape, np.float64)
+    bb, cc, yy, xx = np.meshgrid(np.arange(B), np.arange(Cn), np.arange(h), np.arange(w), indexing="ij")
+    ldy = np.array([p[0] for p in pl]).reshape(4, 1, 1, 1, 1)
+    ldx = np.array([p[1] for p in pl]).reshape(4, 1, 1, 1, 1)
+    for n in range(4):
+        gf = np.sum(g * (P[n + 1].astype(np.float64) - P[n].astype(np.float64)), axis=-1)
+        ay = np.take_along_axis(np.broadcast_to(ldy, f.shape), order, axis=0)[n]
+        ax = np.take_along_axis(np.broadcast_to(ldx, f.shape), order, axis=0)[n]
+        np.add.at(gimg, (bb, cc, yy + ay, xx + ax), gf)
+    return out, gw, gimg
+
+
 def load_luts(model_dir, linear=False, lut_name="LUTft", modes="sct", modes2="sct"):
     """LUT dictionary as eval_lut_sr.py:750-775 builds it (kept int8)."""
     import os

@@ -357,6 +357,81 @@ def g9_bicubic_resize():
     print("G9", len(out))
 
 
+def _swf2lut(model, outC, linear):
+    """Reference SWF2LUT on the CPU with the shipped LUTs (it loads `LUT_*.npy`; the shipped files are `LUTft_*`)."""
+    import shutil
+    import tempfile
+    from resample.model import SWF2LUT
+    d = tempfile.mkdtemp(dir=os.path.join(REPO, "gpurun_out") if os.path.isdir(os.path.join(REPO, "gpurun_out")) else None)
+    for f in os.listdir(os.path.join(ASSETS, model)):
+        shutil.copy(os.path.join(ASSETS, model, f), os.path.join(d, f.replace("LUTft_", "LUT_")))
+    opt = types.SimpleNamespace(modes="sct", modes2="sct", stages=2, norm=255, interval=4, expDir=d)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = SWF2LUT(opt, inC=1, outC=outC)
+    shutil.rmtree(d)
+    return m
+
+
+def g10_swf2lut():
+    from resize_right.resize_right2d_torch import AmplifiedLinearResize2dTorch
+    sys.path.insert(0, OUT)
+    import swf_inputs
+    out = {}
+    for model, outC, linear in (("lerf-g", 3, False), ("lerf-l", 1, True)):
+        m = _swf2lut(model, outC, linear)
+        # A: InterpTorchBatch forward + autograd gradients, every mode of the function
+        for mi, mode in enumerate("sdyct"):
+            key = "weight_s2_%sr0" % (mode if mode in "sct" else "s")
+            bd, img, G = swf_inputs.case_inputs(1000 + mi, mode, outC)
+            wt = torch.tensor(swf_inputs.case_weight(getattr(m, key).detach().numpy(), 2000 + mi)).requires_grad_(True)
+            it = torch.tensor(img, requires_grad=True)
+            o = m.InterpTorchBatch(wt, outC, mode, it, bd)
+            (o * torch.tensor(G)).sum().backward()
+            gw = wt.grad.numpy()
+            rows = np.nonzero(np.abs(gw).sum(1))[0]
+            pre = "%s/interp/%s/" % (model, mode)
+            out[pre + "out"] = o.detach().numpy()
+            out[pre + "gimg"] = it.grad.numpy()
+            out[pre + "gw_rows"] = rows.astype(np.int32)
+            out[pre + "gw_vals"] = gw[rows]
+        # B: predict, both stages
+        rng = np.random.default_rng(3000)
+        x = rng.random((2, 1, 12, 10)).astype(np.float32)
+        feat = m.predict(torch.tensor(x), stage=1)
+        hyper = m.predict(feat / 255.0, stage=2)
+        out["%s/predict/x" % model] = x
+        out["%s/predict/feat" % model] = feat.detach().numpy()
+        out["%s/predict/hyper" % model] = hyper.detach().numpy()
+        # C: one training step of train_model.py:416-441 (x2), gradients of three LUT parameters
+        lb = rng.random((2, 1, 24, 20)).astype(np.float32)
+        m.zero_grad()
+        feat = m.predict(torch.tensor(x), stage=1)
+        hyper = m.predict(feat / 255.0, stage=2)
+        if linear:
+            rz = AmplifiedLinearResize2dTorch(support_sz=2, device="cpu")
+            rz.set_shape([2, 1, 12, 10], scale_factors=2)
+            pred = rz.resize(feat, hyper)
+        else:
+            rz = SteeringGaussianResize2dTorch(support_sz=2, device="cpu", max_sigma=10)
+            rz.set_shape([2, 1, 12, 10], scale_factors=2)
+            pred = rz.resize(feat, hyper[:, :1], hyper[:, 1:2], hyper[:, 2:])
+        pred = torch.clamp(pred, 0, 255) / 255.0
+        loss = torch.nn.functional.mse_loss(pred, torch.tensor(lb))
+        loss.backward()
+        out["%s/step/lb" % model] = lb
+        out["%s/step/loss" % model] = np.array([loss.item()])
+        out["%s/step/pred" % model] = pred.detach().numpy()
+        for key in ("weight_s1_sr0", "weight_s1_tr0", "weight_s2_cr1", "weight_s2_tr0"):
+            gw = getattr(m, key).grad.numpy()
+            rows = np.nonzero(np.abs(gw).sum(1))[0]
+            out["%s/step/%s/rows" % (model, key)] = rows.astype(np.int32)
+            out["%s/step/%s/vals" % (model, key)] = gw[rows]
+    np.savez_compressed(os.path.join(OUT, "g10_swf2lut.npz"), **out)
+    print("G10", len(out), os.path.getsize(os.path.join(OUT, "g10_swf2lut.npz")))
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -376,7 +451,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -393,3 +468,5 @@ if __name__ == "__main__":
         g8_ssim()
     if "g9" in which:
         g9_bicubic_resize()
+    if "g10" in which:
+        g10_swf2lut()

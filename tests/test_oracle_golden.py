@@ -194,3 +194,24 @@ def test_bicubic_resize_torch_golden(oracle, golden, ci):
     ref = g["%d/out" % ci]
     assert o.reshape(ref.shape).shape == ref.shape
     assert np.max(np.abs(o.reshape(ref.shape) - ref)) <= 2e-3
+
+
+@pytest.mark.parametrize("mi,mode", list(enumerate("sdyct")))
+@pytest.mark.parametrize("model", ["lerf-g", "lerf-l"])
+def test_swf2lut_interp_restatement(oracle, golden, luts_g, luts_l, model, mi, mode):
+    """SWF2LUT.InterpTorchBatch of the reference (forward + autograd gradients) vs oracle.swf2lut_interp."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import swf_inputs
+    g = golden("g10_swf2lut.npz")
+    luts, outC = (luts_g, 3) if model == "lerf-g" else (luts_l, 1)
+    key = "s2_%sr0" % (mode if mode in "sct" else "s")
+    bd, img, G = swf_inputs.case_inputs(1000 + mi, mode, outC)
+    w = swf_inputs.case_weight(luts[key].astype(np.float32).reshape(-1, outC) / np.float32(127.0), 2000 + mi)
+    out, gw, gimg = oracle.swf2lut_interp(w, outC, mode, img, bd, G)
+    pre = "%s/interp/%s/" % (model, mode)
+    assert np.array_equal(out, g[pre + "out"])
+    assert np.max(np.abs(gimg - g[pre + "gimg"])) <= 2e-5
+    rows = g[pre + "gw_rows"]
+    assert np.array_equal(np.nonzero(np.abs(gw).sum(1))[0], rows)
+    assert np.max(np.abs(gw[rows] - g[pre + "gw_vals"])) <= 2e-5 * np.abs(g[pre + "gw_vals"]).max()
