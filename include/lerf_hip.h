@@ -123,6 +123,12 @@ int lerf_mode_offsets(char mode, int rot, int8_t dy[4], int8_t dx[4]);
 int lerf_sr_axis_tables(int n_in, int n_out, double scale, int S,
                         int32_t* left, double* dis64, float* dis32, int32_t* pads);
 
+/* The same tables with the float32 arithmetic of the reference's torch classes
+ * (Resize2dTorch.get_distance, resize_right/resize_right2d_torch.py:48-103): bit-equal to the class's
+ * field_of_view / dis tensors, including the scales where float32 and float64 put a support boundary on different
+ * sides (x3, S=2).  pads may be NULL. */
+int lerf_sr_axis_tables_f32(int n_in, int n_out, double scale, int S, int32_t* left, float* dis32, int32_t* pads);
+
 /* ceil(scale * n_in) (resize_right/resize_right2d_numpy.py:41-45) */
 int lerf_out_size(int n_in, double scale);
 
@@ -243,6 +249,15 @@ int lerf_swf2lut_interp_f32(const float* weight, int oC, char mode, const float*
                             float* out, void* stream);
 int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const float* img, const float* grad_out,
                                 int n_planes, int h, int w, int bd, float* grad_weight, float* grad_img, void* stream);
+
+/* Backward of lerf_resize (kinds GAUSS, LINEAR) on planar float32 maps, as autograd derives it for
+ * SteeringGaussianResize2dTorch.resize / AmplifiedLinearResize2dTorch.resize (resize_right2d_torch.py:154-247):
+ * feat, h0..h2: float32 [N][H][W] (hyper maps in [0,1]; h1, h2 unused for LINEAR), grad_out: float32
+ * [N][out_h][out_w].  grad_feat / grad_h*: float32 [N][H][W], ACCUMULATED into with float atomics (zero them first);
+ * any of them may be NULL.  Uses the float32 distance tables of `geo`. */
+int lerf_resize_bwd_f32(const float* feat, const float* h0, const float* h1, const float* h2, int N, int H, int W,
+                        const lerf_sr_geo_t* geo, int kind, double max_sigma, const float* grad_out, float* grad_feat,
+                        float* grad_h0, float* grad_h1, float* grad_h2, void* stream);
 
 #ifdef __cplusplus
 }

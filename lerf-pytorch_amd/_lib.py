@@ -23,13 +23,13 @@ KINDS = {"gauss": KIND_GAUSS, "linear": KIND_LINEAR, "nearest": KIND_NEAREST, "c
          "bilinear": KIND_BILINEAR, "lanczos2": KIND_LANCZOS2, "lanczos3": KIND_LANCZOS3}
 
 EXPORTS = [
-    "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables",
+    "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables", "lerf_sr_axis_tables_f32",
     "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
     "lerf_lut_stages_u8",
     "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_u8",
     "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed",
     "lerf_metric_y_sse_u8", "lerf_metric_ssim_y_u8", "lerf_metric_masked_sse_u8",
-    "lerf_swf2lut_interp_f32", "lerf_swf2lut_interp_bwd_f32",
+    "lerf_swf2lut_interp_f32", "lerf_swf2lut_interp_bwd_f32", "lerf_resize_bwd_f32",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
     L.lerf_device_count.restype = C.c_int
     L.lerf_mode_offsets.argtypes = [C.c_char, C.c_int, C.c_void_p, C.c_void_p]
     L.lerf_sr_axis_tables.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lerf_sr_axis_tables_f32.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lerf_out_size.argtypes = [C.c_int, C.c_double]
     L.lerf_invert3x3.argtypes = [C.c_void_p, C.c_void_p]
     L.lerf_warp_pads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -118,6 +119,8 @@ def lib():
                                           C.c_void_p, C.c_void_p]
     L.lerf_swf2lut_interp_bwd_f32.argtypes = [C.c_void_p, C.c_int, C.c_char, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lerf_resize_bwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SrGeo),
+                                      C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:          # AttributeError here = the .so does not match include/lerf_hip.h
         getattr(L, name)
     if L.lerf_abi_version() != 1:
@@ -156,6 +159,16 @@ def sr_axis_tables(n_in: int, n_out: int, scale: float, S: int):
     check(lib().lerf_sr_axis_tables(int(n_in), int(n_out), float(scale), int(S), left.ctypes.data,
                                     dis64.ctypes.data, dis32.ctypes.data, pads.ctypes.data), "lerf_sr_axis_tables")
     return left, dis64, dis32, (int(pads[0]), int(pads[1]))
+
+
+def sr_axis_tables_f32(n_in: int, n_out: int, scale: float, S: int):
+    """float32 tables of the reference's torch classes (resize_right2d_torch.py:48-103)."""
+    left = np.zeros(n_out, np.int32)
+    dis32 = np.zeros((n_out, S), np.float32)
+    pads = np.zeros(2, np.int32)
+    check(lib().lerf_sr_axis_tables_f32(int(n_in), int(n_out), float(scale), int(S), left.ctypes.data,
+                                        dis32.ctypes.data, pads.ctypes.data), "lerf_sr_axis_tables_f32")
+    return left, dis32.astype(np.float64), dis32, (int(pads[0]), int(pads[1]))
 
 
 def warp_pads(minv: np.ndarray, in_hw, out_hw, S: int):

@@ -111,6 +111,36 @@ int lerf_sr_axis_tables(int n_in, int n_out, double scale, int S, int32_t* left,
     return LERF_OK;
 }
 
+int lerf_sr_axis_tables_f32(int n_in, int n_out, double scale, int S, int32_t* left, float* dis32, int32_t* pads) {
+#pragma clang fp contract(off)
+    if (n_in < 1 || n_out < 1 || !(scale > 0.0) || S < 1 || S > LERF_MAX_SUPPORT || !left || !dis32) return LERF_EINVAL;
+    // Resize2dTorch.get_projected_grid2d / get_field_of_view2d / cal_pad_sz / get_distance
+    // (resize_right/resize_right2d_torch.py:48-103): every tensor op is float32, the python scalars are float64
+    // expressions rounded to float32 when they meet the tensor.
+    const float sf = (float)scale;
+    const float a = (float)((double)(n_in - 1) / 2);
+    const float b = (float)((double)(n_out - 1) / (2 * scale));
+    const float half = (float)((double)S / 2);
+    int pad_lo = 0;
+    for (int i = 0; i < n_out; ++i) {
+        float g = (float)i / sf;                        // :60
+        g = g + a;
+        g = g - b;
+        float t = g - half;                             // :69
+        t = t - kEps32;
+        const int l = (int)ceilf(t);
+        if (i == 0) pad_lo = -l;                        // :81
+        left[i] = l;
+        const float gp = g + (float)pad_lo;             // :83
+        for (int k = 0; k < S; ++k) dis32[i * S + k] = gp - (float)(l + pad_lo + k);      // :98
+    }
+    if (pads) {
+        pads[0] = pad_lo;
+        pads[1] = left[n_out - 1] + S - 1 - n_in + 1;   // :81
+    }
+    return LERF_OK;
+}
+
 int lerf_invert3x3(const double m[9], double out[9]) {
     if (!m || !out) return LERF_EINVAL;
     double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];

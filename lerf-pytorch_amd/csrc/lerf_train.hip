@@ -130,6 +130,100 @@ interp_bwd_kernel(const float* __restrict__ weight, const float* __restrict__ im
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the SR resamplers (SteeringGaussianResize2dTorch.resize / AmplifiedLinearResize2dTorch.resize,
+// resize_right2d_torch.py:154-247) on planar float32 maps, as autograd derives it:
+//   out = sum_t w_t v_t / W,  W = sum_t w_t          v_t = input at the tap (0 outside the frame)
+//   d out / d v_t = w_t / W                           (scattered to the tap's input pixel when inside)
+//   d out / d w_t = (v_t - out) / W
+//   gauss:  w = exp(-e/2), e = tx^2 - 2 rho tx ty + ty^2, tx = sx dx, ty = sy dy, rho = 2 h0 - 1, s = max_sigma h
+//   linear: w = max(lx, 0) max(ly, 0), l(x) = (alpha x + 1)[-1 <= x < 0] + (1 - alpha x)[0 <= x <= 1], alpha = max_sigma (2 h - 1)
+// hyper-parameter gradients land on the CLAMPED tap position (replicate padding).  One thread per output element,
+// float atomics into the gradient maps (accumulating: the caller zeroes them or passes running sums).
+// ---------------------------------------------------------------------------------------------------------------
+struct Tap {
+    float v, w, dx, dy, tx, ty, rho, alpha, lx, ly, cx, cy;
+    int64_t pos;
+    bool inside;
+};
+
+template <int KIND>
+__device__ __forceinline__ Tap load_tap(const float* __restrict__ feat, const float* __restrict__ h0, const float* __restrict__ h1,
+                                        const float* __restrict__ h2, int64_t plane, int H, int W, int rr, int cc, float dx, float dy,
+                                        float max_sigma) {
+    Tap t;
+    const int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
+    t.inside = (rr == rcl) && (cc == ccl);
+    t.pos = plane + (int64_t)rcl * W + ccl;
+    t.v = t.inside ? feat[t.pos] : 0.0f;
+    t.dx = dx;
+    t.dy = dy;
+    if (KIND == LERF_KIND_GAUSS) {
+        t.rho = h0[t.pos] * 2.0f - 1.0f;
+        t.tx = h1[t.pos] * max_sigma * dx;
+        t.ty = h2[t.pos] * max_sigma * dy;
+        t.w = t.tx * t.tx - 2.0f * t.rho * (t.tx * t.ty) + t.ty * t.ty;      // the exponent e; turned into a weight by the caller
+    } else {
+        t.alpha = max_sigma * (h0[t.pos] * 2.0f - 1.0f);
+        t.lx = (t.alpha * dx + 1.0f) * ((-1.0f <= dx && dx < 0.0f) ? 1.0f : 0.0f) + (1.0f - t.alpha * dx) * ((0.0f <= dx && dx <= 1.0f) ? 1.0f : 0.0f);
+        t.ly = (t.alpha * dy + 1.0f) * ((-1.0f <= dy && dy < 0.0f) ? 1.0f : 0.0f) + (1.0f - t.alpha * dy) * ((0.0f <= dy && dy <= 1.0f) ? 1.0f : 0.0f);
+        t.cx = fmaxf(t.lx, 0.0f);
+        t.cy = fmaxf(t.ly, 0.0f);
+        t.w = t.cx * t.cy;
+    }
+    return t;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+resize_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ h0, const float* __restrict__ h1,
+                  const float* __restrict__ h2, int N, int H, int W, int S, int oH, int oW, const int* __restrict__ left_r,
+                  const float* __restrict__ dis_r, const int* __restrict__ left_c, const float* __restrict__ dis_c, float max_sigma,
+                  const float* __restrict__ gout, float* __restrict__ gfeat, float* __restrict__ gh0, float* __restrict__ gh1,
+                  float* __restrict__ gh2) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, n = blockIdx.z;
+    if (j >= oW) return;
+    const int64_t plane = (int64_t)n * H * W;
+    const int lr = left_r[i], lc = left_c[j];
+    float emin = 0.0f;
+    if (KIND == LERF_KIND_GAUSS) {
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b < S; ++b) {
+                const Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
+                emin = (a == 0 && b == 0) ? t.w : fminf(emin, t.w);
+            }
+    }
+    float Wsum = 0.0f, num = 0.0f;
+    for (int a = 0; a < S; ++a)
+        for (int b = 0; b < S; ++b) {
+            Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
+            const float w = KIND == LERF_KIND_GAUSS ? __expf(-0.5f * (t.w - emin)) : t.w;
+            Wsum += w;
+            num += w * t.v;
+        }
+    const float out = num / Wsum;
+    const float g = gout[((int64_t)n * oH + i) * oW + j];
+    for (int a = 0; a < S; ++a)
+        for (int b = 0; b < S; ++b) {
+            Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
+            const float w = KIND == LERF_KIND_GAUSS ? __expf(-0.5f * (t.w - emin)) : t.w;
+            if (gfeat && t.inside) atomicAdd(gfeat + t.pos, g * w / Wsum);
+            const float gw = g * (t.v - out) / Wsum;          // d loss / d w_t
+            if (KIND == LERF_KIND_GAUSS) {
+                const float c = gw * (-0.5f * w);               // d loss / d e_t
+                if (gh0) atomicAdd(gh0 + t.pos, c * (-2.0f * t.tx * t.ty) * 2.0f);
+                if (gh1) atomicAdd(gh1 + t.pos, c * (2.0f * t.dx * (t.tx - t.rho * t.ty)) * max_sigma);
+                if (gh2) atomicAdd(gh2 + t.pos, c * (2.0f * t.dy * (t.ty - t.rho * t.tx)) * max_sigma);
+            } else if (gh0) {
+                // clamp(l, 0) passes the gradient where l >= 0 (torch.clamp backward)
+                const float dlx = (t.lx >= 0.0f ? 1.0f : 0.0f) * (t.dx * ((-1.0f <= t.dx && t.dx < 0.0f) ? 1.0f : 0.0f) - t.dx * ((0.0f <= t.dx && t.dx <= 1.0f) ? 1.0f : 0.0f));
+                const float dly = (t.ly >= 0.0f ? 1.0f : 0.0f) * (t.dy * ((-1.0f <= t.dy && t.dy < 0.0f) ? 1.0f : 0.0f) - t.dy * ((0.0f <= t.dy && t.dy <= 1.0f) ? 1.0f : 0.0f));
+                atomicAdd(gh0 + t.pos, gw * (dlx * t.cy + t.cx * dly) * 2.0f * max_sigma);
+            }
+        }
+}
+
 }  // namespace train
 }  // namespace lerf
 
@@ -167,6 +261,27 @@ int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const fl
         hipLaunchKernelGGL(interp_bwd_kernel<3>, grid, block, 0, st, weight, img, grad_out, n_planes, h, w, bd, pt, grad_weight, grad_img);
     else
         return LERF_EUNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+}
+
+int lerf_resize_bwd_f32(const float* feat, const float* h0, const float* h1, const float* h2, int N, int H, int W,
+                        const lerf_sr_geo_t* geo, int kind, double max_sigma, const float* grad_out, float* grad_feat,
+                        float* grad_h0, float* grad_h1, float* grad_h2, void* stream) {
+    if (!feat || !h0 || !geo || !grad_out || N < 1 || H < 1 || W < 1) return LERF_EINVAL;
+    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return LERF_EUNSUPPORTED;
+    if (kind == LERF_KIND_GAUSS && (!h1 || !h2)) return LERF_EINVAL;
+    if (!geo->left_r || !geo->left_c || !geo->dis_r || !geo->dis_c || geo->out_h < 1 || geo->out_w < 1) return LERF_EINVAL;
+    if (geo->S < 1 || geo->S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
+    dim3 block(256), grid((geo->out_w + 255) / 256, geo->out_h, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == LERF_KIND_GAUSS)
+        hipLaunchKernelGGL(resize_bwd_kernel<LERF_KIND_GAUSS>, grid, block, 0, st, feat, h0, h1, h2, N, H, W, geo->S, geo->out_h,
+                           geo->out_w, geo->left_r, geo->dis_r, geo->left_c, geo->dis_c, (float)max_sigma, grad_out, grad_feat,
+                           grad_h0, grad_h1, grad_h2);
+    else
+        hipLaunchKernelGGL(resize_bwd_kernel<LERF_KIND_LINEAR>, grid, block, 0, st, feat, h0, h1, h2, N, H, W, geo->S, geo->out_h,
+                           geo->out_w, geo->left_r, geo->dis_r, geo->left_c, geo->dis_c, (float)max_sigma, grad_out, grad_feat,
+                           grad_h0, nullptr, nullptr);
     return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
 }
 

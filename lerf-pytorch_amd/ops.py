@@ -21,7 +21,9 @@ class SrGeometry:
     """Separable SR geometry (Resize2dNumpy.set_shape, resize_right2d_numpy.py:18-140)
     as two 1-D tables per axis, resident on the device."""
 
-    def __init__(self, in_hw, scale_factors=None, out_hw=None, support=2, device=None):
+    def __init__(self, in_hw, scale_factors=None, out_hw=None, support=2, device=None, arithmetic="f64"):
+        """arithmetic: "f64" = the numpy classes' float64 tables (normative for the eval path); "torch32" = the
+        float32 tables of the reference's torch classes (resize_right2d_torch.py:48-103), bit-equal to theirs."""
         torch = _torch()
         H, W = int(in_hw[0]), int(in_hw[1])
         if out_hw is not None and scale_factors is None:
@@ -35,8 +37,9 @@ class SrGeometry:
             out_hw = (_lib.out_size(H, sh), _lib.out_size(W, sw))          # :41-45
         self.in_hw, self.out_hw, self.scales, self.S = (H, W), (int(out_hw[0]), int(out_hw[1])), (sh, sw), int(support)
         self.device = torch.device(device if device is not None else "cuda")
-        lr, dr64, dr32, pr = _lib.sr_axis_tables(H, self.out_hw[0], sh, self.S)
-        lc, dc64, dc32, pc = _lib.sr_axis_tables(W, self.out_hw[1], sw, self.S)
+        tables = {"f64": _lib.sr_axis_tables, "torch32": _lib.sr_axis_tables_f32}[arithmetic]
+        lr, dr64, dr32, pr = tables(H, self.out_hw[0], sh, self.S)
+        lc, dc64, dc32, pc = tables(W, self.out_hw[1], sw, self.S)
         self.pad_vec = ((0, 0), pr, pc)                                     # :129
         self.host = dict(left_r=lr, dis_r=dr64, dis_r32=dr32, left_c=lc, dis_c=dc64, dis_c32=dc32)
         self._upload()

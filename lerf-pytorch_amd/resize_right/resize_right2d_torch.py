@@ -1,10 +1,10 @@
 """torch-facing resampler classes: drop-in for the LeRF classes of the
 reference's resize_right/resize_right2d_torch.py ([B,C,H,W] tensors on the GPU).
 
-Geometry follows the normative numpy path (float64 on the host, see
-resize_right2d_numpy.py:57-140); SR returns float32, warps return float64 like
+SR geometry follows the torch classes' own float32 arithmetic (resize_right2d_torch.py:48-103, bit-equal tables:
+lerf_sr_axis_tables_f32), warp geometry the float64 one; SR returns float32, warps return float64 like
 the reference (its warp distances are double, resize_right2d_torch.py:286-296).
-Forward only: these operators carry no autograd graph.
+The SR classes carry autograd (HIP backward, `_ResizeFn`); the warp classes are forward only.
 """
 from __future__ import annotations
 
@@ -13,6 +13,36 @@ from math import ceil
 import torch
 
 from .. import _lib, ops
+
+
+class _ResizeFn(torch.autograd.Function):
+    """lerf_resize forward, lerf_resize_bwd_f32 backward (the gradient autograd derives for
+    resize_right2d_torch.py:154-247) -- used when an input of resize() requires grad (train_model.py:431-441)."""
+
+    @staticmethod
+    def forward(ctx, geo, kind, max_sigma, x, *hs):
+        x = x.detach().contiguous().float()
+        hs = [h.detach().contiguous().float() for h in hs]
+        out = ops.resize_planar(x, hs, geo, kind, max_sigma, out="f32")
+        ctx.save_for_backward(x, *hs)
+        ctx.meta = (geo, kind, float(max_sigma))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import ctypes as C
+        x, *hs = ctx.saved_tensors
+        geo, kind, max_sigma = ctx.meta
+        g = grad_out.contiguous().float()
+        N, H, W = x.shape
+        need = ctx.needs_input_grad[3:]
+        grads = [torch.zeros_like(x) if need[k] else None for k in range(1 + len(hs))]
+        hp = [C.c_void_p(h.data_ptr()) for h in hs] + [C.c_void_p(None)] * (3 - len(hs))
+        gp = [C.c_void_p(t.data_ptr() if t is not None else None) for t in grads] + [C.c_void_p(None)] * (3 - len(hs))
+        _lib.check(_lib.lib().lerf_resize_bwd_f32(C.c_void_p(x.data_ptr()), hp[0], hp[1], hp[2], N, H, W, geo.ref(),
+                                                  _lib.KINDS[kind], max_sigma, C.c_void_p(g.data_ptr()), gp[0], gp[1], gp[2],
+                                                  gp[3], _lib.current_stream()), "lerf_resize_bwd_f32")
+        return (None, None, None) + tuple(grads)
 
 
 def _check_dev(t, name):
@@ -48,7 +78,7 @@ class Resize2dTorch(object):
         scale_factors = [1] * (4 - len(scale_factors)) + list(scale_factors)
         self.in_shape = in_shape
         self.scale_factors = [float(s) for s in scale_factors]
-        self.geo = ops.SrGeometry(in_shape[2:], self.scale_factors[2:], out_hw, self.support_sz)
+        self.geo = ops.SrGeometry(in_shape[2:], self.scale_factors[2:], out_hw, self.support_sz, arithmetic="torch32")
         self.out_shape = [ceil(self.scale_factors[0] * in_shape[0]), ceil(self.scale_factors[1] * in_shape[1]),
                           self.geo.out_hw[0], self.geo.out_hw[1]]
         pr, pc = self.geo.pad_vec[1], self.geo.pad_vec[2]
@@ -64,7 +94,10 @@ class Resize2dTorch(object):
         for h in hypers:
             _check_dev(h, "hyper-parameter map")
             hs.append(h.reshape(B * Cn, H, W))
-        out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f32")
+        if kind in ("gauss", "linear") and torch.is_grad_enabled() and any(t.requires_grad for t in [x] + hs):
+            out = _ResizeFn.apply(self.geo, kind, max_sigma, x, *hs)
+        else:
+            out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f32")
         return out.reshape(B, Cn, self.geo.out_hw[0], self.geo.out_hw[1])
 
 

@@ -176,6 +176,22 @@ def sr_axis_tables(n_in: int, n_out: int, scale: float, S: int):
     return left, dis, pad_lo, pad_hi
 
 
+def sr_axis_tables_torch32(n_in: int, n_out: int, scale: float, S: int):
+    """The same tables in the float32 arithmetic of the reference's torch classes
+    (Resize2dTorch.get_distance, resize_right2d_torch.py:48-103); dis is returned as float64 values of the float32s."""
+    f = np.float32
+    g = np.arange(n_out, dtype=np.int64).astype(f) / f(scale)
+    g = g + f((n_in - 1) / 2)
+    g = g - f((n_out - 1) / (2 * float(scale)))
+    left = np.ceil((g - f(S / 2)) - f(EPS32)).astype(np.int64)
+    pad_lo = int(-left[0])
+    pad_hi = int(left[-1] + (S - 1) - n_in + 1)
+    gp = g + f(pad_lo)
+    fov = (left + pad_lo)[:, None] + np.arange(S)[None, :]
+    dis = (gp[:, None] - fov.astype(f)).astype(f)
+    return left, dis.astype(np.float64), pad_lo, pad_hi
+
+
 def _hyper_f32(hq_u8):
     """float32(hq)/255 exactly as eval_lut_sr.py:623-628."""
     return (np.asarray(hq_u8).astype(np.float32) / np.float32(255.0)).astype(np.float32)
@@ -208,7 +224,7 @@ def _lin_w(alpha, dx, dy):
     return np.clip(_lin_alpha(dx, alpha), 0, None) * np.clip(_lin_alpha(dy, alpha), 0, None)
 
 
-def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss"):
+def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss", geometry="f64"):
     """Spatially-varying SR from float32 [C,H,W] maps (the class API of
     SteeringGaussianResize2dNumpy.resize / AmplifiedLinearResize2dNumpy.resize).
 
@@ -218,8 +234,9 @@ def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss")
     feat = np.asarray(feat, dtype=np.float32)
     C, H, W = feat.shape
     oH, oW = out_size(H, sh), out_size(W, sw)
-    lx, disx, _, _ = sr_axis_tables(H, oH, sh, S)
-    ly, disy, _, _ = sr_axis_tables(W, oW, sw, S)
+    tables = sr_axis_tables if geometry == "f64" else sr_axis_tables_torch32       # torch classes: float32 geometry
+    lx, disx, _, _ = tables(H, oH, sh, S)
+    ly, disy, _, _ = tables(W, oW, sw, S)
     if kind == "gauss":
         rho = np.asarray(p0, np.float32) * 2 - 1
         sx = np.asarray(p1, np.float32) * max_sigma

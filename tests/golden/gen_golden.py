@@ -432,6 +432,40 @@ def g10_swf2lut():
     print("G10", len(out), os.path.getsize(os.path.join(OUT, "g10_swf2lut.npz")))
 
 
+def g11_resize_grads():
+    """autograd gradients of the reference's torch resamplers (resize_right2d_torch.py:140-247) on the CPU."""
+    from resize_right.resize_right2d_torch import AmplifiedLinearResize2dTorch
+    out = {}
+    for ci, (B, Cn, H, W, s, S) in enumerate([(2, 1, 12, 10, 2, 2), (1, 2, 9, 11, 4, 2), (1, 1, 10, 8, 2.5, 4), (1, 1, 6, 7, 3, 2)]):
+        rng = np.random.default_rng(1100 + ci)
+        x = rng.integers(0, 256, (B, Cn, H, W)).astype(np.float32)
+        hy = rng.random((3, B, Cn, H, W)).astype(np.float32)
+        for kind in ("gauss", "linear"):
+            if kind == "linear" and S != 2:
+                continue
+            if kind == "gauss":
+                r = SteeringGaussianResize2dTorch(support_sz=S, device="cpu", max_sigma=10)
+            else:
+                r = AmplifiedLinearResize2dTorch(support_sz=2, device="cpu")
+            r.set_shape([B, Cn, H, W], scale_factors=[s, s])
+            xt = torch.tensor(x, requires_grad=True)
+            ht = [torch.tensor(hy[k], requires_grad=True) for k in range(3)]
+            o = r.resize(xt, ht[0], ht[1], ht[2]) if kind == "gauss" else r.resize(xt, ht[0])
+            G = np.random.default_rng(1200 + ci).standard_normal(tuple(o.shape)).astype(np.float32)
+            (o * torch.tensor(G)).sum().backward()
+            pre = "%s/%d/" % (kind, ci)
+            out[pre + "cfg"] = np.array([B, Cn, H, W, s, S], dtype=np.float64)
+            out[pre + "x"] = x.astype(np.uint8)
+            out[pre + "hy"] = hy
+            out[pre + "G"] = G
+            out[pre + "out"] = o.detach().numpy()
+            out[pre + "gx"] = xt.grad.numpy()
+            for k in range(3 if kind == "gauss" else 1):
+                out[pre + "gh%d" % k] = ht[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g11_resize_grads.npz"), **out)
+    print("G11", len(out), os.path.getsize(os.path.join(OUT, "g11_resize_grads.npz")))
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -451,7 +485,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -470,3 +504,5 @@ if __name__ == "__main__":
         g9_bicubic_resize()
     if "g10" in which:
         g10_swf2lut()
+    if "g11" in which:
+        g11_resize_grads()

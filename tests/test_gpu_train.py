@@ -111,3 +111,97 @@ def test_mode_and_device_errors(torch, models):
         m.InterpTorchBatch(m.weight_s2_sr0.cpu(), 3, "s", x.cpu(), 1)
     with pytest.raises(ValueError):
         m.InterpTorchBatch(m.weight_s2_sr0, 3, "c", x, 1)            # pad smaller than the pattern reach
+
+
+# ---------------------------------------------------------------- resampler backward + one training step
+def _resizer(torch, kind, S):
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import AmplifiedLinearResize2dTorch, SteeringGaussianResize2dTorch
+    if kind == "gauss":
+        return SteeringGaussianResize2dTorch(support_sz=S, device=torch.device("cuda"), max_sigma=10)
+    return AmplifiedLinearResize2dTorch(support_sz=2, device=torch.device("cuda"))
+
+
+@pytest.mark.parametrize("kind,ci", [("gauss", 0), ("gauss", 1), ("gauss", 2), ("gauss", 3), ("linear", 0), ("linear", 1), ("linear", 3)])
+def test_resizer_gradients_golden(torch, golden, kind, ci):
+    """autograd gradients of the reference's torch resamplers (same float32 geometry; float32 arithmetic on both sides)."""
+    g = golden("g11_resize_grads.npz")
+    pre = "%s/%d/" % (kind, ci)
+    B, Cn, H, W, s, S = g[pre + "cfg"]
+    B, Cn, H, W, S = int(B), int(Cn), int(H), int(W), int(S)
+    r = _resizer(torch, kind, S)
+    r.set_shape([B, Cn, H, W], scale_factors=[float(s), float(s)])
+    x = torch.tensor(g[pre + "x"].astype(np.float32), device="cuda", requires_grad=True)
+    hs = [torch.tensor(g[pre + "hy"][k], device="cuda", requires_grad=True) for k in range(3 if kind == "gauss" else 1)]
+    o = r.resize(x, *hs)
+    ref = g[pre + "out"]
+    assert np.max(np.abs(o.detach().cpu().numpy() - ref)) <= 5e-4
+    (o * torch.tensor(g[pre + "G"], device="cuda")).sum().backward()
+    for got, want in [(x.grad, g[pre + "gx"])] + [(hs[k].grad, g[pre + "gh%d" % k]) for k in range(len(hs))]:
+        want = np.asarray(want)
+        assert np.max(np.abs(got.cpu().numpy() - want)) <= 1e-3 * max(np.abs(want).max(), 1.0)
+
+
+@pytest.mark.parametrize("kind,S,shape,scale", [("gauss", 2, (3, 9, 7), 2.0), ("gauss", 4, (1, 8, 8), 3.0), ("linear", 2, (2, 6, 10), 1.7)])
+def test_resizer_gradients_finite_differences(torch, kind, S, shape, scale):
+    """the HIP backward against central differences of the float64 HIP forward (same geometry on both sides)."""
+    from lerf_pytorch_amd import ops
+    rng = np.random.default_rng(S + shape[1])
+    N, H, W = shape
+    geo = ops.SrGeometry((H, W), [scale, scale], None, S)
+    x = rng.integers(0, 256, shape).astype(np.float32)
+    nh = 3 if kind == "gauss" else 1
+    hy = (0.2 + 0.6 * rng.random((nh,) + shape)).astype(np.float32)
+    G = rng.standard_normal((N,) + geo.out_hw).astype(np.float32)
+    ms = 10.0 if kind == "gauss" else 1.0
+
+    def f64(xv, hv):
+        o = ops.resize_planar(torch.tensor(xv, device="cuda"), [torch.tensor(h, device="cuda") for h in hv], geo, kind, ms, out="f64")
+        return float((o * torch.tensor(G, device="cuda").double()).sum())
+
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import _ResizeFn
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    ht = [torch.tensor(hy[k], device="cuda", requires_grad=True) for k in range(nh)]
+    (_ResizeFn.apply(geo, kind, ms, xt, *ht) * torch.tensor(G, device="cuda")).sum().backward()
+    eps = 1e-3
+    for _ in range(12):
+        n, y, xx = rng.integers(0, N), rng.integers(0, H), rng.integers(0, W)
+        for k in range(nh):
+            hp, hm = hy.copy(), hy.copy()
+            hp[k, n, y, xx] += eps
+            hm[k, n, y, xx] -= eps
+            fd = (f64(x, hp) - f64(x, hm)) / (2 * eps)
+            an = float(ht[k].grad[n, y, xx])
+            assert abs(fd - an) <= 2e-2 * max(1.0, abs(fd)), (kind, k, fd, an)
+        xp, xm = x.copy(), x.copy()
+        xp[n, y, xx] += 1.0
+        xm[n, y, xx] -= 1.0
+        fd = (f64(xp, hy) - f64(xm, hy)) / 2.0
+        assert abs(fd - float(xt.grad[n, y, xx])) <= 1e-3 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("name", ["lerf-g", "lerf-l"])
+def test_training_step_gradients_golden(torch, golden, name):
+    """train_model.py:416-441 (x2): predict stage 1 -> stage 2 -> resize -> clamp -> MSE; LUT gradients of the reference."""
+    import torch.nn.functional as F
+    g = golden("g10_swf2lut.npz")
+    m = _model(torch, name)
+    x = torch.tensor(g["%s/predict/x" % name], device="cuda")
+    lb = torch.tensor(g["%s/step/lb" % name], device="cuda")
+    feat = m.predict(x, stage=1)
+    hyper = m.predict(feat / 255.0, stage=2)
+    r = _resizer(torch, "gauss" if name == "lerf-g" else "linear", 2)
+    r.set_shape([2, 1, 12, 10], scale_factors=2)
+    pred = r.resize(feat, hyper[:, :1], hyper[:, 1:2], hyper[:, 2:]) if name == "lerf-g" else r.resize(feat, hyper)
+    pred = torch.clamp(pred, 0, 255) / 255.0
+    loss = F.mse_loss(pred, lb)
+    loss.backward()
+    assert abs(loss.item() - float(g["%s/step/loss" % name][0])) <= 1e-6
+    assert np.max(np.abs(pred.detach().cpu().numpy() - g["%s/step/pred" % name])) <= 2e-5
+    for key in ("weight_s1_sr0", "weight_s1_tr0", "weight_s2_cr1", "weight_s2_tr0"):
+        gw = getattr(m, key).grad.cpu().numpy()
+        rows, vals = g["%s/step/%s/rows" % (name, key)], g["%s/step/%s/vals" % (name, key)]
+        scale = max(np.abs(vals).max(), 1e-12)
+        assert np.max(np.abs(gw[rows] - vals)) <= 2e-3 * scale, key
+        other = np.ones(gw.shape[0], bool)
+        other[rows] = False
+        assert np.max(np.abs(gw[other])) <= 1e-6 * scale, key

@@ -152,3 +152,14 @@ def test_strip_plan_property(H, world, S, scale):
         assert p.out_rows()[0] == prev
         prev = p.out_rows()[1]
     assert prev == len(left)
+
+
+@pytest.mark.parametrize("n_in,scale,S", [(6, 3, 2), (17, 3, 4), (33, 1.7, 2), (1080, 2, 2), (10, 2.5, 4), (48, 4, 2), (7, 1.0, 2)])
+def test_torch32_axis_tables_equal_oracle(oracle, n_in, scale, S):
+    """lerf_sr_axis_tables_f32 == the float32 restatement of Resize2dTorch.get_distance (pinned to the reference's
+    tensors when the goldens were generated: tests/golden/gen_golden.py g6 / g9 / g11 outputs depend on them)."""
+    from lerf_pytorch_amd import _lib
+    n_out = oracle.out_size(n_in, scale)
+    left, dis64, dis32, pads = _lib.sr_axis_tables_f32(n_in, n_out, scale, S)
+    rl, rd, plo, phi = oracle.sr_axis_tables_torch32(n_in, n_out, scale, S)
+    assert np.array_equal(left, rl) and np.array_equal(dis64, rd) and pads == (plo, phi)
