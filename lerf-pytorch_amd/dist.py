@@ -122,3 +122,36 @@ def sr_frame_strips(engine, own_rows, H, scale, group=None, gather=False):
     bufs = [torch.empty((b - a,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device) for a, b in counts]
     dist.all_gather(bufs, out.contiguous(), group=group)
     return torch.cat(bufs, dim=0)
+
+
+# --------------------------------------------------------------------------- data-parallel LUT fine-tuning
+def allreduce_grads(model, group=None):
+    """Average the parameter gradients of a fine-tuning model over the ranks: the data-parallel counterpart of the
+    reference's nn.DataParallel wrapper (train_model.py:355-357, gpuNum > 1), one process per GPU.
+
+    The nine LUT gradients (3 x 83521 + 6 x 83521 x oC floats, about 7 MB for LeRF-G) travel as ONE flat bucket -- a
+    single RCCL all-reduce per step; on the point-to-point xGMI ring that is bandwidth-bound and far cheaper than nine
+    latency-bound small ones.  Parameters without a gradient contribute zeros so that every rank reduces the same
+    layout.  No-op for world size 1."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    params = [p for p in model.parameters() if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= world
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n

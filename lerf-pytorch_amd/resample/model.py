@@ -140,3 +140,51 @@ class SWF2LUT(nn.Module):
                     avg_factor, bias, norm = len(self.modes) * 4, self.norm // 2, float(self.norm)
                 x = torch.clamp(round_func((pred / avg_factor)) + bias, 0, self.norm) / norm
         return x
+
+
+def export_luts(model: SWF2LUT, exp_dir: str, lut_name: str = "LUTft"):
+    """Write the fine-tuned int8 LUTs the way train_model.py:481-497 does:
+    `<exp_dir>/<lut_name>_s{stage}_{mode}r{r}.npy = round(clip(weight, -1, 1) * 127).astype(int8)` -- the files
+    eval_lut_sr / eval_lut_warp (here: LutSet.from_dir, LerfEngine) load."""
+    paths = []
+    os.makedirs(exp_dir, exist_ok=True)
+    keys = ["s2_{}r{}".format(m, r) for m in model.modes2 for r in (0, 1)] + ["s1_{}r0".format(m) for m in model.modes]
+    for key in keys:
+        w = getattr(model, "weight_" + key).detach().cpu().numpy()
+        p = os.path.join(exp_dir, "{}_{}.npy".format(lut_name, key))
+        np.save(p, np.round(np.clip(w, -1, 1) * 127).astype(np.int8))
+        paths.append(p)
+    return paths
+
+
+def mulut_predict(model_G, x, stage=1, inC=1):
+    """train_model.py:38-46: the model sees one channel at a time when inC == 1."""
+    if inC == 1:
+        return torch.cat([model_G.predict(x[:, i:i + 1, :, :], stage=stage) for i in range(x.shape[1])], dim=1)
+    return model_G.predict(x, stage=stage)
+
+
+def lutft_step(model_G, resizer, im, lb, opt_G=None, linear=False, norm=255, featC=1, reduce_grads=None):
+    """One LUT fine-tuning iteration, train_model.py:416-442 (`--lutft --twoStage`): stage 1 -> stage 2 -> spatially
+    varying resize -> clamp -> MSE against the HR patch; backward; optimiser step.  `resizer` is a torch-facing
+    resampler with set_shape already called for im's shape.  `reduce_grads(model)` (e.g. dist.allreduce_grads) runs
+    between backward and step for data-parallel training.  Returns the loss tensor."""
+    if opt_G is not None:
+        opt_G.zero_grad()
+    feat_im = mulut_predict(model_G, im, 1)
+    hyper_in = feat_im / float(norm)
+    pred_hyper = mulut_predict(model_G, hyper_in, 2)
+    if linear:
+        pred = resizer.resize(feat_im, pred_hyper)
+    else:
+        pred = resizer.resize(feat_im, pred_hyper[:, :1 * featC, :, :], pred_hyper[:, 1 * featC:2 * featC, :, :],
+                              pred_hyper[:, 2 * featC:, :, :])
+    pred = torch.clamp(pred, 0, norm) / float(norm)
+    loss_G = F.mse_loss(pred, lb)
+    if loss_G.requires_grad:
+        loss_G.backward()
+        if reduce_grads is not None:
+            reduce_grads(model_G)
+        if opt_G is not None:
+            opt_G.step()
+    return loss_G

@@ -80,3 +80,47 @@ def test_gloo_world2_halo_exchange_and_stitch(tmp_path, oracle, luts_g):
     for r in range(world):
         assert np.load(tmp_path / ("ok_%d.npy" % r)).all()
     assert np.array_equal(np.concatenate(parts, axis=0), full)
+
+
+def _grad_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import torch.nn as nn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lerf_pytorch_amd import dist as ldist
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(torch.zeros(5, 3))
+            self.b = nn.Parameter(torch.zeros(7))
+            self.c = nn.Parameter(torch.zeros(2, 2))          # never receives a gradient on rank 1
+    m = M()
+    m.a.grad = torch.full((5, 3), float(rank + 1))
+    m.b.grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+    if rank == 0:
+        m.c.grad = torch.ones(2, 2)
+    ldist.allreduce_grads(m)
+    q.put((rank, m.a.grad.clone().numpy(), m.b.grad.clone().numpy(), m.c.grad.clone().numpy()))
+    dist.destroy_process_group()
+
+
+def test_allreduce_grads_world2():
+    """flat-bucket gradient averaging of the LUT fine-tuning path (gloo, world size 2)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, a, b, c in res:
+        assert np.allclose(a, 1.5)
+        assert np.allclose(b, np.arange(7) * 1.5)
+        assert np.allclose(c, 0.5)

@@ -205,3 +205,32 @@ def test_training_step_gradients_golden(torch, golden, name):
         other = np.ones(gw.shape[0], bool)
         other[rows] = False
         assert np.max(np.abs(gw[other])) <= 1e-6 * scale, key
+
+
+def test_finetune_steps_reduce_loss_and_export(torch, tmp_path, oracle):
+    """A few Adam steps of lutft_step lower the loss on a fixed batch; export_luts writes int8 files the eval
+    engine loads, and whose stage outputs equal the oracle's on the same files (train_model.py:416-442, 481-497)."""
+    from lerf_pytorch_amd.resample.model import export_luts, lutft_step
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch
+    import lerf_pytorch_amd as L
+    m = _model(torch, "lerf-g")
+    rng = np.random.default_rng(77)
+    # smooth synthetic HR patches, LR = 2x2 box average
+    hr = rng.random((4, 1, 6, 6)).astype(np.float32)
+    hr = np.kron(hr, np.ones((1, 1, 8, 8), np.float32))
+    hr = 0.5 * hr + 0.5 * np.roll(hr, 3, axis=3)
+    lr = hr.reshape(4, 1, 24, 2, 24, 2).mean(axis=(3, 5))
+    im, lb = torch.tensor(lr, device="cuda"), torch.tensor(hr, device="cuda")
+    r = SteeringGaussianResize2dTorch(support_sz=2, device=torch.device("cuda"), max_sigma=10)
+    r.set_shape([4, 1, 24, 24], scale_factors=2)
+    opt_G = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    losses = [float(lutft_step(m, r, im, lb, opt_G).detach()) for _ in range(12)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0] * 0.98, losses
+    paths = export_luts(m, str(tmp_path), "LUTft")
+    assert len(paths) == 9 and all(np.load(p).dtype == np.int8 for p in paths)
+    eng = L.LerfEngine(L.LutSet.from_dir(str(tmp_path), linear=False))
+    img = rng.integers(0, 256, (20, 24, 3), dtype=np.uint8)
+    feat, hq = eng.stages(img)
+    rf, rh = oracle.lut_stages(img, oracle.load_luts(str(tmp_path), linear=False), 3)
+    assert np.array_equal(feat, rf) and np.array_equal(hq, rh)
