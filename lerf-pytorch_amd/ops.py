@@ -21,9 +21,12 @@ class SrGeometry:
     """Separable SR geometry (Resize2dNumpy.set_shape, resize_right2d_numpy.py:18-140)
     as two 1-D tables per axis, resident on the device."""
 
-    def __init__(self, in_hw, scale_factors=None, out_hw=None, support=2, device=None, arithmetic="f64"):
+    def __init__(self, in_hw, scale_factors=None, out_hw=None, support=2, device=None, arithmetic="f64", dis_scale=1.0):
         """arithmetic: "f64" = the numpy classes' float64 tables (normative for the eval path); "torch32" = the
-        float32 tables of the reference's torch classes (resize_right2d_torch.py:48-103), bit-equal to theirs."""
+        float32 tables of the reference's torch classes (resize_right2d_torch.py:48-103), bit-equal to theirs.
+        dis_scale: factor applied to the distances the weights see -- the anti-aliasing of the numpy Gaussian class
+        for down-sampling (`min_scale_factor * dis`, resize_right2d_numpy.py:186-193); `support` is then the enlarged
+        ceil(support / min_scale_factor) of :51-55 (the caller computes it, like the reference's set_scale_and_out_sz)."""
         torch = _torch()
         H, W = int(in_hw[0]), int(in_hw[1])
         if out_hw is not None and scale_factors is None:
@@ -31,8 +34,11 @@ class SrGeometry:
         if not isinstance(scale_factors, (list, tuple)):
             scale_factors = [scale_factors, scale_factors]                 # :33-37
         sh, sw = float(scale_factors[0]), float(scale_factors[1])
-        if sh < 1.0 or sw < 1.0:
-            raise NotImplementedError("down-sampling (anti-aliasing, resize_right2d_numpy.py:51-55) is out of scope")
+        if not (sh > 0.0 and sw > 0.0):
+            raise ValueError("scale factors must be positive")
+        if not 1 <= int(support) <= _lib.LERF_MAX_SUPPORT:
+            raise NotImplementedError("support size {} (after anti-aliasing enlargement) exceeds the kernels' maximum of {}"
+                                      .format(support, _lib.LERF_MAX_SUPPORT))
         if out_hw is None:
             out_hw = (_lib.out_size(H, sh), _lib.out_size(W, sw))          # :41-45
         self.in_hw, self.out_hw, self.scales, self.S = (H, W), (int(out_hw[0]), int(out_hw[1])), (sh, sw), int(support)
@@ -40,6 +46,9 @@ class SrGeometry:
         tables = {"f64": _lib.sr_axis_tables, "torch32": _lib.sr_axis_tables_f32}[arithmetic]
         lr, dr64, dr32, pr = tables(H, self.out_hw[0], sh, self.S)
         lc, dc64, dc32, pc = tables(W, self.out_hw[1], sw, self.S)
+        if float(dis_scale) != 1.0:
+            dr64, dc64 = float(dis_scale) * dr64, float(dis_scale) * dc64
+            dr32, dc32 = dr64.astype(np.float32), dc64.astype(np.float32)
         self.pad_vec = ((0, 0), pr, pc)                                     # :129
         self.host = dict(left_r=lr, dis_r=dr64, dis_r32=dr32, left_c=lc, dis_c=dc64, dis_c32=dc32)
         self._upload()

@@ -22,6 +22,7 @@ def _to_dev(a):
 
 class Resize2dNumpy(object):
     """Geometry holder (reference: resize_right2d_numpy.py:10-140)."""
+    _scales_distances = False
 
     def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
         if pad_mode != "constant":
@@ -49,7 +50,16 @@ class Resize2dNumpy(object):
         scale_factors = [1] * (3 - len(scale_factors)) + list(scale_factors)
         self.in_shape = in_shape
         self.scale_factors = [float(s) for s in scale_factors]
-        self.geo = ops.SrGeometry(in_shape[1:], self.scale_factors[1:], out_hw, self.support_sz)
+        # anti-aliasing for down-sampling (:51-55).  The reference indexes its [C, H, W] scale list with [0] and [1],
+        # i.e. it looks at the channel factor (always 1) and the ROW factor only: a column-only down-sampling gets no
+        # anti-aliasing and the enlargement is ceil(S / sh).  Reproduced.  Like the reference, the enlarged support
+        # and the flag stay on the object: a later set_shape never resets them.
+        if self.scale_factors[0] < 1.0 or self.scale_factors[1] < 1.0:
+            self.antialias = True
+            self.min_scale_factor = min([self.scale_factors[1], self.scale_factors[0]])
+            self.support_sz = ceil(self.support_sz / self.min_scale_factor)
+        dis_scale = self.min_scale_factor if (self.antialias and self._scales_distances) else 1.0
+        self.geo = ops.SrGeometry(in_shape[1:], self.scale_factors[1:], out_hw, self.support_sz, dis_scale=dis_scale)
         self.out_shape = [ceil(self.scale_factors[0] * in_shape[0]), self.geo.out_hw[0], self.geo.out_hw[1]]
         self.in_sz = [in_shape[1], in_shape[2]]
         self.out_sz = [self.geo.out_hw[0], self.geo.out_hw[1]]
@@ -65,6 +75,8 @@ class Resize2dNumpy(object):
 
 
 class SteeringGaussianResize2dNumpy(Resize2dNumpy):
+    _scales_distances = True        # weights = m * sk_weight(..., m * dis_x, m * dis_y) when anti-aliasing (:186-193)
+
     def __init__(self, support_sz=4, device="CPU", pad_mode="constant", max_sigma=10):
         super().__init__(support_sz, device, pad_mode)
         self.max_sigma = max_sigma

@@ -83,6 +83,11 @@ class Resize2dTorch(object):
                           self.geo.out_hw[0], self.geo.out_hw[1]]
         pr, pc = self.geo.pad_vec[1], self.geo.pad_vec[2]
         self.pad_vec = [pr[0], pr[1], pc[0], pc[1]]            # the reference's ordering (:93-95)
+        if tuple(pr) != tuple(pc):
+            # F.pad consumes pad_vec last-dimension first, so the reference pads the columns with the ROW pads and
+            # vice versa (:189); harmless while both are (S/2, S/2) -- every up-sampling -- but a shifted / out-of-range
+            # gather when they differ (some down-samplings).  That case is not reproduced.
+            raise NotImplementedError("row pads {} != column pads {}: the reference mis-pads this geometry".format(pr, pc))
 
     def _run(self, kind, input, hypers, max_sigma):
         _check_dev(input, "input")

@@ -235,8 +235,18 @@ def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss",
     C, H, W = feat.shape
     oH, oW = out_size(H, sh), out_size(W, sw)
     tables = sr_axis_tables if geometry == "f64" else sr_axis_tables_torch32       # torch classes: float32 geometry
+    aa = 1.0
+    if geometry == "f64" and sh < 1.0:
+        # anti-aliasing of the numpy classes (resize_right2d_numpy.py:51-55, 186-193): enlarged support for both
+        # kinds; the Gaussian additionally sees distances scaled by m.  The reference reads scale_factors[0] (channels,
+        # = 1) and [1] (rows) of its [C, H, W] list, so only a ROW factor < 1 triggers it and m = sh.
+        m = min(sh, 1.0)
+        S = math.ceil(S / m)
+        if kind == "gauss":
+            aa = m
     lx, disx, _, _ = tables(H, oH, sh, S)
     ly, disy, _, _ = tables(W, oW, sw, S)
+    disx, disy = aa * disx, aa * disy
     if kind == "gauss":
         rho = np.asarray(p0, np.float32) * 2 - 1
         sx = np.asarray(p1, np.float32) * max_sigma

@@ -466,6 +466,34 @@ def g11_resize_grads():
     print("G11", len(out), os.path.getsize(os.path.join(OUT, "g11_resize_grads.npz")))
 
 
+def g12_downscale():
+    """scale < 1: anti-aliased numpy classes (resize_right2d_numpy.py:51-55, 186-193) and the torch class (none)."""
+    out = {}
+    cases = [(3, 16, 20, 0.5, 0.5, 2), (2, 17, 13, 0.75, 0.5, 2), (1, 24, 24, 0.5, 0.5, 4), (2, 15, 21, 0.6, 0.6, 2), (1, 12, 10, 0.9, 1.5, 2), (1, 12, 20, 1.5, 0.5, 2)]
+    for ci, (Cn, H, W, sh, sw, S) in enumerate(cases):
+        rng = np.random.default_rng(1300 + ci)
+        feat = rng.integers(0, 256, (Cn, H, W)).astype(np.float32)
+        hq = rng.integers(0, 256, (3, Cn, H, W)).astype(np.float32)
+        hy = hq / np.float32(255)
+        r = SteeringGaussianResize2dNumpy(support_sz=S, max_sigma=10)
+        r.set_shape([Cn, H, W], scale_factors=[sh, sw])
+        out["%d/cfg" % ci] = np.array([Cn, H, W, sh, sw, S, r.support_sz], dtype=np.float64)
+        out["%d/feat" % ci] = feat.astype(np.uint8)
+        out["%d/hq" % ci] = hq.astype(np.uint8)
+        out["%d/gauss" % ci] = r.resize(feat, hy[0], hy[1], hy[2])
+        out["%d/pad" % ci] = np.array([r.pad_vec[1][0], r.pad_vec[1][1], r.pad_vec[2][0], r.pad_vec[2][1]])
+        if S == 2:
+            l = AmplifiedLinearResize2dNumpy()
+            l.set_shape([Cn, H, W], scale_factors=[sh, sw])
+            out["%d/linear" % ci] = l.resize(feat, hy[0])
+        t = SteeringGaussianResize2dTorch(support_sz=S, device="cpu", max_sigma=10)
+        t.set_shape([1, Cn, H, W], scale_factors=[sh, sw])
+        out["%d/torch" % ci] = t.resize(torch.tensor(feat[None]), torch.tensor(hy[0][None]), torch.tensor(hy[1][None]),
+                                        torch.tensor(hy[2][None])).numpy()
+    np.savez_compressed(os.path.join(OUT, "g12_downscale.npz"), **out)
+    print("G12", len(out))
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -485,7 +513,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -506,3 +534,5 @@ if __name__ == "__main__":
         g10_swf2lut()
     if "g11" in which:
         g11_resize_grads()
+    if "g12" in which:
+        g12_downscale()

@@ -312,7 +312,9 @@ def test_error_behaviour(torch, eng_g):
     with pytest.raises(ValueError):
         eng_g.sr(np.zeros((8, 8, 3), np.float32), 2)
     with pytest.raises(NotImplementedError):
-        ops.SrGeometry((8, 8), [0.5, 0.5], None, 2)
+        ops.SrGeometry((8, 8), [0.2, 0.2], None, 10)          # anti-aliased support beyond the kernels' maximum (8)
+    with pytest.raises(ValueError):
+        ops.SrGeometry((8, 8), [0.0, 1.0], None, 2)
     with pytest.raises(ValueError):
         ops.lut_stages(torch.zeros((8, 8, 3), dtype=torch.float32, device="cuda"), eng_g.luts)
 
@@ -482,3 +484,64 @@ def test_resize2d_torch_base_class_needs_a_kernel(torch):
     r.set_shape([1, 1, 8, 8], scale_factors=2)
     with pytest.raises(NotImplementedError):
         r.resize(torch.zeros(1, 1, 8, 8, device="cuda"))
+
+
+# ---------------------------------------------------------------- down-sampling
+@pytest.mark.parametrize("ci", range(6))
+def test_downscale_numpy_classes_golden(golden, ci):
+    from lerf_pytorch_amd.resize_right.resize_right2d_numpy import AmplifiedLinearResize2dNumpy, SteeringGaussianResize2dNumpy
+    g = golden("g12_downscale.npz")
+    Cn, H, W, sh, sw, S, S2 = g["%d/cfg" % ci]
+    feat = g["%d/feat" % ci].astype(np.float32)
+    hy = g["%d/hq" % ci].astype(np.float32) / np.float32(255)
+    r = SteeringGaussianResize2dNumpy(support_sz=int(S), max_sigma=10)
+    r.set_shape([int(Cn), int(H), int(W)], scale_factors=[float(sh), float(sw)])
+    assert r.support_sz == int(S2) and r.antialias == (sh < 1.0)
+    assert [r.pad_vec[1][0], r.pad_vec[1][1], r.pad_vec[2][0], r.pad_vec[2][1]] == list(g["%d/pad" % ci])
+    assert np.max(np.abs(r.resize(feat, hy[0], hy[1], hy[2]) - g["%d/gauss" % ci])) <= 1e-9
+    if "%d/linear" % ci in g:
+        l = AmplifiedLinearResize2dNumpy()
+        l.set_shape([int(Cn), int(H), int(W)], scale_factors=[float(sh), float(sw)])
+        np.testing.assert_allclose(l.resize(feat, hy[0]), g["%d/linear" % ci], rtol=0, atol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_downscale_torch_class_golden(torch, golden, ci):
+    """the torch classes do not anti-alias (`if False:`, resize_right2d_torch.py:38-44)."""
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch
+    g = golden("g12_downscale.npz")
+    Cn, H, W, sh, sw, S, S2 = g["%d/cfg" % ci]
+    feat = torch.tensor(g["%d/feat" % ci].astype(np.float32)[None], device="cuda")
+    hy = torch.tensor((g["%d/hq" % ci].astype(np.float32) / np.float32(255))[:, None], device="cuda")
+    t = SteeringGaussianResize2dTorch(support_sz=int(S), device=torch.device("cuda"), max_sigma=10)
+    if ci in (3, 5):  # row pads != column pads there: the reference mis-pads (F.pad order), not reproduced
+        with pytest.raises(NotImplementedError, match="mis-pads"):
+            t.set_shape([1, int(Cn), int(H), int(W)], scale_factors=[float(sh), float(sw)])
+        return
+    t.set_shape([1, int(Cn), int(H), int(W)], scale_factors=[float(sh), float(sw)])
+    o = t.resize(feat, hy[0], hy[1], hy[2]).cpu().numpy()
+    assert np.max(np.abs(o - g["%d/torch" % ci])) <= F32_OBSERVED
+
+
+@pytest.mark.parametrize("model,scale", [("lerf-g", (0.5, 0.5)), ("lerf-g", (0.75, 1.25)), ("lerf-l", (0.6, 0.6))])
+def test_engine_downscale_vs_oracle(eng_g, eng_l, oracle, luts_g, luts_l, model, scale):
+    """LerfEngine.sr with a scale < 1 (falls back from the tile-fused kernel to the direct kernels)."""
+    eng, luts = (eng_g, luts_g) if model == "lerf-g" else (eng_l, luts_l)
+    rng = np.random.default_rng(int(scale[0] * 100))
+    img = rng.integers(0, 256, (40, 52, 3), dtype=np.uint8)
+    from lerf_pytorch_amd.resize_right.resize_right2d_numpy import AmplifiedLinearResize2dNumpy, SteeringGaussianResize2dNumpy
+    feat, hq = eng.stages(img)
+    fc = feat.transpose(2, 0, 1).astype(np.float32)
+    hy = hq.astype(np.float32) / np.float32(255)
+    if model == "lerf-g":
+        want = oracle.resize_params_f32(fc, hy[..., 0].transpose(2, 0, 1), hy[..., 1].transpose(2, 0, 1), hy[..., 2].transpose(2, 0, 1),
+                                        scale[0], scale[1], 2, 10, "gauss")
+        r = SteeringGaussianResize2dNumpy(support_sz=2, max_sigma=10)
+        r.set_shape(list(fc.shape), scale_factors=list(scale))
+        got = r.resize(fc, hy[..., 0].transpose(2, 0, 1), hy[..., 1].transpose(2, 0, 1), hy[..., 2].transpose(2, 0, 1))
+    else:
+        want = oracle.resize_params_f32(fc, hy[..., 0].transpose(2, 0, 1), None, None, scale[0], scale[1], 2, 1, "linear")
+        r = AmplifiedLinearResize2dNumpy()
+        r.set_shape(list(fc.shape), scale_factors=list(scale))
+        got = r.resize(fc, hy[..., 0].transpose(2, 0, 1))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9, equal_nan=True)

@@ -215,3 +215,17 @@ def test_swf2lut_interp_restatement(oracle, golden, luts_g, luts_l, model, mi, m
     rows = g[pre + "gw_rows"]
     assert np.array_equal(np.nonzero(np.abs(gw).sum(1))[0], rows)
     assert np.max(np.abs(gw[rows] - g[pre + "gw_vals"])) <= 2e-5 * np.abs(g[pre + "gw_vals"]).max()
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_downscale_antialias_golden(oracle, golden, ci):
+    """scale < 1 through the reference's numpy classes (anti-aliasing keyed on the ROW factor only, :51-55, 186-193)."""
+    g = golden("g12_downscale.npz")
+    Cn, H, W, sh, sw, S, S2 = g["%d/cfg" % ci]
+    feat = g["%d/feat" % ci].astype(np.float32)
+    hy = g["%d/hq" % ci].astype(np.float32) / np.float32(255)
+    o = oracle.resize_params_f32(feat, hy[0], hy[1], hy[2], sh, sw, int(S), 10, "gauss")
+    assert np.max(np.abs(o - g["%d/gauss" % ci])) <= 1e-9
+    if "%d/linear" % ci in g:
+        o = oracle.resize_params_f32(feat, hy[0], None, None, sh, sw, 2, 1, "linear")
+        np.testing.assert_allclose(o, g["%d/linear" % ci], rtol=0, atol=1e-9, equal_nan=True)
