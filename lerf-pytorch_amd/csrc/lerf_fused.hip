@@ -53,7 +53,9 @@ struct Dims {
     static constexpr int R3 = S / 2;
     static constexpr int HY = TH + 2 * R3, HX = TW + 2 * R3, HP = HX * CH, NH = HY * HP;   // hyper region
     static constexpr int FY = HY + 2 * R2, FX = HX + 2 * R2, FP = FX * CH, NF = FY * FP;   // feat region
-    static constexpr int IY = FY + 2 * R1, IX = FX + 2 * R1, IP = IX * CH, NI = IY * IP;   // input region
+    // input region; its LDS pitch is a dword multiple with room for a 0..3 byte phase, so that interior tiles can be
+    // fetched as aligned dwords (row r of the tile = global bytes from the 4-byte boundary below its first pixel)
+    static constexpr int IY = FY + 2 * R1, IX = FX + 2 * R1, IPB = IX * CH, IP = (IPB + 3 + 3) / 4 * 4, NI = IY * IP;
     static constexpr int up16(int x) { return (x + 15) / 16 * 16; }
     static constexpr int OFF_B = 0;
     static constexpr int OFF_X = up16(NF);                       // stage-dependent area starts here
@@ -357,33 +359,64 @@ sr_fused_kernel(Params P) {
 #ifdef LERF_STAMPS
     if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
 #endif
-    // ---- input tile with clamped coordinates (np.pad(..., 'edge') in every rotated frame);
-    //      every load of a thread is issued before its first LDS store (one L2/HBM latency, not 18)
+    // ---- input tile.  Interior tiles whose rows all start at the same offset from a 4-byte boundary (frame pitch
+    //      and frame stride multiples of 4: every RGB frame whose width is a multiple of 4) are fetched as aligned
+    //      dwords, 5 loads per thread, and land in LDS with that offset as a phase; the other tiles go byte by byte
+    //      with clamped coordinates (np.pad(..., 'edge') in every rotated frame).  Either way every load of a thread is
+    //      issued before its first LDS store (one L2/HBM latency).
+    int cphase = 0;
     {
         uint8_t* Ct = smem + D::OFF_C;
-        constexpr int KI = (D::NI + NT - 1) / NT;
-        uint8_t v[KI];
+        const int64_t row0 = ((int64_t)iy0 * W + ix0) * CH;                     // first byte of the region in the frame
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(img) + (uintptr_t)row0;
+        const bool dwords = interior && ((W * CH) & 3) == 0 && (P.in_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.img) & 3) == 0 &&
+                            (iy0 + D::IY < P.H || (ix0 * CH - (int)(a0 & 3)) + D::IP <= W * CH);   // never read past the frame
+        if (dwords) {
+            cphase = (int)(a0 & 3);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(a0 - (uintptr_t)cphase);
+            constexpr int RD = D::IP / 4, ND = D::IY * RD, KD = (ND + NT - 1) / NT;
+            const int rowdw = (W * CH) >> 2;
+            uint32_t v[KD];
 #pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int p = min(tid + k * NT, D::NI - 1);
-            int ry = p / D::IP;
-            int r3 = p - ry * D::IP;
-            int rx = r3 / CH;
-            int c = r3 - rx * CH;
-            int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
-            v[k] = img[((int64_t)gy * W + gx) * CH + c];
-        }
-        if (D::GEO_EARLY && !EMIT) geo_search();           // table look-ups while the tile loads are in flight
+            for (int k = 0; k < KD; ++k) {
+                const int p = min(tid + k * NT, ND - 1);
+                const int ry = p / RD;
+                v[k] = src[(int64_t)ry * rowdw + (p - ry * RD)];
+            }
+            if (D::GEO_EARLY && !EMIT) geo_search();       // table look-ups while the tile loads are in flight
 #pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int p = tid + k * NT;
-            if (p < D::NI) Ct[p] = v[k];
+            for (int k = 0; k < KD; ++k) {
+                const int p = tid + k * NT;
+                if (p < ND) reinterpret_cast<uint32_t*>(Ct)[p] = v[k];
+            }
+        } else {
+            constexpr int NB = D::IY * D::IPB, KI = (NB + NT - 1) / NT;
+            uint8_t v[KI];
+#pragma unroll
+            for (int k = 0; k < KI; ++k) {
+                const int p = min(tid + k * NT, NB - 1);
+                int ry = p / D::IPB;
+                int r3 = p - ry * D::IPB;
+                int rx = r3 / CH;
+                int c = r3 - rx * CH;
+                int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
+                v[k] = img[((int64_t)gy * W + gx) * CH + c];
+            }
+            if (D::GEO_EARLY && !EMIT) geo_search();
+#pragma unroll
+            for (int k = 0; k < KI; ++k) {
+                const int p = tid + k * NT;
+                if (p < NB) {
+                    const int ry = p / D::IPB;
+                    Ct[ry * D::IP + (p - ry * D::IPB)] = v[k];
+                }
+            }
         }
     }
 
     // ---- stage 1: three byte LUTs, 4 rotations each (eval_lut_sr.py:541-577)
     {
-        const uint8_t* Ct = smem + D::OFF_C;
+        const uint8_t* Ct = smem + D::OFF_C + cphase;
         int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
         int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
         const int div1 = kQ * 3;
