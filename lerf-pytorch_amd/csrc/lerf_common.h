@@ -53,6 +53,25 @@ __host__ __device__ inline int rne_div_clip255(int n, int d) {
     return q > 255 ? 255 : q;
 }
 
+// The same for the two divisors the pipeline uses (48 = 16*3 in stage 1, 192 = 16*12 in stage 2), branch-free:
+// floor(m / d) = (m * 0xAAAB) >> SH exactly for m < 2^17 (0xAAAB / 2^23 exceeds 1/192 by 2.6e-8 relative), and
+// rne(m / d) = floor((m + d/2 - 1 + (floor(m / d) & 1)) / d): the parity term sends exact halves to the even side.
+template <int D>
+__device__ __forceinline__ int rne_div_clip255_c(int n) {
+    static_assert(D == 48 || D == 192, "divisors of the LeRF stages");
+    constexpr int SH = D == 48 ? 21 : 23;
+    const unsigned m = (unsigned)(n > 0 ? n : 0);
+    const unsigned k = __umul24(m, 0xAAABu) >> SH;
+    const unsigned q = __umul24(m + (unsigned)(D / 2 - 1) + (k & 1u), 0xAAABu) >> SH;
+    return (int)(q < 255u ? q : 255u);
+}
+
+__device__ __forceinline__ int rne_div_clip255_fast(int n, int d) {
+    if (d == 48) return rne_div_clip255_c<48>(n);      // d is a compile-time constant at every call site
+    if (d == 192) return rne_div_clip255_c<192>(n);
+    return rne_div_clip255(n, d);
+}
+
 // compare-exchange, descending
 __device__ __forceinline__ void ce_desc(unsigned& a, unsigned& b) {
     unsigned hi = a > b ? a : b;

@@ -257,7 +257,7 @@ __device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src
         int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut, src + a);
         if (PHASE != 0) v += (int)acc16[p];
         if (PHASE == 2)
-            dst8[p] = (uint8_t)rne_div_clip255(v + bias * div, div);
+            dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
         else
             acc16[p] = (int16_t)v;
     }
@@ -730,11 +730,12 @@ sr_fused_kernel(Params P) {
                 int n0 = (int)(accA[k] & 0xFFFFu) - div2;
                 int n2 = (int)(accA[k] >> 16) - div2;
                 int n1 = (int)((k & 1) ? (accB2[k >> 1] >> 16) : (accB2[k >> 1] & 0xFFFFu)) - div2;
-                uint32_t h0 = (uint32_t)rne_div_clip255(n0, div2);
-                uint32_t h1 = (uint32_t)rne_div_clip255(n1, div2);
-                uint32_t h2 = (uint32_t)rne_div_clip255(n2, div2);
-                bool inside;
-                int a = center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, &inside);
+                uint32_t h0 = (uint32_t)rne_div_clip255_fast(n0, div2);
+                uint32_t h1 = (uint32_t)rne_div_clip255_fast(n1, div2);
+                uint32_t h2 = (uint32_t)rne_div_clip255_fast(n2, div2);
+                bool inside = true;
+                int a = (int)((k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu));   // interior tile: the slot's own address
+                if (Hc >= 0) a = center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, &inside);
                 uint32_t fv = inside ? (uint32_t)Bt[a] : 0u;      // zero-padded image outside the frame (:208)
                 Dt[p] = h0 | (h1 << 8) | (h2 << 16) | (fv << 24);
             }
