@@ -1093,17 +1093,6 @@ __global__ void pack_bytes_kernel(const int8_t* __restrict__ src, int8_t* __rest
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < fused::LUT_PAD) dst[i] = i < LERF_LUT_ENTRIES ? src[i] : (int8_t)0;
 }
-__global__ void pack_dwords_kernel(const int8_t* __restrict__ src, uint32_t* __restrict__ dst) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= fused::LUT_PAD) return;
-    uint32_t d = 0;
-    if (i < LERF_LUT_ENTRIES)
-        // e0 -> byte 0, e2 -> byte 2 (one mask gives the 16-bit-spaced pair), e1 -> byte 3 (one shift, no mask)
-        d = (uint32_t)((int)src[i * 3 + 0] + 128) | ((uint32_t)((int)src[i * 3 + 2] + 128) << 16) |
-            ((uint32_t)((int)src[i * 3 + 1] + 128) << 24);
-    dst[i] = d;
-}
-
 int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st) {
     if (L->n_modes1 != 3 || L->n_modes2 != 3) return LERF_EUNSUPPORTED;
     if (L->oC != 1 && L->oC != 3) return LERF_EUNSUPPORTED;

@@ -352,6 +352,23 @@ def test_torch_custom_ops(torch, eng_g):
     o = torch.ops.lerf.resize_gauss(fe, hy[0], hy[1], hy[2], 2.0, 2.0, 2, 10.0)
     assert o.shape == (1, 3, 96, 80)
     assert (o[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).int() - out.int()).abs().max() <= 1
+    M = torch.tensor([[2.05, 0.12, 3.0], [-0.08, 1.95, 4.0], [1.5e-4, -1.0e-4, 1.0]], dtype=torch.float64)
+    w = torch.ops.lerf.warp_fused(x, h, M, 90, 70, 2, 10.0)
+    assert torch.equal(w, eng_g.warp(x, M, (90, 70), return_mask=False)[0])
+
+
+def test_torch_custom_ops_linear(torch, eng_l):
+    from lerf_pytorch_amd import ops, torch_ops
+    h = torch_ops.register_luts(eng_l.luts)
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.integers(0, 256, (30, 44, 3), dtype=np.uint8)).cuda()
+    assert torch.equal(torch.ops.lerf.sr_fused(x, h, 1.5, 2.0, 2, 10.0), eng_l.sr(x, (1.5, 2.0)))
+    feat, hq = torch.ops.lerf.lut_stages(x, h)
+    fe = feat.permute(2, 0, 1).float().unsqueeze(0)
+    al = (hq.float() / 255).permute(3, 2, 0, 1)[0].unsqueeze(0)
+    o = torch.ops.lerf.resize_linear(fe, al, 1.5, 2.0, 1.0)
+    geo = ops.SrGeometry((30, 44), [1.5, 2.0], None, 2)
+    assert torch.equal(o[0], ops.resize_planar(fe[0], [al[0]], geo, "linear", 1.0, out="f32"))
 
 
 def test_full_frame_bytes_equal_cpu_oracle(torch, eng_g, luts_g):
