@@ -470,6 +470,39 @@ static int launch_resize_fixed(const ResizeArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // A7/A8: homographic warp, geometry per output pixel in float64
 // ---------------------------------------------------------------------------
+// Tie guard of the uint8 warps: an output within kTieEps of a half-integer is re-evaluated in float64 with the
+// reference's dtype chain (s3::eval64), like the SR kernels do; `tap(r, c)` returns (k0 | k1<<8 | k2<<16 | val<<24)
+// of the clamped source pixel.
+template <int KIND, int S, typename F>
+__device__ __forceinline__ double warp_eval64(int H, int W, const WarpGeo& g, int lr, int lc, double gr, double gc,
+                                              float max_sigma, F tap) {
+    uint32_t dd[S * S];
+    double dx[S], dy[S];
+#pragma unroll
+    for (int b = 0; b < S; ++b) dx[b] = gr - (double)clampi(lr + b, 0, H - 1);
+#pragma unroll
+    for (int a = 0; a < S; ++a) dy[a] = gc - (double)clampi(lc + a, 0, W - 1);
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int b = 0; b < S; ++b) {
+            const int sr = clampi(lr + b, 0, H - 1) - g.pad_r_lo, sc_ = clampi(lc + a, 0, W - 1) - g.pad_c_lo;
+            const int rcl = clampi(sr, 0, H - 1), ccl = clampi(sc_, 0, W - 1);
+            const uint32_t d = tap(rcl, ccl);
+            dd[a * S + b] = ((sr == rcl) && (sc_ == ccl)) ? d : (d & 0x00FFFFFFu);      // zero image outside the frame
+        }
+    return s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx, dy, max_sigma);
+}
+
+template <int KIND, typename F>
+__device__ __forceinline__ bool warp_tie_guard(float res, int S, int H, int W, const WarpGeo& g, int lr, int lc, double gr,
+                                               double gc, float max_sigma, F tap, uint8_t* dst) {
+    if (!(KIND == LERF_KIND_GAUSS || KIND == LERF_KIND_LINEAR) || !s3::near_tie(res)) return false;
+    if (S == 2) *dst = s3::to_u8_d(warp_eval64<KIND, 2>(H, W, g, lr, lc, gr, gc, max_sigma, tap));
+    else if (S == 4) *dst = s3::to_u8_d(warp_eval64<KIND, 4>(H, W, g, lr, lc, gr, gc, max_sigma, tap));
+    else return false;
+    return true;
+}
 template <typename TI, typename TH, typename TO, typename A, int KIND>
 __global__ void __launch_bounds__(256)
 warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
@@ -528,6 +561,17 @@ warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
     }
     A res = num / den;
     if (KIND == LERF_KIND_GAUSS && emin * (A)0.5 > (A)745.2) res = (A)(0.0 / 0.0);
+    if (sizeof(TI) == 1 && sizeof(TH) == 1 && sizeof(TO) == 1) {
+        auto tap = [&](int rcl, int ccl) -> uint32_t {
+            const int64_t ho = rcl * hy + ccl * hx + c * hc;
+            const uint32_t k0 = (uint32_t)h0[ho];
+            const uint32_t k12 = KIND == LERF_KIND_GAUSS ? (((uint32_t)h1[ho]) << 8) | (((uint32_t)h2[ho]) << 16) : 0u;
+            return k0 | k12 | ((uint32_t)feat[rcl * fy + ccl * fx + c * fc] << 24);
+        };
+        if (warp_tie_guard<KIND>((float)res, S, H, W, g, lr, lc, gr, gc, (float)max_sigma, tap,
+                                 reinterpret_cast<uint8_t*>(out + i * oy + j * ox + c * oc)))
+            return;
+    }
     Storer<TO>::put(out + i * oy + j * ox + c * oc, res);
 }
 
@@ -634,6 +678,12 @@ warp_packed_kernel(const uint32_t* __restrict__ packed, int H, int W, int C, War
     }
     float res = num / den;
     if (KIND == LERF_KIND_GAUSS && emin * 0.5f > 745.2f) res = __builtin_nanf("");
+    if (sizeof(TO) == 1) {
+        auto tap = [&](int rcl, int ccl) -> uint32_t { return packed[((int64_t)rcl * W + ccl) * C + c]; };
+        if (warp_tie_guard<KIND>(res, S, H, W, g, lr, lc, gr, gc, max_sigma, tap,
+                                 reinterpret_cast<uint8_t*>(out + i * oy + j * ox + c * oc)))
+            return;
+    }
     Storer<TO>::put(out + i * oy + j * ox + c * oc, res);
 }
 

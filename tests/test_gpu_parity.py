@@ -6,7 +6,7 @@ Tolerances
   * stage 3, float64 outputs:        <= 1e-9 absolute (0..255 scale)
   * stage 3, float32 outputs:        <= 2.55e-2 absolute (= 1e-4 of the 255 range, north_star's fp32 bound);
                                      the observed maximum is also asserted to stay below 5e-4
-  * uint8 outputs:                   <= 1 LSB, and the Set5 md5s of the reference must match exactly
+  * uint8 outputs:                   the Set5 md5s of the reference must match exactly (SR and warp)
 """
 import hashlib
 import json
@@ -24,8 +24,7 @@ F32_TOL = 2.55e-2
 F32_OBSERVED = 5e-4
 # SR uint8 outputs: float32 arithmetic + a float64 re-evaluation of values within 3e-4 of a half-integer
 # (tie guard, csrc/lerf_stage3.h) -> byte-identical to the reference on every input tested.
-# Warp uint8 outputs: float32 only; the float64 reference rounds a handful of near-ties the other way.
-MISMATCH_FRAC = 5e-5
+# Warp uint8 outputs carry the same guard (warp_tie_guard) and are byte-identical on the valid region as well.
 
 
 @pytest.fixture(scope="module")
@@ -268,9 +267,7 @@ def test_set5_warp_md5_and_mpsnr(oracle, luts_g, luts_l, eng_g, eng_l, model, p)
         ref8 = oracle.warp_pipeline(lr, luts_g if model == "lerf-g" else luts_l, np.array(r["matrix"]), gt.shape[:2],
                                     linear=(model == "lerf-l"))
         assert _md5(ref8 * mask) == r["md5_out_masked"]
-        d = np.abs((o8 * mask).astype(int) - (ref8 * mask).astype(int))
-        assert d.max() <= 1                             # warp stage 3 is float32 without a tie guard
-        assert (d != 0).sum() <= MISMATCH_FRAC * d.size + 1
+        assert _md5(o8 * mask) == r["md5_out_masked"]   # the reference's own bytes (float32 + float64 tie guard)
         m = oracle.mpsnr(o8, gt, mask)
         assert abs(m - r["mpsnr"]) <= 0.01
         ms.append(m)
