@@ -687,9 +687,108 @@ warp_packed_kernel(const uint32_t* __restrict__ packed, int H, int W, int C, War
     Storer<TO>::put(out + i * oy + j * ox + c * oc, res);
 }
 
+// The same, one thread per output PIXEL of an RGB frame with S = 2: the float64 projection, the support and the
+// four tap positions / distances are computed once and shared by the three channels (the per-channel kernel above
+// spends most of its time repeating the two float64 divisions of the projection).
+template <typename TO, int KIND>
+__global__ void __launch_bounds__(256)
+warp_packed_px_kernel(const uint32_t* __restrict__ packed, int H, int W, WarpGeo g, float max_sigma,
+                      TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+    constexpr int S = 2, C = 3;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= g.oW) return;
+    double gr, gc;
+    project_point(g.minv, i, j, H, W, &gr, &gc);
+    const int lr = left_boundary(gr, S) + g.pad_r_lo;
+    const int lc = left_boundary(gc, S) + g.pad_c_lo;
+    gr += (double)g.pad_r_lo;
+    gc += (double)g.pad_c_lo;
+    int64_t pos[S * S];
+    float dx[S], dy[S];
+    int cx[S], cy[S];
+    bool in_r[S], in_c[S];
+    int rrow[S], rcol[S];
+#pragma unroll
+    for (int b = 0; b < S; ++b) {
+        const int pr = clampi(lr + b, 0, H - 1);
+        const double d = gr - (double)pr;
+        dx[b] = (float)d;
+        cx[b] = dist_class(d);
+        const int sr = pr - g.pad_r_lo;
+        rrow[b] = clampi(sr, 0, H - 1);
+        in_r[b] = sr == rrow[b];
+    }
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+        const int pc = clampi(lc + a, 0, W - 1);
+        const double d = gc - (double)pc;
+        dy[a] = (float)d;
+        cy[a] = dist_class(d);
+        const int sc_ = pc - g.pad_c_lo;
+        rcol[a] = clampi(sc_, 0, W - 1);
+        in_c[a] = sc_ == rcol[a];
+    }
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int b = 0; b < S; ++b) pos[a * S + b] = ((int64_t)rrow[b] * W + rcol[a]) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        uint32_t d[S * S];
+#pragma unroll
+        for (int t = 0; t < S * S; ++t) d[t] = packed[pos[t] + c];
+        float e[S * S], emin = 0.0f, num = 0.0f, den = 0.0f;
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int b = 0; b < S; ++b) {
+                const uint32_t q = d[a * S + b];
+                if (KIND == LERF_KIND_GAUSS) {
+                    e[a * S + b] = s3::gauss_form(s3::u8_over_255((float)(q & 0xFFu)), s3::u8_over_255((float)((q >> 8) & 0xFFu)),
+                                                  s3::u8_over_255((float)((q >> 16) & 0xFFu)), max_sigma, dx[b], dy[a]);
+                    emin = (a == 0 && b == 0) ? e[0] : fminf(e[a * S + b], emin);
+                } else {
+                    const float alpha = s3::lin_alpha_of(s3::u8_over_255((float)(q & 0xFFu)), max_sigma);
+                    e[a * S + b] = s3::lin_factor(alpha, dx[b], cx[b]) * s3::lin_factor(alpha, dy[a], cy[a]);
+                }
+            }
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int b = 0; b < S; ++b) {
+                const float w = KIND == LERF_KIND_GAUSS ? s3::gauss_weight(e[a * S + b], emin) : e[a * S + b];
+                const float val = (in_r[b] && in_c[a]) ? (float)(d[a * S + b] >> 24) : 0.0f;
+                num += w * val;
+                den += w;
+            }
+        float res = num / den;
+        if (KIND == LERF_KIND_GAUSS && emin * 0.5f > 745.2f) res = __builtin_nanf("");
+        TO* dst = out + i * oy + j * ox + c * oc;
+        if (sizeof(TO) == 1) {
+            auto tap = [&](int rcl, int ccl) -> uint32_t { return packed[((int64_t)rcl * W + ccl) * C + c]; };
+            if (warp_tie_guard<KIND>(res, S, H, W, g, lr, lc, gr, gc, max_sigma, tap, reinterpret_cast<uint8_t*>(dst))) continue;
+        }
+        Storer<TO>::put(dst, res);
+    }
+}
+
 int launch_warp_packed(const uint32_t* packed, int H, int W, int C, const WarpGeo& geo, int kind, float max_sigma,
                        void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, hipStream_t st) {
     if (geo.S < 1 || geo.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
+    if (C == 3 && geo.S == 2 && (kind == LERF_KIND_GAUSS || kind == LERF_KIND_LINEAR) &&
+        (out_dtype == LERF_U8 || out_dtype == LERF_F32)) {
+        dim3 blockp(256), gridp((geo.oW + 255) / 256, geo.oH);
+#define LERF_WPX(TO, KIND)                                                                                            \
+    hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND>), gridp, blockp, 0, st, packed, H, W, geo, max_sigma, (TO*)out, oy, ox, oc)
+        if (kind == LERF_KIND_GAUSS) {
+            if (out_dtype == LERF_U8) LERF_WPX(uint8_t, LERF_KIND_GAUSS); else LERF_WPX(float, LERF_KIND_GAUSS);
+        } else {
+            if (out_dtype == LERF_U8) LERF_WPX(uint8_t, LERF_KIND_LINEAR); else LERF_WPX(float, LERF_KIND_LINEAR);
+        }
+#undef LERF_WPX
+        return LERF_OK;
+    }
     dim3 block(256), grid((geo.oW * C + 255) / 256, geo.oH);
 #define LERF_WPK(TO, KIND)                                                                                         \
     hipLaunchKernelGGL((warp_packed_kernel<TO, KIND>), grid, block, 0, st, packed, H, W, C, geo, max_sigma, (TO*)out, \
