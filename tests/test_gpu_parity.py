@@ -559,3 +559,23 @@ def test_engine_downscale_vs_oracle(eng_g, eng_l, oracle, luts_g, luts_l, model,
         r.set_shape(list(fc.shape), scale_factors=list(scale))
         got = r.resize(fc, hy[..., 0].transpose(2, 0, 1))
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-9, equal_nan=True)
+
+
+def test_streaming_sr_matches_engine(torch, eng_g):
+    """host -> host pipeline (kernel I/O on pinned host memory) returns the same bytes as the synchronous engine."""
+    from lerf_pytorch_amd.stream import StreamingSR
+    rng = np.random.default_rng(12)
+    batches = [rng.integers(0, 256, (2, 40, 52, 3), dtype=np.uint8) for _ in range(5)]
+    st = StreamingSR(eng_g, (40, 52), 2, frames_per_batch=2, depth=2)
+    outs = [o.copy() for o in st.run(batches)]
+    assert len(outs) == 5
+    for b, o in zip(batches, outs):
+        assert np.array_equal(o, eng_g.sr(torch.from_numpy(b).cuda(), 2).cpu().numpy())
+    st.input()[:] = batches[1]                     # producer fills the pinned buffer itself
+    i = st.submit()
+    st.submit(batches[2])
+    with pytest.raises(RuntimeError):
+        st.submit(batches[3])                      # every slot holds an uncollected result
+    assert np.array_equal(st.result(i), outs[1])
+    with pytest.raises(ValueError):
+        st.submit(batches[0][:1])
