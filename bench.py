@@ -183,15 +183,18 @@ def main():
     value = pix_per_step * args.steps / dt / 1e6
     alg_bytes = B * (H * W * C + oH * oW * C) + LUT_BYTES_G          # per launch (fused uint8 path)
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, binding = None, None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile) and not args.unfused:
         try:
             tj = json.load(open(tfile))
             if tj.get("frames") == B and tj.get("input") == args.input:
                 traffic = tj.get("bytes_per_launch")
+                # what actually binds this gather path (rocprofv3 PMC passes of the same command)
+                binding = {k: tj[k] for k in ("valu_instr_per_cu_cycle", "lds_array_busy", "lds_bank_conflict_share", "l2_hit_rate",
+                                              "kernel_trace_avg_us") if k in tj}
         except Exception:
-            traffic = None
+            traffic, binding = None, None
 
     res = {
         "metric": "Mpix/s LeRF-G x2 SR (2K->4K)", "value": round(value, 2), "unit": "Mpix/s",
@@ -205,7 +208,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "gather/VALU-bound path: 3.75 B per output pixel, see DESIGN.md"},
+                     "note": "gather/VALU-bound path: 3.75 B per output pixel, see DESIGN.md",
+                     "binding_resources_from_pmc": binding},
         "mpix_s_other_input": {other: round(other_mpix, 2)} if other_mpix else None,
     }
 
