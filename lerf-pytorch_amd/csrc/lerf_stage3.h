@@ -103,20 +103,25 @@ __device__ __forceinline__ float lin_factor(float alpha, float x, int cls) {
 template <bool GAUSS, int N, bool FAST = false, bool SCALED = false>
 __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]) {
 #pragma clang fp contract(off)
-    float num = 0.0f, den = 0.0f;
+    // the sums start from the first tap (0 + x and fma(w, v, 0) are exact, but without fast-math the compiler keeps them)
+    float num, den;
     if (GAUSS) {
         float emin = e[0];
 #pragma unroll
         for (int k = 1; k < N; ++k) emin = fminf(emin, e[k]);
+        den = SCALED ? gauss_weight_scaled(e[0], emin) : gauss_weight(e[0], emin);
+        num = den * v[0];
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
+        for (int k = 1; k < N; ++k) {
             const float w = SCALED ? gauss_weight_scaled(e[k], emin) : gauss_weight(e[k], emin);
             num = __builtin_fmaf(w, v[k], num);
             den += w;
         }
     } else {
+        den = e[0];
+        num = e[0] * v[0];
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
+        for (int k = 1; k < N; ++k) {
             num = __builtin_fmaf(e[k], v[k], num);
             den += e[k];
         }
