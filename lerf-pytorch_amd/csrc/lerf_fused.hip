@@ -854,7 +854,7 @@ sr_fused_kernel(Params P) {
                             }
                         const float xf = s3::finish<KIND == LERF_KIND_GAUSS, 4, true, true>(e, v);
                         bool tie;
-                        packed[r] |= s3::to_u8_tie(xf, &tie) << (8 * u);
+                        packed[r] = s3::pack_u8_tie(xf, u, packed[r], &tie);
                         if (tie) tiemask |= 1u << (r * 4 + u);
                     }
                 }
@@ -949,7 +949,7 @@ sr_fused_kernel(Params P) {
                 }
                 const float xf = s3::finish<KIND == LERF_KIND_GAUSS, S * S, true, true>(e, v);
                 bool tie;
-                packed |= s3::to_u8_tie(xf, &tie) << (8 * u);
+                packed = s3::pack_u8_tie(xf, u, packed, &tie);
                 if (tie) tiemask |= 1u << u;
             }
             if (tiemask != 0 && P.dis_r64 != nullptr) {

@@ -149,6 +149,14 @@ __device__ __forceinline__ bool near_tie(float x) {
     return __builtin_fabsf(x - __builtin_rintf(x)) > 0.5f - kTieEps;
 }
 
+// byte BYTE of `packed` <- clip(rne(x), 0, 255) with one v_cvt_pk_u8_f32 (saturating convert + byte insert), and
+// the tie test on the same v_rndne
+__device__ __forceinline__ uint32_t pack_u8_tie(float x, int byte, uint32_t packed, bool* tie) {
+    const float r = __builtin_rintf(x);
+    *tie = __builtin_fabsf(x - r) > 0.5f - kTieEps;
+    return __builtin_amdgcn_cvt_pk_u8_f32(r, (unsigned)byte, packed);
+}
+
 // to_u8 and the tie test sharing one v_rndne
 __device__ __forceinline__ uint32_t to_u8_tie(float x, bool* tie) {
     const float r = __builtin_rintf(x);
