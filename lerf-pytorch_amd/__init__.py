@@ -8,5 +8,6 @@ from . import _lib  # noqa: F401
 from ._lib import LerfError, LIB_PATH  # noqa: F401
 from .luts import LutSet, load_lut_arrays  # noqa: F401
 from .pipeline import LerfEngine, sr, warp  # noqa: F401
+from . import metrics, stream  # noqa: F401
 
 __all__ = ["LerfEngine", "LutSet", "load_lut_arrays", "sr", "warp", "LerfError", "LIB_PATH"]
