@@ -112,33 +112,33 @@ class SWF2LUT(nn.Module):
         outC = 1 if stage == 1 else self.outC
         return self.InterpTorchBatch(getattr(self, "weight_" + key), outC, mode, x, pad)
 
+    def _rotation_ensemble(self, x, modes, stage, lut_of_rotation):
+        """Sum over modes and the four quarter-turns of one stage: rotate, replicate-pad bottom/right by the mode's
+        reach, LUT pass, rotate back, straight-through round (model.py:405-412, 419-424)."""
+        total = 0
+        for mode in modes:
+            reach = mode_pad_dict[mode]
+            for quarter_turns in range(4):
+                rotated = F.pad(torch.rot90(x, quarter_turns, [2, 3]), (0, reach, 0, reach), mode="replicate")
+                passed = self.forward(rotated, stage=stage, mode=mode, r=lut_of_rotation(quarter_turns))
+                total = total + round_func(torch.rot90(passed, (4 - quarter_turns) % 4, [2, 3]))
+        return total
+
     def predict(self, x, stage=None):
-        x = round_func(x * 255.0)                               # 8-bit input (:400)
-        if stage == 2:                                          # hyper stage (:403-414)
-            pred = 0
-            for mode in self.modes2:
-                pad = mode_pad_dict[mode]
-                for r in [0, 2]:
-                    pred += round_func(torch.rot90(self.forward(F.pad(torch.rot90(x, r, [2, 3]), (0, pad, 0, pad), mode="replicate"),
-                                                                stage=self.stages, mode=mode, r=0), (4 - r) % 4, [2, 3]))
-                for r in [1, 3]:
-                    pred += round_func(torch.rot90(self.forward(F.pad(torch.rot90(x, r, [2, 3]), (0, pad, 0, pad), mode="replicate"),
-                                                                stage=self.stages, mode=mode, r=1), (4 - r) % 4, [2, 3]))
-            avg_factor, bias, norm = len(self.modes2) * 4, self.norm // 2, float(self.norm)
-            x = torch.clamp(round_func((pred / avg_factor) + bias), 0, self.norm) / norm
-        else:                                                   # stage 1 (:415-429)
-            for s in range(self.stages - 1):
-                pred = 0
-                for mode in self.modes:
-                    pad = mode_pad_dict[mode]
-                    for r in [0, 1, 2, 3]:
-                        pred += round_func(torch.rot90(self.forward(F.pad(torch.rot90(x, r, [2, 3]), (0, pad, 0, pad), mode="replicate"),
-                                                                    stage=s + 1, mode=mode, r=0), (4 - r) % 4, [2, 3]))
-                if s + 1 == self.stages - 1:
-                    avg_factor, bias, norm = len(self.modes), 0, 1
-                else:
-                    avg_factor, bias, norm = len(self.modes) * 4, self.norm // 2, float(self.norm)
-                x = torch.clamp(round_func((pred / avg_factor)) + bias, 0, self.norm) / norm
+        """x in [0, 1]; stage 2 -> hyper-parameter maps in [0, 1] ([B, outC, H, W] per input channel), otherwise the
+        pre-filtered image in 0..255 (model.py:398-431)."""
+        x = round_func(x * 255.0)                                             # 8-bit input
+        if stage == 2:
+            # hyper stage: LUT r0 serves rotations 0 and 2, LUT r1 rotations 1 and 3; mean over 4 x modes, + 127
+            pred = self._rotation_ensemble(x, self.modes2, self.stages, lambda q: q & 1)
+            return torch.clamp(round_func(pred / (len(self.modes2) * 4) + self.norm // 2), 0, self.norm) / float(self.norm)
+        # feature stage(s): one LUT per mode for all four rotations
+        for s in range(self.stages - 1):
+            pred = self._rotation_ensemble(x, self.modes, s + 1, lambda q: 0)
+            if s + 1 == self.stages - 1:        # the last feature stage keeps the 0..255 range (divide by the modes only)
+                x = torch.clamp(round_func(pred / len(self.modes)), 0, self.norm)
+            else:
+                x = torch.clamp(round_func(pred / (len(self.modes) * 4)) + self.norm // 2, 0, self.norm) / float(self.norm)
         return x
 
 
