@@ -96,38 +96,77 @@ interp_fwd_kernel(const float* __restrict__ weight, const float* __restrict__ im
     }
 }
 
-template <int OC>
+// Backward.  One workgroup owns a band of rows of one plane (about 4096 pixels).  Photo-like patches hit very few LUT
+// rows (every pixel of a smooth region lands in the same 16-corner cell), and float atomics to one address serialise at
+// the memory side of the 8 XCDs, so the LUT-row contributions are first summed in an LDS table keyed by the row
+// (open slot claimed with an LDS compare-and-swap, ds_add_f32 into it; a key that finds its slot taken by another row
+// goes to global memory directly) and flushed with one global atomic per occupied entry.  Worst case (uniform noise:
+// more distinct rows than slots) costs what the direct version cost; a smooth batch needs ~20x fewer global atomics.
+template <int OC, int LOG_TS>
 __global__ void __launch_bounds__(256)
 interp_bwd_kernel(const float* __restrict__ weight, const float* __restrict__ img, const float* __restrict__ gout, int n_planes,
-                  int h, int w, int bd, Pattern pt, float* __restrict__ gweight, float* __restrict__ gimg) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, p = blockIdx.z;
-    if (x >= w) return;
+                  int h, int w, int bd, int rows_per_band, int bands, Pattern pt, float* __restrict__ gweight,
+                  float* __restrict__ gimg) {
+    constexpr int TS = 1 << LOG_TS;
+    __shared__ int tag[TS];
+    __shared__ float val[TS * OC];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x / bands, band = blockIdx.x - p * bands;
+    const int y0 = band * rows_per_band, y1 = min(h, y0 + rows_per_band);
+    for (int i = tid; i < TS; i += 256) tag[i] = -1;
+    for (int i = tid; i < TS * OC; i += 256) val[i] = 0.0f;
+    __syncthreads();
     const int wp = w + bd;
     const int64_t poff = (int64_t)p * (h + bd) * wp;
-    const Walk r = walk_at(img + poff, wp, y, x, pt);
-    float gf[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // d loss / d f at sorted position n
+    for (int i = tid; i < (y1 - y0) * w; i += 256) {
+        const int y = y0 + i / w, x = i % w;
+        const Walk r = walk_at(img + poff, wp, y, x, pt);
+        float g[OC], gf[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // gf: d loss / d f at sorted position n
 #pragma unroll
-    for (int oc = 0; oc < OC; ++oc) {
-        const float g = gout[(((int64_t)p * OC + oc) * h + y) * w + x] / (float)kQ;
-        float P[5];
+        for (int oc = 0; oc < OC; ++oc) g[oc] = gout[(((int64_t)p * OC + oc) * h + y) * w + x] / (float)kQ;
+        float Pprev[OC];
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
-            const float wv = weight[(int64_t)r.idx[n] * OC + oc];
-            const float rq = rintf(wv * 127.0f);
-            P[n] = fminf(fmaxf(rq, -127.0f), 127.0f);
-            if (gweight && r.w[n] != 0 && rq >= -127.0f && rq <= 127.0f)
-                atomicAdd(gweight + (int64_t)r.idx[n] * OC + oc, g * (float)r.w[n] * 127.0f);
-        }
+            const int row = r.idx[n];
+            int slot = -1;
+            if (gweight && r.w[n] != 0) {
+                const int s = (int)(((unsigned)row * 2654435761u) >> (32 - LOG_TS));
+                const int old = atomicCAS(&tag[s], -1, row);
+                slot = (old == -1 || old == row) ? s : -2;      // -2: table slot belongs to another row
+            }
 #pragma unroll
-        for (int n = 0; n < 4; ++n) gf[n] += g * (P[n + 1] - P[n]);
-    }
-    if (gimg) {
+            for (int oc = 0; oc < OC; ++oc) {
+                const float rq = rintf(weight[(int64_t)row * OC + oc] * 127.0f);
+                const float Pn = fminf(fmaxf(rq, -127.0f), 127.0f);
+                if (slot != -1 && rq >= -127.0f && rq <= 127.0f) {
+                    const float c = g[oc] * (float)r.w[n] * 127.0f;
+                    if (slot >= 0) atomicAdd(&val[slot * OC + oc], c);
+                    else atomicAdd(gweight + (int64_t)row * OC + oc, c);
+                }
+                if (n > 0) gf[n - 1] += g[oc] * (Pn - Pprev[oc]);
+                Pprev[oc] = Pn;
+            }
+        }
+        if (gimg) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int a = r.axis[n];
-            atomicAdd(gimg + poff + (y + pt.ldy[a]) * wp + x + pt.ldx[a], gf[n]);
+            for (int n = 0; n < 4; ++n) {
+                const int a = r.axis[n];
+                atomicAdd(gimg + poff + (y + pt.ldy[a]) * wp + x + pt.ldx[a], gf[n]);
+            }
         }
     }
+    __syncthreads();
+    if (gweight)
+        for (int s = tid; s < TS; s += 256) {
+            const int row = tag[s];
+            if (row >= 0) {
+#pragma unroll
+                for (int oc = 0; oc < OC; ++oc) {
+                    const float v = val[s * OC + oc];
+                    if (v != 0.0f) atomicAdd(gweight + (int64_t)row * OC + oc, v);
+                }
+            }
+        }
 }
 
 
@@ -253,12 +292,19 @@ int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const fl
     if (!make_pattern(mode, &pt)) return LERF_EINVAL;
     for (int k = 0; k < 4; ++k)
         if (pt.dy[k] > bd || pt.dx[k] > bd || pt.ldy[k] > bd || pt.ldx[k] > bd) return LERF_EINVAL;
-    dim3 block(256), grid((w + 255) / 256, h, n_planes);
+    // bands of about 4096 pixels per workgroup
+    int rows_per_band = 4096 / w;
+    if (rows_per_band < 1) rows_per_band = 1;
+    if (rows_per_band > h) rows_per_band = h;
+    const int bands = (h + rows_per_band - 1) / rows_per_band;
+    dim3 block(256), grid((unsigned)(n_planes * bands));
     hipStream_t st = (hipStream_t)stream;
     if (oC == 1)
-        hipLaunchKernelGGL(interp_bwd_kernel<1>, grid, block, 0, st, weight, img, grad_out, n_planes, h, w, bd, pt, grad_weight, grad_img);
+        hipLaunchKernelGGL((interp_bwd_kernel<1, 12>), grid, block, 0, st, weight, img, grad_out, n_planes, h, w, bd, rows_per_band, bands,
+                           pt, grad_weight, grad_img);
     else if (oC == 3)
-        hipLaunchKernelGGL(interp_bwd_kernel<3>, grid, block, 0, st, weight, img, grad_out, n_planes, h, w, bd, pt, grad_weight, grad_img);
+        hipLaunchKernelGGL((interp_bwd_kernel<3, 12>), grid, block, 0, st, weight, img, grad_out, n_planes, h, w, bd, rows_per_band, bands,
+                           pt, grad_weight, grad_img);
     else
         return LERF_EUNSUPPORTED;
     return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;

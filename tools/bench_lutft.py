@@ -19,8 +19,16 @@ for name, linear in (("lerf-g", False), ("lerf-l", True)):
          SteeringGaussianResize2dTorch(support_sz=2, device=torch.device("cuda"), max_sigma=10))
     r.set_shape([B, 1, 48, 48], scale_factors=scale)
     rng = np.random.default_rng(0)
-    im = torch.tensor(rng.random((B, 1, 48, 48), dtype=np.float32), device="cuda")
-    lb = torch.tensor(rng.random((B, 1, int(48 * scale), int(48 * scale)), dtype=np.float32), device="cuda")
+    if os.environ.get("LUTFT_SMOOTH"):          # photo-like patches: strong LUT-row locality, the hard case for the atomics
+        base = rng.random((B, 1, 6, 6), dtype=np.float32)
+        hr = np.kron(base, np.ones((1, 1, int(8 * scale), int(8 * scale)), np.float32))
+        hr = (0.25 * (hr + np.roll(hr, 5, 2) + np.roll(hr, 9, 3) + np.roll(np.roll(hr, 3, 2), 7, 3))).astype(np.float32)
+        S = int(scale)
+        lr = hr.reshape(B, 1, 48, S, 48, S).mean(axis=(3, 5))
+        im, lb = torch.tensor(lr, device="cuda"), torch.tensor(hr, device="cuda")
+    else:
+        im = torch.tensor(rng.random((B, 1, 48, 48), dtype=np.float32), device="cuda")
+        lb = torch.tensor(rng.random((B, 1, int(48 * scale), int(48 * scale)), dtype=np.float32), device="cuda")
     opt_G = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
     for _ in range(3): lutft_step(m, r, im, lb, opt_G, linear=linear)
     torch.cuda.synchronize(); t = time.perf_counter(); n = 20
