@@ -102,23 +102,27 @@ interp_fwd_kernel(const float* __restrict__ weight, const float* __restrict__ im
 // (open slot claimed with an LDS compare-and-swap, ds_add_f32 into it; a key that finds its slot taken by another row
 // goes to global memory directly) and flushed with one global atomic per occupied entry.  Worst case (uniform noise:
 // more distinct rows than slots) costs what the direct version cost; a smooth batch needs ~20x fewer global atomics.
+constexpr int BWD_NT = 1024;     // 16 waves per workgroup: the per-pixel chain (image reads -> LUT reads -> LDS CAS) is latency-bound
 template <int OC, int LOG_TS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 interp_bwd_kernel(const float* __restrict__ weight, const float* __restrict__ img, const float* __restrict__ gout, int n_planes,
-                  int h, int w, int bd, int rows_per_band, int bands, Pattern pt, float* __restrict__ gweight,
+                  int h, int w, int bd, int rows_per_band, int bands, int gim_lds, Pattern pt, float* __restrict__ gweight,
                   float* __restrict__ gimg) {
     constexpr int TS = 1 << LOG_TS;
     __shared__ int tag[TS];
     __shared__ float val[TS * OC];
+    extern __shared__ float gim[];          // image-gradient rows of the band (+ bd rows of pattern reach), when it fits
     const int tid = threadIdx.x;
     const int p = blockIdx.x / bands, band = blockIdx.x - p * bands;
     const int y0 = band * rows_per_band, y1 = min(h, y0 + rows_per_band);
-    for (int i = tid; i < TS; i += 256) tag[i] = -1;
-    for (int i = tid; i < TS * OC; i += 256) val[i] = 0.0f;
-    __syncthreads();
     const int wp = w + bd;
+    const int gim_n = gim_lds ? (y1 - y0 + bd) * wp : 0;
+    for (int i = tid; i < TS; i += BWD_NT) tag[i] = -1;
+    for (int i = tid; i < TS * OC; i += BWD_NT) val[i] = 0.0f;
+    for (int i = tid; i < gim_n; i += BWD_NT) gim[i] = 0.0f;
+    __syncthreads();
     const int64_t poff = (int64_t)p * (h + bd) * wp;
-    for (int i = tid; i < (y1 - y0) * w; i += 256) {
+    for (int i = tid; i < (y1 - y0) * w; i += BWD_NT) {
         const int y = y0 + i / w, x = i % w;
         const Walk r = walk_at(img + poff, wp, y, x, pt);
         float g[OC], gf[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // gf: d loss / d f at sorted position n
@@ -151,13 +155,25 @@ interp_bwd_kernel(const float* __restrict__ weight, const float* __restrict__ im
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int a = r.axis[n];
-                atomicAdd(gimg + poff + (y + pt.ldy[a]) * wp + x + pt.ldx[a], gf[n]);
+                if (gim_lds) atomicAdd(&gim[(y - y0 + pt.ldy[a]) * wp + x + pt.ldx[a]], gf[n]);
+                else atomicAdd(gimg + poff + (y + pt.ldy[a]) * wp + x + pt.ldx[a], gf[n]);
             }
         }
     }
     __syncthreads();
+    if (gimg && gim_lds) {
+        // the band's rows of the plane: exclusive when the plane is one band, shared halo rows otherwise
+        float* dst = gimg + poff + (int64_t)y0 * wp;
+        for (int i = tid; i < gim_n; i += BWD_NT) {
+            const float v = gim[i];
+            if (v != 0.0f) {
+                if (bands == 1) dst[i] += v;
+                else atomicAdd(dst + i, v);
+            }
+        }
+    }
     if (gweight)
-        for (int s = tid; s < TS; s += 256) {
+        for (int s = tid; s < TS; s += BWD_NT) {
             const int row = tag[s];
             if (row >= 0) {
 #pragma unroll
@@ -297,14 +313,17 @@ int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const fl
     if (rows_per_band < 1) rows_per_band = 1;
     if (rows_per_band > h) rows_per_band = h;
     const int bands = (h + rows_per_band - 1) / rows_per_band;
-    dim3 block(256), grid((unsigned)(n_planes * bands));
+    dim3 block(BWD_NT), grid((unsigned)(n_planes * bands));
     hipStream_t st = (hipStream_t)stream;
+    size_t gim_bytes = grad_img ? (size_t)(rows_per_band + bd) * (size_t)(w + bd) * sizeof(float) : 0;
+    const int gim_lds = gim_bytes > 0 && gim_bytes <= 40 * 1024;
+    if (!gim_lds) gim_bytes = 0;
     if (oC == 1)
-        hipLaunchKernelGGL((interp_bwd_kernel<1, 12>), grid, block, 0, st, weight, img, grad_out, n_planes, h, w, bd, rows_per_band, bands,
-                           pt, grad_weight, grad_img);
+        hipLaunchKernelGGL((interp_bwd_kernel<1, 12>), grid, block, gim_bytes, st, weight, img, grad_out, n_planes, h, w, bd, rows_per_band,
+                           bands, gim_lds, pt, grad_weight, grad_img);
     else if (oC == 3)
-        hipLaunchKernelGGL((interp_bwd_kernel<3, 12>), grid, block, 0, st, weight, img, grad_out, n_planes, h, w, bd, rows_per_band, bands,
-                           pt, grad_weight, grad_img);
+        hipLaunchKernelGGL((interp_bwd_kernel<3, 12>), grid, block, gim_bytes, st, weight, img, grad_out, n_planes, h, w, bd, rows_per_band,
+                           bands, gim_lds, pt, grad_weight, grad_img);
     else
         return LERF_EUNSUPPORTED;
     return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
