@@ -581,10 +581,14 @@ sr_fused_kernel(Params P) {
                 const int q = p < D::NH ? (int)((qpack >> (2 * k)) & 3u) : 4;
                 const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2),
                                          m3 = __ballot(q == 3);
-                const unsigned long long mm = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
-                const int cur = q == 0 ? cur0 : (q == 1 ? cur1 : (q == 2 ? cur2 : cur3));
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-                if (q < 4) lst[cur + rank] = (uint16_t)p;
+                // destination of this lane under each quarter (mbcnt adds the wave's running base), then one select:
+                // the masks and bases stay scalar operands instead of being moved into VGPRs for a 64-bit select
+                const int o0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, (unsigned)cur0));
+                const int o1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, (unsigned)cur1));
+                const int o2 = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, (unsigned)cur2));
+                const int o3 = __builtin_amdgcn_mbcnt_hi((unsigned)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m3, (unsigned)cur3));
+                const int o = q == 0 ? o0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
+                if (q < 4) lst[o] = (uint16_t)p;
                 cur0 += __popcll(m0);
                 cur1 += __popcll(m1);
                 cur2 += __popcll(m2);
