@@ -93,6 +93,7 @@ struct Params {
     float max_sigma;
     int s2off[6][6];                 // stage-2 LUT l: feat-tile byte offsets of pixels b,c,d for rotations par, par+2
     uint32_t* emit; int64_t emit_sn;   // EMIT kernels: packed stage outputs, frame stride in dwords
+    uint8_t* feat; int64_t feat_sn;    // two-launch path: stage-1 output [N][H][W][3] between s1_kernel and the FROM_FEAT kernel
     unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
 };
 
@@ -286,12 +287,72 @@ __device__ __forceinline__ int wave_lower_bound(const int* __restrict__ a, int n
 }
 
 
+// ---- input tile -> LDS.  Interior tiles whose rows all start at the same offset from a 4-byte boundary (frame pitch
+//      and frame stride multiples of 4: every RGB frame whose width is a multiple of 4) are fetched as aligned dwords
+//      and land in LDS with that offset as a phase (returned); the other tiles go byte by byte with clamped
+//      coordinates (np.pad(..., 'edge') in every rotated frame).  Every load of a thread is issued before its first
+//      LDS store (one L2/HBM latency); `between()` runs while the loads are in flight.
+template <int IY, int IPB, int IP, typename F>
+__device__ __forceinline__ int load_input_tile(uint8_t* Ct, const uint8_t* __restrict__ img, const Params& P, int H, int W, int iy0,
+                                               int ix0, bool interior, int tid, F between) {
+    int cphase = 0;
+    const int64_t row0 = ((int64_t)iy0 * W + ix0) * CH;                     // first byte of the region in the frame
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(img) + (uintptr_t)row0;
+    const bool dwords = interior && ((W * CH) & 3) == 0 && (P.in_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.img) & 3) == 0 &&
+                        (iy0 + IY < P.H || (ix0 * CH - (int)(a0 & 3)) + IP <= W * CH);   // never read past the frame
+    if (dwords) {
+        cphase = (int)(a0 & 3);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a0 - (uintptr_t)cphase);
+        constexpr int RD = IP / 4, ND = IY * RD, KD = (ND + NT - 1) / NT;
+        const int rowdw = (W * CH) >> 2;
+        uint32_t v[KD];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const int p = min(tid + k * NT, ND - 1);
+            const int ry = p / RD;
+            v[k] = src[(int64_t)ry * rowdw + (p - ry * RD)];
+        }
+        between();
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const int p = tid + k * NT;
+            if (p < ND) reinterpret_cast<uint32_t*>(Ct)[p] = v[k];
+        }
+    } else {
+        constexpr int NB = IY * IPB, KI = (NB + NT - 1) / NT;
+        uint8_t v[KI];
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int p = min(tid + k * NT, NB - 1);
+            int ry = p / IPB;
+            int r3 = p - ry * IPB;
+            int rx = r3 / CH;
+            int c = r3 - rx * CH;
+            int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
+            v[k] = img[((int64_t)gy * W + gx) * CH + c];
+        }
+        between();
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int p = tid + k * NT;
+            if (p < NB) {
+                const int ry = p / IPB;
+                Ct[ry * IP + (p - ry * IPB)] = v[k];
+            }
+        }
+    }
+    return cphase;
+}
+
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
 // EMIT = false: the whole SR path.  EMIT = true: stages 1+2 only; the tile's own 64x64 block of
 // (hq0,hq1,hq2,feat) dwords goes to P.emit ([H][W][3] uint32) for the warp kernels / the stage API.
-template <int S, int KIND, bool EMIT>
+// FROM_FEAT = true: stage 1 has been run by s1_kernel over the whole batch; the feat tile (with its halo) is read
+// from P.feat instead of being recomputed from the input tile -- stage 1 then costs 64x64 instead of 72x72 positions
+// per tile (-21 % of its work) for 6 bytes of extra HBM traffic per LR pixel.
+template <int S, int KIND, bool EMIT, bool FROM_FEAT = false>
 __global__ void __launch_bounds__(NT)
 sr_fused_kernel(Params P) {
     using D = Dims<S>;
@@ -319,7 +380,8 @@ sr_fused_kernel(Params P) {
     int* ctl = reinterpret_cast<int*>(smem + D::OFF_CTL);
     // interior tile: the whole input region lies inside the frame, so no coordinate is ever clamped and the
     // centre addresses reduce to a multiply-add (center_addr's H < 0 path); ~80 % of the tiles of a 1080p frame
-    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= P.H && ix0 + D::IX <= P.W;
+    const bool interior = FROM_FEAT ? (fy0 >= 0 && fx0 >= 0 && fy0 + D::FY <= P.H && fx0 + D::FX <= P.W)
+                                    : (iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= P.H && ix0 + D::IX <= P.W);
     const int Hc = interior ? -1 : P.H, Wc = P.W;
 
     int* g_lr = reinterpret_cast<int*>(smem + D::OFF_GEO);
@@ -359,60 +421,10 @@ sr_fused_kernel(Params P) {
 #ifdef LERF_STAMPS
     if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
 #endif
-    // ---- input tile.  Interior tiles whose rows all start at the same offset from a 4-byte boundary (frame pitch
-    //      and frame stride multiples of 4: every RGB frame whose width is a multiple of 4) are fetched as aligned
-    //      dwords, 5 loads per thread, and land in LDS with that offset as a phase; the other tiles go byte by byte
-    //      with clamped coordinates (np.pad(..., 'edge') in every rotated frame).  Either way every load of a thread is
-    //      issued before its first LDS store (one L2/HBM latency).
-    int cphase = 0;
-    {
-        uint8_t* Ct = smem + D::OFF_C;
-        const int64_t row0 = ((int64_t)iy0 * W + ix0) * CH;                     // first byte of the region in the frame
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(img) + (uintptr_t)row0;
-        const bool dwords = interior && ((W * CH) & 3) == 0 && (P.in_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.img) & 3) == 0 &&
-                            (iy0 + D::IY < P.H || (ix0 * CH - (int)(a0 & 3)) + D::IP <= W * CH);   // never read past the frame
-        if (dwords) {
-            cphase = (int)(a0 & 3);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(a0 - (uintptr_t)cphase);
-            constexpr int RD = D::IP / 4, ND = D::IY * RD, KD = (ND + NT - 1) / NT;
-            const int rowdw = (W * CH) >> 2;
-            uint32_t v[KD];
-#pragma unroll
-            for (int k = 0; k < KD; ++k) {
-                const int p = min(tid + k * NT, ND - 1);
-                const int ry = p / RD;
-                v[k] = src[(int64_t)ry * rowdw + (p - ry * RD)];
-            }
-            if (D::GEO_EARLY && !EMIT) geo_search();       // table look-ups while the tile loads are in flight
-#pragma unroll
-            for (int k = 0; k < KD; ++k) {
-                const int p = tid + k * NT;
-                if (p < ND) reinterpret_cast<uint32_t*>(Ct)[p] = v[k];
-            }
-        } else {
-            constexpr int NB = D::IY * D::IPB, KI = (NB + NT - 1) / NT;
-            uint8_t v[KI];
-#pragma unroll
-            for (int k = 0; k < KI; ++k) {
-                const int p = min(tid + k * NT, NB - 1);
-                int ry = p / D::IPB;
-                int r3 = p - ry * D::IPB;
-                int rx = r3 / CH;
-                int c = r3 - rx * CH;
-                int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
-                v[k] = img[((int64_t)gy * W + gx) * CH + c];
-            }
-            if (D::GEO_EARLY && !EMIT) geo_search();
-#pragma unroll
-            for (int k = 0; k < KI; ++k) {
-                const int p = tid + k * NT;
-                if (p < NB) {
-                    const int ry = p / D::IPB;
-                    Ct[ry * D::IP + (p - ry * D::IPB)] = v[k];
-                }
-            }
-        }
-    }
+    if (!FROM_FEAT) {
+    // ---- input tile (load_input_tile), the geometry search riding behind its loads
+    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, P, H, W, iy0, ix0, interior, tid,
+                                                             [&]() { if (D::GEO_EARLY && !EMIT) geo_search(); });
 
     // ---- stage 1: three byte LUTs, 4 rotations each (eval_lut_sr.py:541-577)
     {
@@ -457,6 +469,52 @@ sr_fused_kernel(Params P) {
         LERF_STAMP(5);
         byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
+        LERF_STAMP(6);
+    }
+    } else {
+        // ---- feat tile (with its halo) from the stage-1 launch; out-of-frame positions take the clamped pixel,
+        //      which is what stage 1 evaluates for them
+        const uint8_t* __restrict__ fsrc = P.feat + frame * P.feat_sn;
+        const bool dwords = interior && (D::FP & 3) == 0 && ((W * CH) & 3) == 0 && (P.feat_sn & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(P.feat) & 3) == 0 && ((fx0 * CH) & 3) == 0;
+        if (dwords) {
+            constexpr int RD = D::FP / 4, ND = D::FY * RD, KD = (ND + NT - 1) / NT;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(fsrc + ((int64_t)fy0 * W + fx0) * CH);
+            const int rowdw = (W * CH) >> 2;
+            uint32_t v[KD];
+#pragma unroll
+            for (int k = 0; k < KD; ++k) {
+                const int p = min(tid + k * NT, ND - 1);
+                const int ry = p / RD;
+                v[k] = src[(int64_t)ry * rowdw + (p - ry * RD)];
+            }
+            if (D::GEO_EARLY && !EMIT) geo_search();
+#pragma unroll
+            for (int k = 0; k < KD; ++k) {
+                const int p = tid + k * NT;
+                if (p < ND) reinterpret_cast<uint32_t*>(Bt)[p] = v[k];
+            }
+        } else {
+            constexpr int KI = (D::NF + NT - 1) / NT;
+            uint8_t v[KI];
+#pragma unroll
+            for (int k = 0; k < KI; ++k) {
+                const int p = min(tid + k * NT, D::NF - 1);
+                const int ry = p / D::FP;
+                const int r3 = p - ry * D::FP;
+                const int rx = r3 / CH;
+                const int gy = clampi(fy0 + ry, 0, H - 1), gx = clampi(fx0 + rx, 0, W - 1);
+                v[k] = fsrc[((int64_t)gy * W + gx) * CH + (r3 - rx * CH)];
+            }
+            if (D::GEO_EARLY && !EMIT) geo_search();
+#pragma unroll
+            for (int k = 0; k < KI; ++k) {
+                const int p = tid + k * NT;
+                if (p < D::NF) Bt[p] = v[k];
+            }
+        }
+        __syncthreads();
+        if (D::GEO_EARLY && !EMIT) geo_stage();
         LERF_STAMP(6);
     }
 
@@ -995,6 +1053,82 @@ sr_fused_kernel(Params P) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// stage 1 alone, one 64x64 block per workgroup with no halo (two-launch path): input tile (block + 3 px) -> the
+// three byte LUTs, 4 rotations each -> feat bytes to P.feat.  Same phases as in sr_fused_kernel.
+// ---------------------------------------------------------------------------
+constexpr int up16c(int x) { return (x + 15) / 16 * 16; }
+struct DimsA {
+    static constexpr int FY = TH, FX = TW, FP = FX * CH, NF = FY * FP;
+    static constexpr int IY = FY + 2 * R1, IX = FX + 2 * R1, IPB = IX * CH, IP = (IPB + 3 + 3) / 4 * 4, NI = IY * IP;
+    static constexpr int OFF_LUT = 0;
+    static constexpr int OFF_C = LUT_PAD;
+    static constexpr int OFF_ACC = OFF_C + up16c(NI);
+    static constexpr int OFF_F = OFF_ACC + up16c(NF * 2);
+    static constexpr int LDS_BYTES = OFF_F + up16c(NF);
+};
+
+__global__ void __launch_bounds__(NT)
+s1_kernel(Params P) {
+    using D = DimsA;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tiles = P.tiles_y * P.tiles_x;
+    const int frame = bid / tiles;
+    bid -= frame * tiles;
+    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const int fy0 = tyi * TH, fx0 = txi * TW;
+    const int iy0 = fy0 - R1, ix0 = fx0 - R1;
+    const int H = P.H, W = P.W;
+    const uint8_t* __restrict__ img = P.img + frame * P.in_sn;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= H && ix0 + D::IX <= W;
+    const int Hc = interior ? -1 : H, Wc = W;
+    uint8_t* Ft = smem + D::OFF_F;
+
+    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, P, H, W, iy0, ix0, interior, tid, []() {});
+    {
+        const uint8_t* Ct = smem + D::OFF_C + cphase;
+        int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
+        int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
+        const int div1 = kQ * 3;
+        constexpr int L1N = (LERF_LUT_ENTRIES + 15) / 16, L1TAIL = L1N - 5 * NT;
+        uint4 n0, n1, n2, n3, n4, n5 = make_uint4(0, 0, 0, 0);
+        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
+        __syncthreads();
+        LERF_S1_LOAD(P.pack + 1 * LUT_PAD);
+        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
+        __syncthreads();
+        LERF_S1_STORE();
+        __syncthreads();
+        LERF_S1_LOAD(P.pack + 2 * LUT_PAD);
+        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
+        __syncthreads();
+        LERF_S1_STORE();
+        __syncthreads();
+        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
+        __syncthreads();
+    }
+    // the block's rows to P.feat
+    uint8_t* __restrict__ fdst = P.feat + frame * P.feat_sn;
+    const int rows = min(TH, H - fy0), cols3 = min(TW, W - fx0) * CH;
+    const bool dwords = cols3 == D::FP && ((W * CH) & 3) == 0 && (P.feat_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.feat) & 3) == 0;
+    if (dwords) {
+        constexpr int RD = D::FP / 4;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(fdst + ((int64_t)fy0 * W + fx0) * CH);
+        const int rowdw = (W * CH) >> 2;
+        for (int i = tid; i < rows * RD; i += NT) {
+            const int r = i / RD;
+            dst[(int64_t)r * rowdw + (i - r * RD)] = reinterpret_cast<const uint32_t*>(Ft)[i];
+        }
+    } else {
+        for (int i = tid; i < rows * cols3; i += NT) {
+            const int r = i / cols3, c3 = i - r * cols3;
+            fdst[((int64_t)(fy0 + r) * W + fx0) * CH + c3] = Ft[r * D::FP + c3];
+        }
+    }
+}
+
 }  // namespace fused
 
 // ---------------------------------------------------------------------------
@@ -1034,12 +1168,30 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
         }
     }
     P.emit = (uint32_t*)a.emit; P.emit_sn = a.emit_sn;
+    P.feat = nullptr; P.feat_sn = 0;
+    const int64_t blocks = (int64_t)a.n * P.tiles_y * P.tiles_x;
+    if (blocks > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
+#ifndef LERF_STAMPS
+    // two launches when the caller's workspace can hold the stage-1 output of the batch: stage 1 without halo
+    // recomputation, then stages 2+3 from it (the diagnostic build keeps the single launch: its stamps live in the workspace)
+    if (!EMIT && a.workspace != nullptr) {
+        P.feat = (uint8_t*)a.workspace;
+        P.feat_sn = ((int64_t)a.H * a.W * a.C + 15) / 16 * 16;
+        auto ka = fused::s1_kernel;
+        auto kb = fused::sr_fused_kernel<S, KIND, false, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                fused::DimsA::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, D::LDS_BYTES) != hipSuccess)
+            return LERF_ELAUNCH;
+        hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(fused::NT), fused::DimsA::LDS_BYTES, st, P);
+        hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(fused::NT), D::LDS_BYTES, st, P);
+        return LERF_OK;
+    }
+#endif
     auto kern = fused::sr_fused_kernel<S, KIND, EMIT>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             D::LDS_BYTES) != hipSuccess)
         return LERF_ELAUNCH;
-    const int64_t blocks = (int64_t)a.n * P.tiles_y * P.tiles_x;
-    if (blocks > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(fused::NT), D::LDS_BYTES, st, P);
     return LERF_OK;
 }
