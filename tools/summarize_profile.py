@@ -8,21 +8,29 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 ks = glob.glob(src + "/stats/*/*kernel_stats.csv")[0]
 shutil.copy(ks, os.path.join(dst, label + "_kernel_stats.csv"))
-out = ["rocprofv3 PMC summary (%s), fused kernel sr_fused_kernel<2,0,false>, command: bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input" % label,
+out = ["rocprofv3 PMC summary (%s), s1_kernel + sr_fused_kernel<2,0,false,true>, command: bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input" % label,
        "(8 frames 1920x1080->3840x2160 per launch, uniform-noise input; one --pmc pass per counter group; mean over the launches of a run)"]
 vals = {}
 for d in sorted(glob.glob(src + "/pmc_*/")):
     f = glob.glob(d + "*/*counter_collection.csv")
     if not f: continue
+    # one bench step = s1_kernel + sr_fused_kernel<.., FROM_FEAT>: counters are summed over the pair
     agg = collections.defaultdict(list)
+    first = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
+        if "s1_kernel" in r["Kernel_Name"]: first[r["Counter_Name"]].append(float(r["Counter_Value"]))
         if "sr_fused" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
+        a = first.get(k, [])
+        if len(a) == len(v):
+            v = [x + y for x, y in zip(v, a)]
         vals[k] = sum(v) / len(v)
-        out.append("%-24s mean %.6g   min %.6g   max %.6g" % (k, vals[k], min(v), max(v)))
+        out.append("%-24s mean %.6g   min %.6g   max %.6g   (per step: both launches)" % (k, vals[k], min(v), max(v)))
+avg = 0.0
 for r in csv.DictReader(open(ks)):
-    if "sr_fused" in r["Name"]:
-        avg = float(r["AverageNs"]); out.append("kernel-trace: %s calls, average %.1f us" % (r["Calls"], avg / 1e3))
+    if "sr_fused" in r["Name"] or "s1_kernel" in r["Name"]:
+        avg += float(r["AverageNs"]); out.append("kernel-trace: %s: %s calls, average %.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+out.append("kernel-trace: one step (stage-1 launch + stages-2/3 launch) = %.1f us" % (avg / 1e3))
 fetch, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
 alg = 250585941
 out += ["", "HBM-side traffic per launch: FETCH_SIZE %.1f MB raw (x2 by the gfx950 rule for 16-B/lane streaming reads = %.1f MB), WRITE_SIZE %.1f MB" % (fetch / 1e6, 2 * fetch / 1e6, write / 1e6),
