@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LERF_ABI_VERSION 1
+#define LERF_ABI_VERSION 2
 #define LERF_MAX_MODES 5          /* s, c, t, d, y  (resample/eval_lut_sr.py:12-18) */
 #define LERF_LUT_ENTRIES 83521    /* 17^4, interval = 4 (resample/eval_lut_sr.py:27-28) */
 #define LERF_MAX_SUPPORT 8
@@ -196,9 +196,11 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
 
 /* Stages 1+2 by the tile-fused kernel (modes "sct"/"sct", C = 3, luts->fused_pack set), `n` frames:
  * packed[(y*W + x)*3 + c] = hq0 | hq1<<8 | hq2<<16 | feat<<24  (hq1, hq2 = 0 for LeRF-L).
- * Same values as lerf_lut_stages_u8, ~4x faster; feeds lerf_warp_packed / lerf_unpack_stages. */
+ * Same values as lerf_lut_stages_u8, ~4x faster; feeds lerf_warp_packed / lerf_unpack_stages.
+ * workspace: optional device scratch of lerf_sr_fused_workspace_bytes(H, W, C, n) bytes (NULL = none): with it stage 1
+ * runs as its own launch without recomputing tile halos, like lerf_sr_fused_u8. */
 int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
-                          const lerf_luts_t* luts, uint32_t* packed, int64_t packed_sn, void* stream);
+                          const lerf_luts_t* luts, uint32_t* packed, int64_t packed_sn, void* workspace, void* stream);
 
 /* packed dwords -> feat uint8 [n_pxch] and hq uint8 [n_pxch][oC] (either may be NULL) */
 int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, void* stream);

@@ -103,7 +103,7 @@ def lib():
     L.lerf_warp.argtypes = [C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo),
                             C.c_int, C.c_double, C.POINTER(Plane), C.c_void_p]
     L.lerf_stages_packed_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
-                                        C.c_void_p, C.c_int64, C.c_void_p]
+                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.lerf_unpack_stages.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lerf_warp_packed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo), C.c_int, C.c_double,
                                    C.POINTER(Plane), C.c_void_p]
@@ -123,7 +123,7 @@ def lib():
                                       C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:          # AttributeError here = the .so does not match include/lerf_hip.h
         getattr(L, name)
-    if L.lerf_abi_version() != 1:
+    if L.lerf_abi_version() != 2:
         raise LerfError("liblerf_hip.so ABI version mismatch")
     _lib = L
     return L

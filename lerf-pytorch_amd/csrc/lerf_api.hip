@@ -273,12 +273,12 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int 
 }
 
 int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts,
-                          uint32_t* packed, int64_t packed_sn, void* stream) {
+                          uint32_t* packed, int64_t packed_sn, void* workspace, void* stream) {
     if (!img || !luts || !packed || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
     FusedArgs f{};
     f.img = img; f.in_sn = in_sn; f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts;
     f.S = 2; f.oH = H; f.oW = W; f.kind = luts->oC == 3 ? LERF_KIND_GAUSS : LERF_KIND_LINEAR;
-    f.emit = packed; f.emit_sn = packed_sn;
+    f.emit = packed; f.emit_sn = packed_sn; f.workspace = workspace;
     if (!fused_stages_supported(f)) return LERF_EUNSUPPORTED;
     int rc = launch_stages_fused(f, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();

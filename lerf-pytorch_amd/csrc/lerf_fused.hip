@@ -1174,11 +1174,11 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
 #ifndef LERF_STAMPS
     // two launches when the caller's workspace can hold the stage-1 output of the batch: stage 1 without halo
     // recomputation, then stages 2+3 from it (the diagnostic build keeps the single launch: its stamps live in the workspace)
-    if (!EMIT && a.workspace != nullptr) {
+    if (a.workspace != nullptr) {
         P.feat = (uint8_t*)a.workspace;
         P.feat_sn = ((int64_t)a.H * a.W * a.C + 15) / 16 * 16;
         auto ka = fused::s1_kernel;
-        auto kb = fused::sr_fused_kernel<S, KIND, false, true>;
+        auto kb = fused::sr_fused_kernel<S, KIND, EMIT, true>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 fused::DimsA::LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, D::LDS_BYTES) != hipSuccess)

@@ -163,7 +163,7 @@ def lut_stages(img_u8_hwc, luts):
     return feat, hq
 
 
-def stages_packed(img_u8, luts):
+def stages_packed(img_u8, luts, workspace=None):
     """uint8 [H,W,3] / [N,H,W,3] -> int32 [.., H,W,3] packed (hq0 | hq1<<8 | hq2<<16 | feat<<24) by the tile-fused
     stages kernel.  Raises LerfError(unsupported) for configurations it does not cover."""
     torch = _torch()
@@ -173,9 +173,12 @@ def stages_packed(img_u8, luts):
     img = (img_u8.unsqueeze(0) if squeeze else img_u8).contiguous()
     N, H, W, Cn = img.shape
     packed = torch.empty((N, H, W, Cn), dtype=torch.int32, device=img.device)
+    need = _lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(int(need), 1), dtype=torch.uint8, device=img.device)
     _lib.check(_lib.lib().lerf_stages_packed_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(),
-                                                packed.data_ptr(), packed.stride(0), _lib.current_stream()),
-               "lerf_stages_packed_u8")
+                                                packed.data_ptr(), packed.stride(0), workspace.data_ptr(),
+                                                _lib.current_stream()), "lerf_stages_packed_u8")
     return packed[0] if squeeze else packed
 
 
