@@ -230,6 +230,12 @@ __device__ __forceinline__ Tap load_tap(const float* __restrict__ feat, const fl
     return t;
 }
 
+// One workgroup = a 16 x 64 block of outputs of one plane.  Its taps fall into a small window of the input (about
+// 16/s + S rows by 64/s + S columns), so the four gradient maps of that window are accumulated in LDS (ds_add_f32) and
+// flushed with one global atomic per window element: at x4 that is ~40x fewer global atomics than one per tap and map.
+// Windows that do not fit (down-sampling) fall back to global atomics per tap.
+constexpr int RB_ROWS = 16, RB_COLS = 64, RB_WIN_MAX = (RB_ROWS + LERF_MAX_SUPPORT + 1) * (RB_COLS + LERF_MAX_SUPPORT + 1);
+
 template <int KIND>
 __global__ void __launch_bounds__(256)
 resize_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ h0, const float* __restrict__ h1,
@@ -237,46 +243,83 @@ resize_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ h0, 
                   const float* __restrict__ dis_r, const int* __restrict__ left_c, const float* __restrict__ dis_c, float max_sigma,
                   const float* __restrict__ gout, float* __restrict__ gfeat, float* __restrict__ gh0, float* __restrict__ gh1,
                   float* __restrict__ gh2) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, n = blockIdx.z;
-    if (j >= oW) return;
+    __shared__ float win[4][RB_WIN_MAX];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * RB_COLS, i0 = blockIdx.y * RB_ROWS, n = blockIdx.z;
+    const int i1 = min(i0 + RB_ROWS, oH) - 1, j1 = min(j0 + RB_COLS, oW) - 1;
+    // window of clamped source positions touched by this block (left tables are non-decreasing)
+    const int wr0 = clampi(left_r[i0], 0, H - 1), wr1 = clampi(left_r[i1] + S - 1, 0, H - 1);
+    const int wc0 = clampi(left_c[j0], 0, W - 1), wc1 = clampi(left_c[j1] + S - 1, 0, W - 1);
+    const int wh = wr1 - wr0 + 1, ww = wc1 - wc0 + 1;
+    const bool lds = wh * ww <= RB_WIN_MAX;
+    if (lds) {
+        for (int k = tid; k < wh * ww; k += 256) { win[0][k] = 0.0f; win[1][k] = 0.0f; win[2][k] = 0.0f; win[3][k] = 0.0f; }
+        __syncthreads();
+    }
     const int64_t plane = (int64_t)n * H * W;
-    const int lr = left_r[i], lc = left_c[j];
-    float emin = 0.0f;
-    if (KIND == LERF_KIND_GAUSS) {
+    for (int e = tid; e < RB_ROWS * RB_COLS; e += 256) {
+        const int i = i0 + e / RB_COLS, j = j0 + e % RB_COLS;
+        if (i >= oH || j >= oW) continue;
+        const int lr = left_r[i], lc = left_c[j];
+        float emin = 0.0f;
+        if (KIND == LERF_KIND_GAUSS) {
+            for (int a = 0; a < S; ++a)
+                for (int b = 0; b < S; ++b) {
+                    const Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
+                    emin = (a == 0 && b == 0) ? t.w : fminf(emin, t.w);
+                }
+        }
+        float Wsum = 0.0f, num = 0.0f;
         for (int a = 0; a < S; ++a)
             for (int b = 0; b < S; ++b) {
-                const Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
-                emin = (a == 0 && b == 0) ? t.w : fminf(emin, t.w);
+                Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
+                const float w = KIND == LERF_KIND_GAUSS ? __expf(-0.5f * (t.w - emin)) : t.w;
+                Wsum += w;
+                num += w * t.v;
+            }
+        const float out = num / Wsum;
+        const float g = gout[((int64_t)n * oH + i) * oW + j];
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b < S; ++b) {
+                Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
+                const float w = KIND == LERF_KIND_GAUSS ? __expf(-0.5f * (t.w - emin)) : t.w;
+                const int64_t rel = t.pos - plane;
+                const int k = ((int)(rel / W) - wr0) * ww + ((int)(rel % W) - wc0);        // window slot of the clamped tap
+                float gv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (t.inside) gv[0] = g * w / Wsum;
+                const float gw = g * (t.v - out) / Wsum;          // d loss / d w_t
+                if (KIND == LERF_KIND_GAUSS) {
+                    const float c = gw * (-0.5f * w);               // d loss / d e_t
+                    gv[1] = c * (-2.0f * t.tx * t.ty) * 2.0f;
+                    gv[2] = c * (2.0f * t.dx * (t.tx - t.rho * t.ty)) * max_sigma;
+                    gv[3] = c * (2.0f * t.dy * (t.ty - t.rho * t.tx)) * max_sigma;
+                } else {
+                    // clamp(l, 0) passes the gradient where l >= 0 (torch.clamp backward)
+                    const float dlx = (t.lx >= 0.0f ? 1.0f : 0.0f) * (t.dx * ((-1.0f <= t.dx && t.dx < 0.0f) ? 1.0f : 0.0f) - t.dx * ((0.0f <= t.dx && t.dx <= 1.0f) ? 1.0f : 0.0f));
+                    const float dly = (t.ly >= 0.0f ? 1.0f : 0.0f) * (t.dy * ((-1.0f <= t.dy && t.dy < 0.0f) ? 1.0f : 0.0f) - t.dy * ((0.0f <= t.dy && t.dy <= 1.0f) ? 1.0f : 0.0f));
+                    gv[1] = gw * (dlx * t.cy + t.cx * dly) * 2.0f * max_sigma;
+                }
+                float* const dst[4] = {gfeat, gh0, gh1, gh2};
+#pragma unroll
+                for (int m = 0; m < (KIND == LERF_KIND_GAUSS ? 4 : 2); ++m) {
+                    if (!dst[m] || (m == 0 && !t.inside)) continue;
+                    if (lds) atomicAdd(&win[m][k], gv[m]);
+                    else atomicAdd(dst[m] + t.pos, gv[m]);
+                }
             }
     }
-    float Wsum = 0.0f, num = 0.0f;
-    for (int a = 0; a < S; ++a)
-        for (int b = 0; b < S; ++b) {
-            Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
-            const float w = KIND == LERF_KIND_GAUSS ? __expf(-0.5f * (t.w - emin)) : t.w;
-            Wsum += w;
-            num += w * t.v;
-        }
-    const float out = num / Wsum;
-    const float g = gout[((int64_t)n * oH + i) * oW + j];
-    for (int a = 0; a < S; ++a)
-        for (int b = 0; b < S; ++b) {
-            Tap t = load_tap<KIND>(feat, h0, h1, h2, plane, H, W, lr + b, lc + a, dis_r[i * S + b], dis_c[j * S + a], max_sigma);
-            const float w = KIND == LERF_KIND_GAUSS ? __expf(-0.5f * (t.w - emin)) : t.w;
-            if (gfeat && t.inside) atomicAdd(gfeat + t.pos, g * w / Wsum);
-            const float gw = g * (t.v - out) / Wsum;          // d loss / d w_t
-            if (KIND == LERF_KIND_GAUSS) {
-                const float c = gw * (-0.5f * w);               // d loss / d e_t
-                if (gh0) atomicAdd(gh0 + t.pos, c * (-2.0f * t.tx * t.ty) * 2.0f);
-                if (gh1) atomicAdd(gh1 + t.pos, c * (2.0f * t.dx * (t.tx - t.rho * t.ty)) * max_sigma);
-                if (gh2) atomicAdd(gh2 + t.pos, c * (2.0f * t.dy * (t.ty - t.rho * t.tx)) * max_sigma);
-            } else if (gh0) {
-                // clamp(l, 0) passes the gradient where l >= 0 (torch.clamp backward)
-                const float dlx = (t.lx >= 0.0f ? 1.0f : 0.0f) * (t.dx * ((-1.0f <= t.dx && t.dx < 0.0f) ? 1.0f : 0.0f) - t.dx * ((0.0f <= t.dx && t.dx <= 1.0f) ? 1.0f : 0.0f));
-                const float dly = (t.ly >= 0.0f ? 1.0f : 0.0f) * (t.dy * ((-1.0f <= t.dy && t.dy < 0.0f) ? 1.0f : 0.0f) - t.dy * ((0.0f <= t.dy && t.dy <= 1.0f) ? 1.0f : 0.0f));
-                atomicAdd(gh0 + t.pos, gw * (dlx * t.cy + t.cx * dly) * 2.0f * max_sigma);
+    if (lds) {
+        __syncthreads();
+        float* const dst[4] = {gfeat, gh0, gh1, gh2};
+        for (int k = tid; k < wh * ww; k += 256) {
+            const int64_t pos = plane + (int64_t)(wr0 + k / ww) * W + wc0 + k % ww;
+#pragma unroll
+            for (int m = 0; m < (KIND == LERF_KIND_GAUSS ? 4 : 2); ++m) {
+                const float v = win[m][k];
+                if (dst[m] && v != 0.0f) atomicAdd(dst[m] + pos, v);
             }
         }
+    }
 }
 
 }  // namespace train
@@ -337,7 +380,7 @@ int lerf_resize_bwd_f32(const float* feat, const float* h0, const float* h1, con
     if (kind == LERF_KIND_GAUSS && (!h1 || !h2)) return LERF_EINVAL;
     if (!geo->left_r || !geo->left_c || !geo->dis_r || !geo->dis_c || geo->out_h < 1 || geo->out_w < 1) return LERF_EINVAL;
     if (geo->S < 1 || geo->S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
-    dim3 block(256), grid((geo->out_w + 255) / 256, geo->out_h, N);
+    dim3 block(256), grid((geo->out_w + RB_COLS - 1) / RB_COLS, (geo->out_h + RB_ROWS - 1) / RB_ROWS, N);
     hipStream_t st = (hipStream_t)stream;
     if (kind == LERF_KIND_GAUSS)
         hipLaunchKernelGGL(resize_bwd_kernel<LERF_KIND_GAUSS>, grid, block, 0, st, feat, h0, h1, h2, N, H, W, geo->S, geo->out_h,
