@@ -41,6 +41,24 @@ out.append("GRBM_GUI_ACTIVE/8 = %.4g cycles per launch -> effective clock %.2f G
 cu = cyc * 256
 out.append("LDS array busy = SQ_LDS_IDX_ACTIVE / (256 CU x cycles) = %.2f ; bank-conflict share of LDS cycles = %.2f" % (vals["SQ_LDS_IDX_ACTIVE"] / cu, vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]))
 out.append("VALU issue = SQ_INSTS_VALU / (256 CU x cycles) = %.2f wave-instr per CU-cycle (4 SIMDs; 2-cycle and 4-cycle instruction classes, see r01_valu_instruction_rates.txt)" % (vals["SQ_INSTS_VALU"] / cu))
+# per-kernel view of the same counters
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(glob.glob(src + "/pmc_*/")):
+    f = glob.glob(d + "*/*counter_collection.csv")
+    if not f: continue
+    for r in csv.DictReader(open(f[0])):
+        kn = "s1_kernel" if "s1_kernel" in r["Kernel_Name"] else ("sr_fused_kernel" if "sr_fused" in r["Kernel_Name"] else None)
+        if kn: per[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out.append("")
+out.append("per kernel (means per launch):")
+for kn, c in per.items():
+    m = {k: sum(v) / len(v) for k, v in c.items()}
+    if "GRBM_GUI_ACTIVE" not in m: continue
+    cyc_k = m["GRBM_GUI_ACTIVE"] / 8 * 256
+    out.append("  %-16s %.3g cycles; VALU issue %.2f per CU-cycle; LDS array busy %.2f (bank conflicts %.2f of it); L2 hit %.3f; FETCH %.1f MB raw, WRITE %.1f MB"
+               % (kn, m["GRBM_GUI_ACTIVE"] / 8, m["SQ_INSTS_VALU"] / cyc_k, m["SQ_LDS_IDX_ACTIVE"] / cyc_k,
+                  m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"], m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]),
+                  m["FETCH_SIZE"] * 1024 / 1e6, m["WRITE_SIZE"] * 1024 / 1e6))
 open(os.path.join(dst, label + "_pmc_summary.txt"), "w").write("\n".join(out) + "\n")
 json.dump({"frames": 8, "input": "noise", "bytes_per_launch": int(2 * fetch + write),
            "valu_instr_per_cu_cycle": round(vals["SQ_INSTS_VALU"] / cu, 3), "lds_array_busy": round(vals["SQ_LDS_IDX_ACTIVE"] / cu, 3),
