@@ -1129,6 +1129,13 @@ s1_kernel(Params P) {
     }
 }
 
+#undef LERF_S1_LOAD
+#undef LERF_S1_STORE
+#undef LERF_PRE_LOAD
+#undef LERF_PRE_STORE
+#undef LERF_ADDTID
+#undef LERF_ADDTID4
+
 }  // namespace fused
 
 // ---------------------------------------------------------------------------
