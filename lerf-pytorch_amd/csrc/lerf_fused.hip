@@ -889,9 +889,11 @@ sr_fused_kernel(Params P) {
                         v[a * 2 + b] = (float)(d >> 24);
                         const float k0 = (float)(d & 0xFFu);
                         if (KIND == LERF_KIND_GAUSS) {
-                            p0[a * 2 + b] = s3::gauss_m2rho_u8(k0);
+                            // column-only terms of the quadratic form: p0 <- (-2 rho) ty, ty <- ty^2 (gauss_form_cols)
+                            const float tyv = s3::gauss_t_u8((float)((d >> 16) & 0xFFu), dy);
+                            p0[a * 2 + b] = s3::gauss_m2rho_u8(k0) * tyv;
                             k1[a * 2 + b] = (float)((d >> 8) & 0xFFu);
-                            ty[a * 2 + b] = s3::gauss_t_u8((float)((d >> 16) & 0xFFu), dy);
+                            ty[a * 2 + b] = tyv * tyv;
                         } else {
                             const float alpha = s3::lin_alpha_u8(k0, ms255);
                             p0[a * 2 + b] = alpha;
@@ -910,7 +912,7 @@ sr_fused_kernel(Params P) {
                             for (int b = 0; b < 2; ++b) {
                                 const float dx = g_dr[(il0 + r) * 2 + b];
                                 if (KIND == LERF_KIND_GAUSS)
-                                    e[a * 2 + b] = s3::gauss_form_parts(p0[a * 2 + b], s3::gauss_t_u8(k1[a * 2 + b], dx), ty[a * 2 + b]);
+                                    e[a * 2 + b] = s3::gauss_form_cols(s3::gauss_t_u8(k1[a * 2 + b], dx), ty[a * 2 + b], p0[a * 2 + b]);
                                 else
                                     e[a * 2 + b] = s3::lin_factor(p0[a * 2 + b], dx, s3::dist_class_f(dx)) * ty[a * 2 + b];
                             }

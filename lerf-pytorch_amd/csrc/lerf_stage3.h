@@ -57,10 +57,15 @@ __device__ __forceinline__ float gauss_t_u8(float k, float ds) {
 #pragma clang fp contract(off)
     return k * ds;
 }
+// e' = tx^2 + ty^2 - 2 rho tx ty with the two column-only terms ty^2 and (-2 rho ty) formed first, so that output rows
+// sharing their taps pay three operations per tap (tx, two FMAs)
+__device__ __forceinline__ float gauss_form_cols(float tx, float ty2, float mty) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(tx, mty, __builtin_fmaf(tx, tx, ty2));
+}
 __device__ __forceinline__ float gauss_form_parts(float m2rho, float tx, float ty) {
 #pragma clang fp contract(off)
-    float e = __builtin_fmaf(ty, ty, tx * tx);
-    return __builtin_fmaf(m2rho, tx * ty, e);
+    return gauss_form_cols(tx, ty * ty, m2rho * ty);
 }
 __device__ __forceinline__ float gauss_form_u8(float k0, float k1, float k2, float dxs, float dys) {
     return gauss_form_parts(gauss_m2rho_u8(k0), gauss_t_u8(k1, dxs), gauss_t_u8(k2, dys));
