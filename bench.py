@@ -169,13 +169,15 @@ def main():
     other_mpix = None
     if rank == 0 and world == 1 and not args.no_other_input:
         xo = torch.from_numpy(np.ascontiguousarray(np.tile(host[other], (B // 2 + 1, 1, 1, 1))[:B])).cuda()
-        step(xo, out)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(max(3, args.steps // 4)):
+        n_other = max(5, args.steps // 2)
+        for _ in range(2):
             step(xo, out)
         torch.cuda.synchronize()
-        other_mpix = max(3, args.steps // 4) * B * oH * oW / (time.perf_counter() - t1) / 1e6
+        t1 = time.perf_counter()
+        for _ in range(n_other):
+            step(xo, out)
+        torch.cuda.synchronize()
+        other_mpix = n_other * B * oH * oW / (time.perf_counter() - t1) / 1e6
         step(frames, out)
         torch.cuda.synchronize()
 
