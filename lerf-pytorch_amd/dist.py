@@ -62,51 +62,102 @@ class StripPlan:
         return max(lo, 0) >= self.ylo and min(hi, self.H - 1) < self.yhi
 
 
-def exchange_halos(own_rows, plan: StripPlan, group=None):
+class StripBuffer:
+    """Persistent device (or host, for the gloo tests) storage of one rank's strip INCLUDING its halo rows:
+    `ext` [N, yhi-ylo, W, C] is what the fused kernel reads; `own` is the view of the rank's own rows [y0, y1)
+    inside it -- the producer (H2D copy, decoder, previous stage) writes there, so the strip is never copied again.
+    The halo rows travel through two small contiguous staging tensors per direction (RCCL / gloo point-to-point
+    transfers need contiguous memory; a [N, halo] slice of `ext` is not)."""
+
+    def __init__(self, plan: StripPlan, N, W, C, dtype=None, device=None):
+        import torch
+        self.plan = plan
+        dtype = dtype if dtype is not None else torch.uint8
+        self.ext = torch.empty((N, plan.yhi - plan.ylo, W, C), dtype=dtype, device=device)
+        self.own = self.ext[:, plan.need_top:plan.need_top + (plan.y1 - plan.y0)]
+        mk = lambda rows: torch.empty((N, rows, W, C), dtype=dtype, device=device)
+        self.send_up, self.send_dn = mk(plan.halo), mk(plan.halo)
+        self.recv_top, self.recv_bot = mk(plan.need_top), mk(plan.need_bot)
+
+    def exchange(self, group=None):
+        """Fill the halo rows of `ext` from the neighbouring ranks: one send/recv pair per neighbour inside one
+        batch_isend_irecv (= one ncclGroupStart/End on RCCL).  Returns `ext`.  World of 1: no-op."""
+        import torch.distributed as dist
+        p = self.plan
+        if p.world == 1:
+            return self.ext
+        if (p.H // p.world) < p.halo:
+            raise ValueError("strips thinner than the halo (%d rows) are not supported" % p.halo)
+        h = p.y1 - p.y0
+        ops = []
+        if p.rank > 0:                              # exchange with the strip above
+            self.send_up.copy_(self.own[:, :p.halo])
+            ops.append(dist.P2POp(dist.isend, self.send_up, p.rank - 1, group))
+            ops.append(dist.P2POp(dist.irecv, self.recv_top, p.rank - 1, group))
+        if p.rank < p.world - 1:                    # exchange with the strip below
+            self.send_dn.copy_(self.own[:, h - p.halo:])
+            ops.append(dist.P2POp(dist.isend, self.send_dn, p.rank + 1, group))
+            ops.append(dist.P2POp(dist.irecv, self.recv_bot, p.rank + 1, group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if p.need_top:
+            self.ext[:, :p.need_top].copy_(self.recv_top)
+        if p.need_bot:
+            self.ext[:, p.need_top + h:].copy_(self.recv_bot)
+        return self.ext
+
+
+def exchange_halos(own_rows, plan: StripPlan, group=None, buffer: "StripBuffer | None" = None):
     """own_rows: uint8 tensor [y1-y0, W, C] (or [N, y1-y0, W, C]) of this rank's rows.
     Returns the tensor extended to rows [ylo, yhi) after one send/recv pair per neighbour.
+    Convenience form of StripBuffer: the rows are copied once into a (given or fresh) buffer; callers that
+    produce their rows directly into `StripBuffer.own` avoid even that copy.
     Works with any torch.distributed backend; a world of 1 is a no-op."""
-    import torch
-    import torch.distributed as dist
-
     batched = own_rows.dim() == 4
     x = own_rows if batched else own_rows.unsqueeze(0)
     N, h, W, C = x.shape
     assert h == plan.y1 - plan.y0
     if plan.world == 1:
         return own_rows
-    # neighbours' strips may be shorter than the halo only if H/world < halo: not supported
-    if (plan.H // plan.world) < plan.halo:
-        raise ValueError("strips thinner than the halo (%d rows) are not supported" % plan.halo)
-    top = torch.empty((N, plan.need_top, W, C), dtype=x.dtype, device=x.device)
-    bot = torch.empty((N, plan.need_bot, W, C), dtype=x.dtype, device=x.device)
-    ops = []
-    r = plan.rank
-    if r > 0:                                   # exchange with the strip above
-        ops.append(dist.P2POp(dist.isend, x[:, :plan.halo].contiguous(), r - 1, group))
-        ops.append(dist.P2POp(dist.irecv, top, r - 1, group))
-    if r < plan.world - 1:                      # exchange with the strip below
-        ops.append(dist.P2POp(dist.isend, x[:, h - plan.halo:].contiguous(), r + 1, group))
-        ops.append(dist.P2POp(dist.irecv, bot, r + 1, group))
-    for w in dist.batch_isend_irecv(ops):       # one ncclGroupStart/End on RCCL
-        w.wait()
-    out = torch.cat([top, x, bot], dim=1)
+    if buffer is None:
+        buffer = StripBuffer(plan, N, W, C, x.dtype, x.device)
+    buffer.own.copy_(x)
+    out = buffer.exchange(group)
     return out if batched else out[0]
 
 
-def sr_strip(engine, ext_rows, plan: StripPlan, geo):
+def sr_strip(engine, ext_rows, plan: StripPlan, geo, out=None, workspace=None):
     """This rank's output rows [i0, i1) from its extended strip (rows [ylo, yhi)).
     `geo` = the GLOBAL SrGeometry of the frame; its row tables are rebased to the strip."""
     from . import ops
     local = geo.row_slice(plan.ylo, plan.yhi - plan.ylo, plan.i0, plan.i1)
-    return ops.sr_fused_u8(ext_rows, engine.luts, local, engine.kind, engine.max_sigma)
+    return ops.sr_fused_u8(ext_rows, engine.luts, local, engine.kind, engine.max_sigma, out=out, workspace=workspace)
+
+
+def gather_strips(out_rows, counts, group=None):
+    """All ranks' output strips -> the whole frame on every rank.  Strips differ in height whenever H % world != 0
+    or the scale is not an integer; every rank therefore contributes max(rows) rows (its own, zero-padded) to ONE
+    all_gather_into_tensor (equal sizes: a single RCCL all-gather, and gloo accepts it), and the padding is dropped
+    when the frame is assembled.  counts: [(i0, i1)] per rank."""
+    import torch
+    import torch.distributed as dist
+    world = len(counts)
+    rows = [b - a for a, b in counts]
+    m = max(rows)
+    rest = tuple(out_rows.shape[1:])
+    mine = torch.zeros((m,) + rest, dtype=out_rows.dtype, device=out_rows.device)
+    mine[:out_rows.shape[0]].copy_(out_rows)
+    allb = torch.empty((world * m,) + rest, dtype=out_rows.dtype, device=out_rows.device)
+    dist.all_gather_into_tensor(allb, mine, group=group)
+    if all(r == m for r in rows):
+        return allb
+    return torch.cat([allb[r * m:r * m + rows[r]] for r in range(world)], dim=0)
 
 
 def sr_frame_strips(engine, own_rows, H, scale, group=None, gather=False):
     """SR of one H x W frame distributed over the process group by LR strips.
     own_rows: this rank's rows [y0,y1) (uint8 [y1-y0,W,C] on the GPU).  Returns this rank's
     output rows, or the whole frame on every rank if gather=True."""
-    import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -119,9 +170,7 @@ def sr_frame_strips(engine, own_rows, H, scale, group=None, gather=False):
     if not gather or world == 1:
         return out
     counts = [StripPlan(H, world, r, engine.support, geo.host["left_r"]).out_rows() for r in range(world)]
-    bufs = [torch.empty((b - a,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device) for a, b in counts]
-    dist.all_gather(bufs, out.contiguous(), group=group)
-    return torch.cat(bufs, dim=0)
+    return gather_strips(out, counts, group)
 
 
 # --------------------------------------------------------------------------- data-parallel LUT fine-tuning

@@ -87,3 +87,53 @@ def sr_u8(img_u8, luts, sh, sw, S=2, max_sigma=10.0, linear=False, modes="sct", 
     if rc:
         raise ValueError("lerf_oracle_sr_u8 failed")
     return out
+
+
+def warp(feat_u8, hq_u8, matrix, out_hw, S=2, max_sigma=10.0, kind="gauss"):
+    """float64 [oH,oW,C] (NaN where every weight vanishes); kind in gauss / linear / nearest."""
+    feat = np.ascontiguousarray(feat_u8, dtype=np.uint8)
+    H, W, Cn = feat.shape
+    k = {"gauss": 0, "linear": 1, "nearest": 2}[kind]
+    if k == 2:
+        hq, oC, hp = None, 0, None
+    else:
+        hq = np.ascontiguousarray(hq_u8, dtype=np.uint8)
+        oC, hp = hq.shape[3], C.c_void_p(hq.ctypes.data)
+    minv = np.ascontiguousarray(np.linalg.inv(np.asarray(matrix, dtype=np.float64)))
+    out = np.empty((int(out_hw[0]), int(out_hw[1]), Cn), np.float64)
+    rc = lib().lerf_oracle_warp(C.c_void_p(feat.ctypes.data), hp, H, W, Cn, oC, C.c_void_p(minv.ctypes.data),
+                                int(out_hw[0]), int(out_hw[1]), int(S), C.c_double(max_sigma), k,
+                                C.c_void_p(out.ctypes.data))
+    if rc:
+        raise ValueError("lerf_oracle_warp failed")
+    return out
+
+
+def warp_pads(matrix, in_hw, out_hw, S):
+    minv = np.ascontiguousarray(np.linalg.inv(np.asarray(matrix, dtype=np.float64)))
+    pads = (C.c_int * 4)()
+    lib().lerf_oracle_warp_pads(C.c_void_p(minv.ctypes.data), int(in_hw[0]), int(in_hw[1]), int(out_hw[0]), int(out_hw[1]),
+                                int(S), pads)
+    return tuple(int(v) for v in pads)
+
+
+def warp_u8(img_u8, luts, matrix, out_hw, S=2, max_sigma=10.0, linear=False, border=4, modes="sct", modes2="sct",
+            with_mask=True):
+    """uint8 HWC -> (uint8 [oH,oW,C], bool mask [oH,oW,C] or None): the body of eltr._worker in eval_lut_warp.py."""
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    H, W, Cn = img.shape
+    oC = 1 if linear else 3
+    if linear:
+        S, max_sigma = 2, 1.0
+    s1, s2, keep = _lut_ptrs(luts, modes, modes2, oC)
+    minv = np.ascontiguousarray(np.linalg.inv(np.asarray(matrix, dtype=np.float64)))
+    oH, oW = int(out_hw[0]), int(out_hw[1])
+    out = np.empty((oH, oW, Cn), np.uint8)
+    mask = np.empty((oH, oW, Cn), np.uint8) if with_mask else None
+    rc = lib().lerf_oracle_warp_u8(C.c_void_p(img.ctypes.data), H, W, Cn, modes.encode(), len(modes), s1,
+                                   modes2.encode(), len(modes2), s2, oC, C.c_void_p(minv.ctypes.data), oH, oW, int(S),
+                                   C.c_double(max_sigma), 1 if linear else 0, int(border), C.c_void_p(out.ctypes.data),
+                                   C.c_void_p(mask.ctypes.data) if with_mask else None)
+    if rc:
+        raise ValueError("lerf_oracle_warp_u8 failed")
+    return out, (mask.astype(bool) if with_mask else None)

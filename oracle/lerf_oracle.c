@@ -207,6 +207,129 @@ int lerf_oracle_sr_u8(const uint8_t* img, int H, int W, int C, const char* modes
     return rc;
 }
 
+/* ---------------------------------------------------------------------------------------------------------
+ * homographic warp (resize_right/resize_right2d_numpy.py:284-449 geometry, :496-577 Gaussian, :579-636 linear,
+ * :460-467 + interp_methods.py:67-70 nearest/box).  minv: the INVERSE matrix (np.linalg.inv of the caller, :327).
+ * ------------------------------------------------------------------------------------------------------- */
+static inline void project(const double* m, int i, int j, int H, int W, double* gr, double* gc) {
+    /* (x, y, 1) = (col, row, 1); inv(M) . p; perspective divide; flip; clip to [0, in_sz]  (:318-339) */
+    double x = (double)j, y = (double)i;
+    double X = m[0] * x + m[1] * y + m[2];
+    double Y = m[3] * x + m[4] * y + m[5];
+    double Wh = m[6] * x + m[7] * y + m[8];
+    X = X / Wh;
+    Y = Y / Wh;
+    *gr = Y < 0.0 ? 0.0 : (Y > (double)H ? (double)H : Y);
+    *gc = X < 0.0 ? 0.0 : (X > (double)W ? (double)W : X);
+}
+
+static inline int left_of(double g, int S) {
+    const double eps = 1.1920928955078125e-07;
+    return (int)ceil(g - (double)S / 2 - eps);                         /* :344-350 */
+}
+
+/* pads {r_lo, r_hi, c_lo, c_hi} from the two corner pixels only (:363-369) */
+int lerf_oracle_warp_pads(const double* minv, int H, int W, int oH, int oW, int S, int* pads) {
+    double gr, gc;
+    project(minv, 0, 0, H, W, &gr, &gc);
+    int lr0 = left_of(gr, S), lc0 = left_of(gc, S);
+    project(minv, oH - 1, oW - 1, H, W, &gr, &gc);
+    int lr1 = left_of(gr, S), lc1 = left_of(gc, S);
+    pads[0] = -lr0 > 0 ? -lr0 : 0;
+    pads[1] = lr1 + S - 1 - H + 1 > 0 ? lr1 + S - 1 - H + 1 : 0;
+    pads[2] = -lc0 > 0 ? -lc0 : 0;
+    pads[3] = lc1 + S - 1 - W + 1 > 0 ? lc1 + S - 1 - W + 1 : 0;
+    return 0;
+}
+
+static inline double box1(double x) {                                   /* interp_methods.py:67-70 */
+    return (double)(-1 <= x && x < 0) + (double)(0 <= x && x <= 1);
+}
+
+/* feat uint8 [H][W][C], hq uint8 [H][W][C][oC] (NULL for kind 2); out float64 [oH][oW][C] (NaN where every weight
+ * vanishes, the reference's 0/0); kind 0 = gauss, 1 = linear, 2 = nearest (box).
+ * The padded arrays are never materialised: index f into the padded frame = source index f - pad_lo, outside of
+ * which the image is 0 (constant pad) and the hyper maps take the clamped pixel (edge pad) -- with the
+ * reference's quirk that f is clipped to [0, in_sz - 1] in PADDED coordinates (:396-398). */
+int lerf_oracle_warp(const uint8_t* feat, const uint8_t* hq, int H, int W, int C, int oC, const double* minv, int oH, int oW,
+                     int S, double max_sigma, int kind, double* out) {
+    int pads[4];
+    lerf_oracle_warp_pads(minv, H, W, oH, oW, S, pads);
+    const int plr = pads[0], plc = pads[2];
+    const float ms = (float)max_sigma;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < oH; ++i)
+        for (int j = 0; j < oW; ++j) {
+            double gr, gc;
+            project(minv, i, j, H, W, &gr, &gc);
+            const int lr = left_of(gr, S) + plr, lc = left_of(gc, S) + plc;
+            const double grp = gr + (double)plr, gcp = gc + (double)plc;
+            for (int c = 0; c < C; ++c) {
+                double num = 0, den = 0;
+                for (int a = 0; a < S; ++a)
+                    for (int b = 0; b < S; ++b) {
+                        const int fr = clampi(lr + b, 0, H - 1), fc = clampi(lc + a, 0, W - 1);   /* padded coords */
+                        const double dx = grp - (double)fr, dy = gcp - (double)fc;
+                        const int sr = fr - plr, sc = fc - plc;                                     /* source coords */
+                        const int rcl = clampi(sr, 0, H - 1), ccl = clampi(sc, 0, W - 1);
+                        const double val = (sr == rcl && sc == ccl) ? (double)feat[((size_t)rcl * W + ccl) * C + c] : 0.0;
+                        double w;
+                        if (kind == 0) {
+                            const uint8_t* h = hq + (((size_t)rcl * W + ccl) * C + c) * oC;
+                            float h0 = (float)h[0] / 255.0f, h1 = (float)h[1] / 255.0f, h2 = (float)h[2] / 255.0f;
+                            double rho = (double)(h0 * 2.0f - 1.0f), sx = (double)(h1 * ms), sy = (double)(h2 * ms);
+                            double xn = (sx * dx) * (sx * dx), yn = (sy * dy) * (sy * dy), xy = sx * dx * sy * dy;
+                            w = exp(-0.5 * (xn - 2 * rho * xy + yn));
+                        } else if (kind == 1) {
+                            const uint8_t* h = hq + (((size_t)rcl * W + ccl) * C + c) * oC;
+                            float h0 = (float)h[0] / 255.0f;
+                            double al = (double)(ms * (h0 * 2.0f - 1.0f));
+                            double wx = lin_alpha(dx, al), wy = lin_alpha(dy, al);
+                            w = (wx < 0 ? 0 : wx) * (wy < 0 ? 0 : wy);
+                        } else {
+                            w = box1(dx) * box1(dy);
+                        }
+                        num += w * val;
+                        den += w;
+                    }
+                out[((size_t)i * oW + j) * C + c] = num / den;            /* 0/0 -> NaN like numpy */
+            }
+        }
+    return 0;
+}
+
+/* whole warp path of eltr._worker (eval_lut_warp.py:100-233): uint8 HWC in -> uint8 HWC out (NaN -> 0) and the
+ * validity mask (nearest warp of a white frame with a `border`-px black rim, == 255; :197-204, 229).
+ * mask may be NULL. */
+int lerf_oracle_warp_u8(const uint8_t* img, int H, int W, int C, const char* modes1, int n1, const int8_t* const* s1,
+                        const char* modes2, int n2, const int8_t* const* s2, int oC, const double* minv, int oH, int oW,
+                        int S, double max_sigma, int kind, int border, uint8_t* out, uint8_t* mask) {
+    uint8_t* feat = (uint8_t*)malloc((size_t)H * W * C);
+    uint8_t* hq = (uint8_t*)malloc((size_t)H * W * C * oC);
+    double* o = (double*)malloc(sizeof(double) * (size_t)oH * oW * C);
+    if (!feat || !hq || !o) return -1;
+    int rc = lerf_oracle_lut_stages(img, H, W, C, modes1, n1, s1, modes2, n2, s2, oC, feat, hq);
+    if (!rc) rc = lerf_oracle_warp(feat, hq, H, W, C, oC, minv, oH, oW, S, max_sigma, kind, o);
+    const size_t n = (size_t)oH * oW * C;
+    if (!rc)
+        for (size_t k = 0; k < n; ++k) {
+            double r = nearbyint(o[k]);                      /* NaN compares false everywhere -> 0 */
+            out[k] = (uint8_t)(r > 0 ? (r > 255 ? 255 : r) : 0);
+        }
+    if (!rc && mask) {
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                for (int c = 0; c < C; ++c)
+                    feat[((size_t)y * W + x) * C + c] =
+                        (y >= border && y < H - border && x >= border && x < W - border) ? 255 : 0;
+        rc = lerf_oracle_warp(feat, NULL, H, W, C, 0, minv, oH, oW, 1, 1.0, 2, o);
+        if (!rc)
+            for (size_t k = 0; k < n; ++k) mask[k] = o[k] == 255.0;
+    }
+    free(feat); free(hq); free(o);
+    return rc;
+}
+
 int lerf_oracle_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -55,22 +55,34 @@ def _worker(rank, world, port, H, W, scale, tmp):
     own = torch.from_numpy(img[plan.y0:plan.y1].copy())
     ext = ldist.exchange_halos(own, plan)
     ok_halo = np.array_equal(ext.numpy(), img[plan.ylo:plan.yhi])
-    # batched exchange
-    ext2 = ldist.exchange_halos(torch.stack([own, own]), plan)
-    ok_halo = ok_halo and np.array_equal(ext2[1].numpy(), img[plan.ylo:plan.yhi])
-    # per-strip compute with the checker: the strip as its own frame (valid for integer scale), cropped
+    # batched exchange through a persistent StripBuffer: rows are produced straight into `own`, halos arrive in place
+    buf = ldist.StripBuffer(plan, 2, W, 3)
+    for rep in range(2):                                          # reused across steps
+        buf.own.copy_(torch.stack([own, own]))
+        ext2 = buf.exchange()
+        ok_halo = ok_halo and ext2.data_ptr() == buf.ext.data_ptr()
+        ok_halo = ok_halo and np.array_equal(ext2[1].numpy(), img[plan.ylo:plan.yhi])
+    # per-strip compute with the checker: LUT stages on the strip alone (their values are wrong only in the outer
+    # 6 rows of an artificial strip border, which stage 3 of the owned rows never reads), stage 3 with the GLOBAL
+    # geometry -- the strip is pasted into an otherwise empty frame so that non-integer scales partition exactly
     luts = O.load_luts(os.path.join(ASSETS, "lerf-g"))
-    o8 = O.sr_pipeline(ext.numpy(), luts, scale, scale)
-    s = int(scale)
-    mine = o8[plan.i0 - plan.ylo * s:plan.i1 - plan.ylo * s]     # global output rows [i0, i1)
+    feat_s, hq_s = O.lut_stages(ext.numpy(), luts, 3)
+    feat = np.zeros((H, W, 3), np.uint8)
+    hq = np.zeros((H, W, 3, 3), np.uint8)
+    feat[plan.ylo:plan.yhi], hq[plan.ylo:plan.yhi] = feat_s, hq_s
+    mine = O.to_u8(O.resize_u8(feat, hq, scale, scale))[plan.i0:plan.i1]     # global output rows [i0, i1)
+    counts = [ldist.StripPlan(H, world, r, 2, left).out_rows() for r in range(world)]
+    whole = ldist.gather_strips(torch.from_numpy(mine.copy()), counts)        # unequal strips, one equal-size all-gather
     np.save(os.path.join(tmp, "out_%d.npy" % rank), mine)
+    np.save(os.path.join(tmp, "whole_%d.npy" % rank), whole.numpy())
     np.save(os.path.join(tmp, "ok_%d.npy" % rank), np.array([ok_halo, plan.check_support(left)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gloo_world2_halo_exchange_and_stitch(tmp_path, oracle, luts_g):
-    H, W, scale, world = 40, 24, 2.0, 2
+@pytest.mark.parametrize("H,W,scale,world", [(40, 24, 2.0, 2), (45, 20, 1.5, 2), (50, 16, 3.0, 3)])
+def test_gloo_halo_exchange_and_stitch(tmp_path, oracle, luts_g, H, W, scale, world):
+    """world-size 2 and 3, including H % world != 0 and a non-integer scale (unequal output strips)"""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, H, W, scale, str(tmp_path)), nprocs=world, join=True)
     rng = np.random.default_rng(42)
@@ -79,6 +91,7 @@ def test_gloo_world2_halo_exchange_and_stitch(tmp_path, oracle, luts_g):
     parts = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)]
     for r in range(world):
         assert np.load(tmp_path / ("ok_%d.npy" % r)).all()
+        assert np.array_equal(np.load(tmp_path / ("whole_%d.npy" % r)), full)
     assert np.array_equal(np.concatenate(parts, axis=0), full)
 
 
