@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: LeRF-G LUT x2 SR, 1920x1080 -> 3840x2160 RGB (BASELINE.json configs[1]).
+"""Benchmark of the LeRF LUT resampling hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4,5}] [--mode frames|strips]
 
-One "step" = one launch of the hot path (stage-1 LUTs -> stage-2 LUTs -> steering-
-Gaussian resampling, uint8 HWC in / uint8 HWC out) over a batch of `--frames`
-synthetic frames already resident in HBM.  For N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank processes its own batch --
-frames are independent, so there is no collective in the data path (weak
-scaling); the barrier only brackets the timed region.
+Default = BASELINE.json configs[1], the configuration the headline metric is quoted on: LeRF-G LUT x2 SR,
+1920x1080 -> 3840x2160 RGB.  One "step" = one pass of the hot path (stage-1 LUTs -> stage-2 LUTs -> spatially
+varying resampling, uint8 HWC in / uint8 HWC out) over a batch of `--frames` synthetic frames already resident in HBM.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against
-HBM bandwidth using the ALGORITHMIC bytes of SURVEY.md 8(d); `cpu_baseline` is
-the C port of the oracle timed on this box's host cores (rank 0, N = 1 only).
+--gpus N > 1: when not already running under torch.distributed.run (no RANK in the environment) this process
+stays GPU-free and spawns N rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set,
+one rank per GPU, RCCL); a failing rank makes the whole command fail.  Under torch.distributed.run it is one rank.
+  --mode frames (default): every rank processes its own batch -- frames are independent, no data-path collective
+                           (weak scaling; the barrier only brackets the timed region);
+  --mode strips:           every frame is split into LR strips over the ranks with an RCCL halo exchange of raw
+                           uint8 rows (strong scaling on the same batch).
+
+--config: 1 = 256x256 tile through the CPU oracle port (plumbing; 1 thread and all cores) beside the GPU,
+          2 = headline, 3 = LeRF-L x1.5/x2.0 (and x2/x2), 4 = LeRF-G homographic warp 1080p -> 4K (isc / osc
+          matrices of SURVEY.md 8d), 5 = batch of 8 frames 2160x3840 -> 4320x7680 (strips by default when N > 1).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the launch against HBM bandwidth using the ALGORITHMIC bytes of
+SURVEY.md 8(d); `cpu_baseline` is the C port of the oracle timed on this box's host cores (rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,13 +36,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H, W, C = 1080, 1920, 3
-SCALE = 2
-LUT_BYTES_G = 1753941          # 3 x 83521 + 6 x 83521 x 3
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+C = 3
+LUT_BYTES = {"lerf-g": 1753941, "lerf-l": 751689}      # 3 x 83521 + 6 x 83521 x oC
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+M_ISC = [[2.05, 0.12, 15.0], [-0.08, 1.95, 40.0], [1.5e-5, -1.0e-5, 1.0]]
+M_OSC = [[4.1, 0.4, 30.0], [0.5, 3.8, 25.0], [8e-5, 1.2e-4, 1.0]]
 
 
-def synth_frames(kind, n, seed):
+# --------------------------------------------------------------------------------------------- synthetic inputs
+def synth_frames(kind, n, seed, H, W):
     """SURVEY.md 8(d) inputs.  'noise': uniform uint8 (worst case for LUT locality);
     'natural': low-pass field (box blur radius 8, 3 passes) + 5 % uniform noise."""
     rng = np.random.default_rng(seed)
@@ -57,42 +70,138 @@ def synth_frames(kind, n, seed):
     return out
 
 
-def cpu_baseline(frames_u8, budget_s=12.0):
-    """C port of the oracle (oracle/lerf_oracle.c, OpenMP) on this host, bounded sample."""
-    from oracle import c_oracle, lerf_oracle
-    luts = lerf_oracle.load_luts(os.path.join(ROOT, "lerf-pytorch_amd", "assets", "models", "lerf-g"))
+def kernel_source_sha():
+    """sha256 over the HIP sources: ties recorded PMC numbers (profiles/hbm_traffic.json) to the kernels they were
+    measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lerf-pytorch_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline legs
+def _oracle_luts(model):
+    from oracle import lerf_oracle
+    return lerf_oracle.load_luts(os.path.join(ROOT, "lerf-pytorch_amd", "assets", "models", model), linear=model == "lerf-l")
+
+
+def cpu_baseline_sr(frames_u8, model, sh, sw, budget_s=12.0, threads=None, max_n=64):
+    """C port of the oracle (oracle/lerf_oracle.c, OpenMP) on this host, bounded sample.  threads=1: one core."""
+    from oracle import c_oracle
+    luts = _oracle_luts(model)
+    if threads is not None:
+        c_oracle.set_threads(threads)
     thr = c_oracle.threads()
     t0 = time.perf_counter()
     n = 0
     out = None
     while True:
-        out = c_oracle.sr_u8(frames_u8[n % len(frames_u8)], luts, SCALE, SCALE)
+        out = c_oracle.sr_u8(frames_u8[n % len(frames_u8)], luts, sh, sw, linear=model == "lerf-l")
         n += 1
-        if time.perf_counter() - t0 >= budget_s or n >= 64:
+        if time.perf_counter() - t0 >= budget_s or n >= max_n:
             break
     dt = time.perf_counter() - t0
+    H, W = frames_u8.shape[1:3]
     return {
         "value": round(n * out.shape[0] * out.shape[1] / dt / 1e6, 4), "unit": "Mpix/s", "cores": thr, "kind": "port",
         "sample": "%d frame(s) %dx%d->%dx%d, same synthetic input, oracle/lerf_oracle.c (OpenMP, %d threads), %.1f s"
                   % (n, W, H, out.shape[1], out.shape[0], thr, dt),
-    }, out
+    }, out, n
 
 
-def main():
+def cpu_baseline_warp(frame_u8, matrix, out_hw, budget_s=12.0):
+    from oracle import c_oracle
+    luts = _oracle_luts("lerf-g")
+    thr = c_oracle.threads()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        out, mask = c_oracle.warp_u8(frame_u8, luts, matrix, out_hw)
+        n += 1
+        if time.perf_counter() - t0 >= budget_s or n >= 32:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n * out_hw[0] * out_hw[1] / dt / 1e6, 4), "unit": "Mpix/s", "cores": thr, "kind": "port",
+        "sample": "%d frame(s) %dx%d->%dx%d warp + mask, same synthetic input, oracle/lerf_oracle.c (OpenMP, %d threads), %.1f s"
+                  % (n, frame_u8.shape[1], frame_u8.shape[0], out_hw[1], out_hw[0], thr, dt),
+    }, out, mask
+
+
+# --------------------------------------------------------------------------------------------- rank launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """GPU-free parent: start n copies of this command, one rank per GPU, and relay rank 0's JSON line.
+    Nothing in this process has touched HIP (torch is not even imported), so no re-exec hazard exists."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   LERF_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = [None] * n
+    deadline = time.time() + 3600
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
+            for i, p in enumerate(procs):                       # a rank failed: stop exactly the children we started
+                if rcs[i] is None:
+                    p.kill()
+                    rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % bad, file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
+# --------------------------------------------------------------------------------------------- main
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8, help="frames per step per GPU")
-    ap.add_argument("--input", choices=["noise", "natural"], default="noise")
+    ap.add_argument("--config", type=int, choices=[1, 2, 3, 4, 5], default=2, help="BASELINE.json configs[] (1-based)")
+    ap.add_argument("--frames", type=int, default=8, help="frames per step (per GPU in frames mode; total batch in config 5)")
+    ap.add_argument("--input", choices=["noise", "natural"], default=None)
+    ap.add_argument("--support", type=int, choices=[2, 4], default=2, help="S (config 2 only: 4 = the class default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-input", action="store_true",
-                    help="skip the short secondary-distribution run (profiling: keeps the kernel trace to one workload)")
-    ap.add_argument("--unfused", action="store_true", help="time the 3-launch direct path instead")
-    ap.add_argument("--mode", choices=["frames", "strips"], default="frames",
-                    help="frames: independent frames per GPU (weak scaling, default); strips: every frame is "
-                         "split into LR strips over the GPUs with an RCCL halo exchange (strong scaling)")
-    args = ap.parse_args()
+                    help="skip the short secondary runs (profiling: keeps the kernel trace to one workload)")
+    ap.add_argument("--unfused", action="store_true", help="config 2: time the 3-launch direct path instead")
+    ap.add_argument("--mode", choices=["frames", "strips"], default=None,
+                    help="frames: independent frames per GPU (default; config 5: the batch is divided over the GPUs); "
+                         "strips: every frame is split into LR strips over the GPUs with an RCCL halo exchange "
+                         "(default for --config 5 with N > 1)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus)                                  # never returns
+    if args.config == 1:
+        return run_config1(args)
 
     import torch
     import torch.distributed as dist
@@ -107,126 +216,279 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    rccl_ranks = 1
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+        rccl_ranks = dist.get_world_size()
+    n_gpus = world
+    if args.gpus != n_gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    eng = L.LerfEngine.shipped("lerf-g", support=2, max_sigma=10.0)
-    geo = eng.sr_geometry((H, W), SCALE)
+    cfg = args.config
+    model = "lerf-l" if cfg == 3 else "lerf-g"
+    H, W = (2160, 3840) if cfg == 5 else (1080, 1920)
+    scale = (1.5, 2.0) if cfg == 3 else (2.0, 2.0)
+    S = args.support if cfg == 2 else 2
+    kind = "linear" if model == "lerf-l" else "gauss"
+    input_kind = args.input or ("natural" if cfg == 4 else "noise")
+    mode = args.mode or ("strips" if (cfg == 5 and world > 1) else "frames")
+    strips = mode == "strips" and world > 1
+    if strips and cfg == 4:
+        raise SystemExit("strips mode is an SR partition; the warp path scales by frames")
+
+    eng = L.LerfEngine.shipped(model, support=S, max_sigma=10.0)
     B = args.frames
-    host = {k: synth_frames(k, B if k == args.input else 2, seed=1000 + rank) for k in ("noise", "natural")}
-    frames = torch.from_numpy(host[args.input]).cuda()
-    oH, oW = geo.out_hw
-    out = torch.empty((B, oH, oW, C), dtype=torch.uint8, device="cuda")
-    ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, B)), dtype=torch.uint8, device="cuda")
+    if cfg == 5 and not strips:
+        if B % world:
+            raise SystemExit("config 5, frames mode: the batch (%d) must divide over %d GPUs" % (B, world))
+        B_local = B // world                                    # strong scaling: the same batch, divided
+    else:
+        B_local = B
+    seed = 1000 + (0 if (cfg == 5) else rank)
+    host = synth_frames(input_kind, B if cfg == 5 else B_local, seed, H, W)
+    if cfg == 5 and not strips:
+        host = host[rank * B_local:(rank + 1) * B_local]
+    ms = eng.max_sigma
 
-    strips = args.mode == "strips" and world > 1
-    if strips:
-        from lerf_pytorch_amd import dist as ldist
-        plan = ldist.StripPlan(H, world, rank, eng.support, geo.host["left_r"])
-        local_geo = geo.row_slice(plan.ylo, plan.yhi - plan.ylo, plan.i0, plan.i1)
-        frames = frames[:, plan.y0:plan.y1].contiguous()         # this rank's rows of every frame
-        out = torch.empty((B, plan.i1 - plan.i0, oW, C), dtype=torch.uint8, device="cuda")
-
-    def step(x, o):
+    def make_sr(scale_hw):
+        geo = eng.sr_geometry((H, W), list(scale_hw))
+        oH, oW = geo.out_hw
+        ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, B_local)), dtype=torch.uint8, device="cuda")
         if strips:
-            ext = ldist.exchange_halos(x, plan)
-            ops.sr_fused_u8(ext, eng.luts, local_geo, "gauss", 10.0, out=o, workspace=ws)
-        elif args.unfused:
-            for b in range(x.shape[0]):
-                feat, hq = ops.lut_stages(x[b], eng.luts)
-                o[b] = ops.resize_hwc_u8(feat, hq, geo, "gauss", 10.0, out="u8")
+            from lerf_pytorch_amd import dist as ldist
+            plan = ldist.StripPlan(H, world, rank, eng.support, geo.host["left_r"])
+            lgeo = geo.row_slice(plan.ylo, plan.yhi - plan.ylo, plan.i0, plan.i1)
+            buf = ldist.StripBuffer(plan, B_local, W, C, torch.uint8, torch.device("cuda"))
+            buf.own.copy_(torch.from_numpy(host[:, plan.y0:plan.y1]).cuda())      # this rank's rows of every frame
+            out = torch.empty((B_local, plan.i1 - plan.i0, oW, C), dtype=torch.uint8, device="cuda")
+
+            def step(o=out):
+                ext = buf.exchange()
+                ops.sr_fused_u8(ext, eng.luts, lgeo, kind, ms, out=o, workspace=ws)
+            return step, out, (oH, oW), None
+        frames = torch.from_numpy(host).cuda()
+        out = torch.empty((B_local, oH, oW, C), dtype=torch.uint8, device="cuda")
+        if args.unfused:
+            def step(x=frames, o=out):
+                for b in range(x.shape[0]):
+                    feat, hq = ops.lut_stages(x[b], eng.luts)
+                    o[b] = ops.resize_hwc_u8(feat, hq, geo, kind, ms, out="u8")
         else:
-            ops.sr_fused_u8(x, eng.luts, geo, "gauss", 10.0, out=o, workspace=ws)
+            def step(x=frames, o=out):
+                ops.sr_fused_u8(x, eng.luts, geo, kind, ms, out=o, workspace=ws)
+        return step, out, (oH, oW), frames
+
+    def make_warp(matrix, out_hw):
+        geo = ops.WarpGeometry((H, W), np.array(matrix), out_hw, eng.support)
+        frames = torch.from_numpy(host).cuda()
+        outs = torch.empty((B_local, out_hw[0], out_hw[1], C), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, B_local)), dtype=torch.uint8, device="cuda")
+
+        def step(x=frames, o=outs):
+            packed = ops.stages_packed(x, eng.luts, workspace=ws)                  # one launch pair for the batch
+            for b in range(x.shape[0]):
+                ops.warp_packed(packed[b], geo, kind, ms, out=o[b])
+        return step, outs, out_hw, frames
+
+    if cfg == 4:
+        step, out, (oH, oW), frames = make_warp(M_ISC, (2 * H, 2 * W))
+    else:
+        step, out, (oH, oW), frames = make_sr(scale)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(frames, out)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step(frames, out)
-        ev[k][1].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            fn()
+            ev[k][1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return dt, launch_ms
+
+    dt, launch_ms = timed(step, args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # secondary distribution (same shapes), short run, rank 0 only
-    other = "natural" if args.input == "noise" else "noise"
-    other_mpix = None
-    if rank == 0 and world == 1 and not args.no_other_input:
-        xo = torch.from_numpy(np.ascontiguousarray(np.tile(host[other], (B // 2 + 1, 1, 1, 1))[:B])).cuda()
-        n_other = max(5, args.steps // 2)
-        for _ in range(2):
-            step(xo, out)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n_other):
-            step(xo, out)
-        torch.cuda.synchronize()
-        other_mpix = n_other * B * oH * oW / (time.perf_counter() - t1) / 1e6
-        step(frames, out)
-        torch.cuda.synchronize()
-
-    pix_per_step = (1 if strips else n_gpus) * B * oH * oW
+    weak = cfg != 5 and not strips
+    pix_per_step = (n_gpus if weak else 1) * (B_local if weak else B) * oH * oW
     value = pix_per_step * args.steps / dt / 1e6
-    alg_bytes = B * (H * W * C + oH * oW * C) + LUT_BYTES_G          # per launch (fused uint8 path)
+    alg_bytes = B_local * (H * W * C + (out.shape[1] if strips else oH) * oW * C) + LUT_BYTES[model]   # this rank's launch
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-    traffic, binding = None, None
+
+    extra = {}
+    single = rank == 0 and world == 1 and not args.no_other_input
+    if single and cfg in (2, 3, 5) and not args.unfused:
+        # (a) the other input distribution, same shapes, short run
+        other = "natural" if input_kind == "noise" else "noise"
+        ho = synth_frames(other, 2, seed, H, W)
+        xo = torch.from_numpy(np.ascontiguousarray(np.tile(ho, (B_local // 2 + 1, 1, 1, 1))[:B_local])).cuda()
+        geo = eng.sr_geometry((H, W), list(scale))
+        ws2 = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, B_local)), dtype=torch.uint8, device="cuda")
+        o2 = torch.empty_like(out)
+        d2, _ = timed(lambda: ops.sr_fused_u8(xo, eng.luts, geo, kind, ms, out=o2, workspace=ws2), max(5, args.steps // 2), 2)
+        extra["mpix_s_other_input"] = {other: round(max(5, args.steps // 2) * B_local * oH * oW / d2 / 1e6, 2)}
+        # (b) latency: ONE frame per launch (510 tiles on 256 CUs at 1080p: tile quantisation shows)
+        o1 = torch.empty_like(out[:1])
+        d1, l1 = timed(lambda: ops.sr_fused_u8(frames[:1], eng.luts, geo, kind, ms, out=o1, workspace=ws2), max(10, args.steps), 3)
+        extra["latency_one_frame_per_launch"] = {"ms": round(l1, 4), "mpix_s": round(oH * oW / (l1 * 1e-3) / 1e6, 2)}
+        del xo, o2, o1
+    if single and cfg == 3:
+        s2, o2, (oh2, ow2), _ = make_sr((2.0, 2.0))
+        d2, _ = timed(s2, max(5, args.steps // 2), 2)
+        extra["mpix_s_scale_2.0x2.0"] = round(max(5, args.steps // 2) * B_local * oh2 * ow2 / d2 / 1e6, 2)
+        del o2
+    if single and cfg == 4:
+        s2, o2, _, _ = make_warp(M_OSC, (2 * H, 2 * W))
+        d2, _ = timed(s2, max(5, args.steps // 2), 2)
+        torch.cuda.synchronize()
+        white = torch.zeros((H, W, C), dtype=torch.uint8, device="cuda")
+        white[4:H - 4, 4:W - 4] = 255
+        res_osc = {"mpix_s": round(max(5, args.steps // 2) * B_local * oH * oW / d2 / 1e6, 2)}
+        for nm, M in (("isc", M_ISC), ("osc", M_OSC)):
+            ngeo = ops.WarpGeometry((H, W), np.array(M), (oH, oW), 1)
+            mk = ops.warp_hwc_u8(white, None, ngeo, "nearest", 1.0, out="f32") == 255
+            frac = float(mk.float().mean().item())
+            if nm == "isc":
+                extra["valid_pixel_fraction_isc"] = round(frac, 4)
+                extra["valid_mpix_s_isc"] = round(value * frac, 2)
+            else:
+                res_osc["valid_pixel_fraction"] = round(frac, 4)
+                res_osc["valid_mpix_s"] = round(res_osc["mpix_s"] * frac, 2)
+        extra["osc_matrix"] = res_osc
+        del o2
+
+    # recorded (not in-run) PMC numbers: only when they were measured on exactly these kernels and this workload
+    traffic, tsrc, binding = None, None, None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tfile) and not args.unfused:
+    sha = kernel_source_sha()
+    if os.path.exists(tfile) and cfg == 2 and not args.unfused and S == 2 and world == 1:
         try:
             tj = json.load(open(tfile))
-            if tj.get("frames") == B and tj.get("input") == args.input:
+            if tj.get("frames") == B_local and tj.get("input") == input_kind and tj.get("kernel_src_sha16") == sha:
                 traffic = tj.get("bytes_per_launch")
-                # what actually binds this gather path (rocprofv3 PMC passes of the same command)
-                binding = {k: tj[k] for k in ("valu_instr_per_cu_cycle", "lds_array_busy", "lds_bank_conflict_share", "l2_hit_rate",
-                                              "kernel_trace_avg_us") if k in tj}
+                tsrc = "recorded, not measured in this run: %s (rocprofv3 --pmc passes of this command on kernel sources sha %s)" % (
+                    tj.get("source"), sha)
+                binding = {k: tj[k] for k in ("valu_instr_per_cu_cycle", "valu_busy", "lds_array_busy", "lds_bank_conflict_share",
+                                              "l2_hit_rate", "kernel_trace_avg_us") if k in tj}
+            else:
+                tsrc = "none: profiles/hbm_traffic.json was recorded for other kernel sources / workload (file sha %s, sources %s)" % (
+                    tj.get("kernel_src_sha16"), sha)
         except Exception:
-            traffic, binding = None, None
+            traffic, tsrc, binding = None, None, None
 
+    names = {2: ("Mpix/s LeRF-G x2 SR (2K->4K)", "LeRF-G LUT x2 SR, 1920x1080->3840x2160 RGB uint8, S=%d, max_sigma=10 (BASELINE configs[1])" % S),
+             3: ("Mpix/s LeRF-L x1.5/x2.0 SR (2K input)", "LeRF-L LUT anisotropic SR x1.5/x2.0, 1920x1080->3840x1620 RGB uint8, S=2 (BASELINE configs[2])"),
+             4: ("Mpix/s LeRF-G homographic warp (2K->4K)", "LeRF-G LUT homographic warp, 1920x1080->3840x2160 RGB uint8, isc-like matrix, S=2 (BASELINE configs[3])"),
+             5: ("Mpix/s LeRF-G x2 SR (4K->8K, batch 8)", "LeRF-G LUT x2 SR, batch of %d frames 3840x2160->7680x4320 RGB uint8, S=2 (BASELINE configs[4])" % B)}
+    if strips:
+        par = "LR strips of every frame over %d GPUs, RCCL halo exchange of %d raw uint8 rows per side (batch_isend_irecv)" % (n_gpus, 3 + 3 + S // 2)
+    elif cfg == 5:
+        par = "the batch divided over %d GPU(s), whole frames, no data-path collective" % n_gpus
+    else:
+        par = "independent frames per GPU, no data-path collective"
     res = {
-        "metric": "Mpix/s LeRF-G x2 SR (2K->4K)", "value": round(value, 2), "unit": "Mpix/s",
+        "metric": names[cfg][0], "value": round(value, 2), "unit": "Mpix/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strips else "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
         "vs_baseline": None, "dtype": "i32+f32 (u8 io)", "data": "synthetic",
-        "config": {"workload": "LeRF-G LUT x2 SR, 1920x1080->3840x2160 RGB uint8, S=2, max_sigma=10 (BASELINE configs[1])",
-                   "frames_per_step_per_gpu": B, "input": args.input, "path": "unfused-3-launch" if args.unfused else "sr_fused_u8",
-                   "parallelism": ("LR strips per frame over %d GPUs, RCCL halo exchange (7 rows per side)" % n_gpus) if strips
-                                  else "independent frames per GPU, no data-path collective"},
+        "config": {"workload": names[cfg][1], "baseline_config": cfg, "frames_per_step_per_gpu": B_local, "input": input_kind,
+                   "path": "unfused-3-launch" if args.unfused else ("stages_packed + warp_packed" if cfg == 4 else "sr_fused_u8"),
+                   "mode": "strips" if strips else "frames", "parallelism": par, "ranks_reported_by_rccl": rccl_ranks},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                      "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "gather/VALU-bound path: 3.75 B per output pixel, see DESIGN.md",
+                     "binding_resource": "valu_issue (gather/VALU-bound path, HBM is the nominal roofline only: %.2f B per output pixel; DESIGN.md section 5)"
+                                         % ((alg_bytes - LUT_BYTES[model]) / (B_local * (out.shape[1] if strips else oH) * oW)),
                      "binding_resources_from_pmc": binding},
-        "mpix_s_other_input": {other: round(other_mpix, 2)} if other_mpix else None,
     }
+    res.update(extra)
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not strips:
-        cb, cpu_out = cpu_baseline(host[args.input])
-        res["cpu_baseline"] = cb
-        # the timed product output must equal the checker's (<= 1 LSB)
-        n_cpu = int(cb["sample"].split()[0])
-        ref_idx = (n_cpu - 1) % len(host[args.input])
-        diff = np.abs(out[ref_idx].cpu().numpy().astype(int) - cpu_out.astype(int))
-        res["parity_vs_cpu_port"] = {"max_abs_diff_u8": int(diff.max()), "mismatches": int((diff != 0).sum())}
+        if cfg == 4:
+            cb, cpu_out, cpu_mask = cpu_baseline_warp(host[0], np.array(M_ISC), (oH, oW))
+            res["cpu_baseline"] = cb
+            step()
+            torch.cuda.synchronize()
+            white = torch.zeros((H, W, C), dtype=torch.uint8, device="cuda")
+            white[4:H - 4, 4:W - 4] = 255
+            mk = (ops.warp_hwc_u8(white, None, ops.WarpGeometry((H, W), np.array(M_ISC), (oH, oW), 1), "nearest", 1.0, out="f32") == 255).cpu().numpy()
+            diff = np.abs(out[0].cpu().numpy().astype(int) - cpu_out.astype(int))
+            res["parity_vs_cpu_port"] = {"max_abs_diff_u8": int(diff.max()), "mismatches": int((diff != 0).sum()),
+                                         "mask_mismatches": int((mk != cpu_mask).sum())}
+        else:
+            budget = 12.0 if cfg != 5 else 20.0
+            cb, cpu_out, n_cpu = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=budget)
+            res["cpu_baseline"] = cb
+            if cfg == 2 and S == 2:
+                # one core, on the 256x256 tile of BASELINE config 1 (a 1080p frame takes about a minute on one core)
+                tile = np.random.default_rng(0).integers(0, 256, (1, 256, 256, C), dtype=np.uint8)
+                cb1, _, _ = cpu_baseline_sr(tile, model, 2.0, 2.0, budget_s=6.0, threads=1, max_n=8)
+                res["cpu_baseline_single_thread"] = cb1
+            # the timed product output must equal the checker's (<= 1 LSB)
+            ref_idx = (n_cpu - 1) % len(host)
+            step()
+            torch.cuda.synchronize()
+            diff = np.abs(out[ref_idx].cpu().numpy().astype(int) - cpu_out.astype(int))
+            res["parity_vs_cpu_port"] = {"max_abs_diff_u8": int(diff.max()), "mismatches": int((diff != 0).sum())}
     if rank == 0:
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def run_config1(args):
+    """BASELINE configs[0]: one 256x256 RGB tile, LeRF-G x2 -- the reference's own CPU-runnable case.  `value` is the C port
+    of the oracle on all host cores; the single-thread figure and (when a GPU is present) the product path on the same tile
+    with its parity against the port ride along.  The reference itself (numpy) takes 15.3 s = 0.017 Mpix/s on this tile
+    (BASELINE.md section 3, 8-vCPU build container)."""
+    tile = np.random.default_rng(0).integers(0, 256, (1, 256, 256, C), dtype=np.uint8)
+    cb_all, out_all, _ = cpu_baseline_sr(tile, "lerf-g", 2.0, 2.0, budget_s=8.0, max_n=200)
+    cb_one, out_one, _ = cpu_baseline_sr(tile, "lerf-g", 2.0, 2.0, budget_s=8.0, threads=1, max_n=8)
+    res = {"metric": "Mpix/s LeRF-G x2 SR, one 256x256 RGB tile on CPU (plumbing)", "value": cb_all["value"], "unit": "Mpix/s",
+           "n_gpus": 0, "steps": 1, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "i32+f64", "data": "synthetic",
+           "config": {"workload": "LeRF-G LUT x2 SR, 256x256->512x512 RGB uint8 tile, S=2 (BASELINE configs[0])", "baseline_config": 1,
+                      "input": "noise", "path": "oracle/lerf_oracle.c (CPU port of the oracle)"},
+           "cpu_baseline": cb_all, "cpu_baseline_single_thread": cb_one,
+           "reference_numpy_build_container": {"value": 0.0172, "unit": "Mpix/s", "source": "BASELINE.md section 3"},
+           "port_threads_agree": bool(np.array_equal(out_all, out_one))}
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import lerf_pytorch_amd as L
+            eng = L.LerfEngine.shipped("lerf-g")
+            x = torch.from_numpy(tile).cuda()
+            o = eng.sr(x, 2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                o = eng.sr(x, 2)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 50 * 1e3
+            d = np.abs(o[0].cpu().numpy().astype(int) - out_all.astype(int))
+            res["n_gpus"] = 1
+            res["gpu_same_tile"] = {"ms_per_call": round(ms, 4), "mpix_s": round(512 * 512 / (ms * 1e-3) / 1e6, 2),
+                                    "max_abs_diff_u8": int(d.max()), "mismatches": int((d != 0).sum())}
+    except ImportError:
+        pass
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":

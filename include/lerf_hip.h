@@ -197,8 +197,8 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
 /* Stages 1+2 by the tile-fused kernel (modes "sct"/"sct", C = 3, luts->fused_pack set), `n` frames:
  * packed[(y*W + x)*3 + c] = hq0 | hq1<<8 | hq2<<16 | feat<<24  (hq1, hq2 = 0 for LeRF-L).
  * Same values as lerf_lut_stages_u8, ~4x faster; feeds lerf_warp_packed / lerf_unpack_stages.
- * workspace: optional device scratch of lerf_sr_fused_workspace_bytes(H, W, C, n) bytes (NULL = none): with it stage 1
- * runs as its own launch without recomputing tile halos, like lerf_sr_fused_u8. */
+ * workspace: optional device scratch of AT LEAST lerf_sr_fused_workspace_bytes(H, W, C, n) bytes (NULL = none): with it
+ * stage 1 runs as its own launch without recomputing tile halos, like lerf_sr_fused_u8. */
 int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
                           const lerf_luts_t* luts, uint32_t* packed, int64_t packed_sn, void* workspace, void* stream);
 
@@ -209,10 +209,15 @@ int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* 
 int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_warp_geo_t* geo,
                      int kind, double max_sigma, const lerf_mplane_t* out, void* stream);
 
-/* Whole SR path of eltr._worker (resample/eval_lut_sr.py:541-665) in one
- * launch per frame batch: uint8 HWC in -> uint8 HWC out, feat and hyper never
- * leave the chip.  `n` frames with batch strides in_sn / out_sn (elements).
- * workspace: lerf_sr_fused_workspace_bytes() bytes of device memory (may be 0). */
+/* Whole SR path of eltr._worker (resample/eval_lut_sr.py:541-665) for a batch of `n` frames (batch strides
+ * in_sn / out_sn in elements): uint8 HWC in -> uint8 HWC out.
+ * workspace != NULL (at least lerf_sr_fused_workspace_bytes(H, W, C, n) bytes of device memory -- a smaller buffer
+ * is written out of bounds): TWO launches over the same grid of 64x64 LR tiles; stage 1 runs once per pixel and its
+ * uint8 output (3 B per LR pixel) waits in the workspace, the second launch runs stage 2, the finalisation and stage
+ * 3 per tile; the hyper-parameters never leave the CU.
+ * workspace == NULL: ONE launch; every tile recomputes stage 1 on its halo (about 4 % slower) and nothing but the
+ * input, the LUT pack and the output touches HBM.  Configurations outside the tile-fused kernel (C != 3, modes !=
+ * "sct", S not in {2,4}, down-sampling) need the workspace and run the three direct kernels through it. */
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n);
 int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
                      const lerf_luts_t* luts, const lerf_sr_geo_t* geo,

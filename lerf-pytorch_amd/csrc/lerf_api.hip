@@ -304,9 +304,13 @@ int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_war
 }
 
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {
-    // room for the unfused fallback (feat + 3 hyper planes per frame); the tile-fused kernel needs none
+    // Two uses, the larger one sizes it: (a) the two-launch tile-fused path parks the stage-1 output of the batch there
+    // (n frames, frame stride rounded up to 16 bytes) between s1_kernel and the stage-2/3 launch; (b) the general
+    // fallback keeps feat + up to 3 hyper planes per frame.  A non-NULL workspace MUST have at least this size.
     if (H < 1 || W < 1 || C < 1 || n < 1) return 0;
-    return (size_t)n * H * W * C * 4;
+    const size_t hwc = (size_t)H * W * C;
+    const size_t a = (size_t)n * ((hwc + 15) / 16 * 16), b = (size_t)n * hwc * 4;
+    return a > b ? a : b;
 }
 
 int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts,

@@ -1,5 +1,8 @@
-// Tile-fused uint8 SR path for MI355X (gfx950): stage-1 LUTs -> stage-2 LUTs ->
-// spatially-varying resampling in ONE launch; feat and hyper never leave the CU.
+// Tile-fused uint8 SR path for MI355X (gfx950): stage-1 LUTs -> stage-2 LUTs -> spatially-varying resampling per
+// 64x64 LR tile.  With a caller workspace (the normal case) it is TWO launches: s1_kernel computes stage 1 once per
+// pixel and parks its uint8 output in the workspace, sr_fused_kernel<.., FROM_FEAT> runs stage 2, the finalisation and
+// stage 3 from it -- the hyper-parameters never leave the CU.  Without a workspace ONE launch does everything and
+// recomputes stage 1 on each tile's halo.
 //
 // Reference path being replaced: eltr._worker, resample/eval_lut_sr.py:541-665
 // (FourSimplexInterpFaster :24-470 x 24 passes, SteeringGaussianResize2dNumpy /

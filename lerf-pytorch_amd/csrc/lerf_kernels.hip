@@ -377,10 +377,10 @@ int launch_resize(const ResizeArgs& a, hipStream_t st) {
     if (a.kind >= LERF_KIND_NEAREST && a.kind <= LERF_KIND_LANCZOS3) return launch_resize_fixed(a, st);
     if (a.in_dtype == LERF_U8 && a.h_dtype == LERF_U8) {
         if (a.out_dtype == LERF_U8) return resize_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
-        if (a.out_dtype == LERF_F32) return resize_dispatch_kind<uint8_t, uint8_t, float, float>(a, st);
+        if (a.out_dtype == LERF_F32) return resize_dispatch_kind<uint8_t, uint8_t, float, double>(a, st);   // float64 arithmetic, rounded once
         if (a.out_dtype == LERF_F64) return resize_dispatch_kind<uint8_t, uint8_t, double, double>(a, st);
     } else if (a.in_dtype == LERF_F32 && a.h_dtype == LERF_F32) {
-        if (a.out_dtype == LERF_F32) return resize_dispatch_kind<float, float, float, float>(a, st);
+        if (a.out_dtype == LERF_F32) return resize_dispatch_kind<float, float, float, double>(a, st);
         if (a.out_dtype == LERF_F64) return resize_dispatch_kind<float, float, double, double>(a, st);
     }
     return LERF_EUNSUPPORTED;
@@ -599,10 +599,10 @@ int launch_warp(const WarpArgs& a, hipStream_t st) {
     const bool fixed = a.kind >= LERF_KIND_NEAREST;     // no hyper-parameter maps
     if (a.in_dtype == LERF_U8 && (a.h_dtype == LERF_U8 || fixed)) {
         if (a.out_dtype == LERF_U8) return warp_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
-        if (a.out_dtype == LERF_F32) return warp_dispatch_kind<uint8_t, uint8_t, float, float>(a, st);
+        if (a.out_dtype == LERF_F32) return warp_dispatch_kind<uint8_t, uint8_t, float, double>(a, st);     // float64 arithmetic, rounded once
         if (a.out_dtype == LERF_F64) return warp_dispatch_kind<uint8_t, uint8_t, double, double>(a, st);
     } else if (a.in_dtype == LERF_F32 && (a.h_dtype == LERF_F32 || fixed)) {
-        if (a.out_dtype == LERF_F32) return warp_dispatch_kind<float, float, float, float>(a, st);
+        if (a.out_dtype == LERF_F32) return warp_dispatch_kind<float, float, float, double>(a, st);
         if (a.out_dtype == LERF_F64) return warp_dispatch_kind<float, float, double, double>(a, st);
     }
     return LERF_EUNSUPPORTED;

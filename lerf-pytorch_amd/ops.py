@@ -173,9 +173,11 @@ def stages_packed(img_u8, luts, workspace=None):
     img = (img_u8.unsqueeze(0) if squeeze else img_u8).contiguous()
     N, H, W, Cn = img.shape
     packed = torch.empty((N, H, W, Cn), dtype=torch.int32, device=img.device)
-    need = _lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N)
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(max(int(need), 1), dtype=torch.uint8, device=img.device)
+    need = int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N))
+    if workspace is None:
+        workspace = fused_workspace(H, W, Cn, N, img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
+        raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
     _lib.check(_lib.lib().lerf_stages_packed_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(),
                                                 packed.data_ptr(), packed.stride(0), workspace.data_ptr(),
                                                 _lib.current_stream()), "lerf_stages_packed_u8")
@@ -193,10 +195,17 @@ def unpack_stages(packed, oC):
 
 
 def warp_packed(packed_hwc, geo: "WarpGeometry", kind="gauss", max_sigma=10.0, out="u8"):
+    """out: "u8" / "f32" (a fresh tensor) or a caller-owned uint8 / float32 tensor [oH,oW,C] to write into."""
     torch = _torch()
     p = packed_hwc.contiguous()
     H, W, Cn = p.shape
-    o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=p.device)
+    if isinstance(out, str):
+        o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=p.device)
+    else:
+        o = out
+        if tuple(o.shape) != (geo.out_hw[0], geo.out_hw[1], Cn) or o.dtype not in (torch.uint8, torch.float32) \
+                or o.device != p.device or o.stride(2) != 1:
+            raise ValueError("out must be a uint8/float32 [oH,oW,C] tensor on the input's device")
     po = _planes_hwc(o)
     _lib.check(_lib.lib().lerf_warp_packed(p.data_ptr(), H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
                                            C.byref(po), _lib.current_stream()), "lerf_warp_packed")
@@ -300,22 +309,71 @@ def warp_planar(feat, hypers, geo: WarpGeometry, kind="gauss", max_sigma=10.0, o
 
 
 # --------------------------------------------------------------------------- fused SR
+_WS = {}
+
+
+def fused_workspace(H, W, Cn, N, device):
+    """Device scratch of lerf_sr_fused_workspace_bytes() bytes for the two-launch fused path (stage-1 output of the
+    batch between s1_kernel and the stage-2/3 launch), cached per device and grown on demand: repeated calls on one
+    stream reuse it (launches on a stream are ordered, so the previous call has consumed it).  Callers that run
+    several streams concurrently pass their own `workspace=`."""
+    torch = _torch()
+    need = max(int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N)), 1)
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _gpu_visible(t):
+    """device memory, or pinned host memory (the kernels read / write it over PCIe: stream.StreamingSR)"""
+    return t.is_cuda or t.is_pinned()
+
+
+def _check_out_u8(out, shape, device, what):
+    torch = _torch()
+    if not isinstance(out, torch.Tensor) or out.dtype != torch.uint8 or tuple(out.shape) != tuple(shape):
+        raise ValueError("%s must be a uint8 tensor of shape %s" % (what, tuple(shape)))
+    if not _gpu_visible(out):
+        raise ValueError("%s must live in device memory or pinned host memory" % what)
+    exp = 1
+    for d in range(out.dim() - 1, 0, -1):               # frames may be strided (dim 0); each frame is dense HWC
+        if out.shape[d] != 1 and out.stride(d) != exp:
+            raise ValueError("%s: every frame must be contiguous [H,W,C]" % what)
+        exp *= out.shape[d]
+
+
 def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out=None, workspace=None):
-    """uint8 [H,W,C] or [N,H,W,C] -> uint8 [oH,oW,C] / [N,oH,oW,C]; one launch per call."""
+    """uint8 [H,W,C] or [N,H,W,C] -> uint8 [oH,oW,C] / [N,oH,oW,C].  Two launches per call (stage 1 over the batch into
+    the workspace, then stages 2+3 per tile); `out` (same rank as the input) and `workspace` may be caller-owned."""
     torch = _torch()
     if img_u8.dtype != torch.uint8:
         raise ValueError("img must be uint8")
     squeeze = img_u8.dim() == 3
-    img = (img_u8.unsqueeze(0) if squeeze else img_u8).contiguous()
+    img = (img_u8.unsqueeze(0) if squeeze else img_u8)
+    if img.dim() != 4:
+        raise ValueError("img must be [H,W,C] or [N,H,W,C]")
+    if not img[0].is_contiguous():
+        img = img.contiguous()
     N, H, W, Cn = img.shape
     if (H, W) != geo.in_hw:
         raise ValueError("geometry was built for another input size")
+    oshape = (N, geo.out_hw[0], geo.out_hw[1], Cn)
+    if not _gpu_visible(img):
+        raise ValueError("img must live in device memory or pinned host memory")
     if out is None:
-        out = torch.empty((N, geo.out_hw[0], geo.out_hw[1], Cn), dtype=torch.uint8, device=img.device)
-    need = _lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N)
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(max(int(need), 1), dtype=torch.uint8, device=img.device)
+        o4 = torch.empty(oshape, dtype=torch.uint8, device=img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    else:
+        o4 = out.unsqueeze(0) if (squeeze and out.dim() == 3) else out
+        _check_out_u8(o4, oshape, img.device, "out")
+    need = int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N))
+    if workspace is None:
+        workspace = fused_workspace(H, W, Cn, N, img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
+        raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
     _lib.check(_lib.lib().lerf_sr_fused_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(), geo.ref(),
-                                           KINDS[kind], float(max_sigma), out.data_ptr(), out.stride(0),
+                                           KINDS[kind], float(max_sigma), o4.data_ptr(), o4.stride(0),
                                            workspace.data_ptr(), _lib.current_stream()), "lerf_sr_fused_u8")
-    return out[0] if squeeze else out
+    return o4[0] if squeeze else o4

@@ -27,7 +27,6 @@ class LerfEngine:
         self.support = 2 if self.linear else int(support)
         self.max_sigma = 1.0 if self.linear else float(max_sigma)
         self._sr_geo = {}
-        self._ws = None
 
     @classmethod
     def shipped(cls, name="lerf-g", **kw):
@@ -96,10 +95,14 @@ class LerfEngine:
         x, as_np = self._dev(img)
         H, W, Cn = x.shape
         geo = ops.WarpGeometry((H, W), matrix, out_hw, self.support)
-        if self._fused_stages_ok(x) and out in ("u8", "f32"):
+        if self._fused_stages_ok(x) and out == "u8":
             o = ops.warp_packed(ops.stages_packed(x, self.luts), geo, self.kind, self.max_sigma, out=out)
         else:
-            feat, hq = ops.lut_stages(x, self.luts)
+            # float outputs: float64 arithmetic in the direct kernel (f32 = rounded once at the store)
+            if self._fused_stages_ok(x):
+                feat, hq = ops.unpack_stages(ops.stages_packed(x, self.luts), self.luts.oC)
+            else:
+                feat, hq = ops.lut_stages(x, self.luts)
             o = ops.warp_hwc_u8(feat, hq, geo, self.kind, self.max_sigma, out=out)
         mask = None
         if return_mask:

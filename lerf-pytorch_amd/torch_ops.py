@@ -48,7 +48,7 @@ def sr_fused(img: torch.Tensor, luts: int, scale_h: float, scale_w: float, suppo
     L = _LUTS[luts]
     linear = L.oC == 1
     geo = _geo(img.shape[-3:-1], scale_h, scale_w, 2 if linear else support, img.device)
-    return ops.sr_fused_u8(img, L, geo, "linear" if linear else "gauss", 1.0 if linear else max_sigma).clone()
+    return ops.sr_fused_u8(img, L, geo, "linear" if linear else "gauss", 1.0 if linear else max_sigma)   # a fresh tensor
 
 
 @sr_fused.register_fake

@@ -27,6 +27,11 @@ def threads():
     return int(lib().lerf_oracle_threads())
 
 
+def set_threads(n):
+    """n > 0: that many OpenMP threads for the following calls; n <= 0: one per host core again."""
+    lib().lerf_oracle_set_threads(int(n))
+
+
 def _lut_ptrs(luts, modes, modes2, oC):
     keep = []
     s1 = (C.c_void_p * len(modes))()

@@ -330,6 +330,15 @@ int lerf_oracle_warp_u8(const uint8_t* img, int H, int W, int C, const char* mod
     return rc;
 }
 
+/* n > 0: use n OpenMP threads from now on; n <= 0: back to one per host core */
+void lerf_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+    (void)n;
+#endif
+}
+
 int lerf_oracle_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

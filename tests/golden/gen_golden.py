@@ -494,6 +494,44 @@ def g12_downscale():
     print("G12", len(out))
 
 
+def g13_torch_warp():
+    """the reference's TORCH warp classes (resize_right/resize_right2d_torch.py:249-487): SteeringGaussianWarp2dTorch
+    (S = 2 and 4), AmplifiedLinearWarp2dTorch, NearestWarp2dTorch, BicubicWarp2dTorch on the G4 inputs, batch of 2
+    single-channel maps ([B,1,H,W], the shape the training/validation code feeds them), float64 matrix."""
+    from resize_right.resize_right2d_torch import (AmplifiedLinearWarp2dTorch, BicubicWarp2dTorch, NearestWarp2dTorch,
+                                                   SteeringGaussianWarp2dTorch)
+    g4 = np.load(os.path.join(OUT, "g4_warp.npz"))
+    out = {}
+    for p in ("isc", "osc"):
+        M = torch.tensor(g4["%s/matrix" % p], dtype=torch.float64)
+        feat = torch.tensor(g4["%s/feat" % p][:2].astype(np.float32)).unsqueeze(1)             # [2,1,52,52]
+        hy = torch.tensor((g4["%s/hq" % p][:, :2].astype(np.float32) / 255.0).astype(np.float32)).unsqueeze(2)   # [3,2,1,52,52]
+        for (oH, oW) in ((60, 70), (97, 41)):
+            key = "%s/%dx%d" % (p, oH, oW)
+            for S in (2, 4):
+                w = SteeringGaussianWarp2dTorch(support_sz=S, device="cpu", max_sigma=10)
+                w.set_shape([2, 1, 52, 52], M, [2, 1, oH, oW])
+                o = w.warp(feat, hy[0], hy[1], hy[2])
+                out[key + "/gauss_S%d" % S] = o.numpy()
+                out[key + "/pad_S%d" % S] = np.array(w.pad_vec)
+            wl = AmplifiedLinearWarp2dTorch(device="cpu")
+            wl.set_shape([2, 1, 52, 52], M, [2, 1, oH, oW])
+            out[key + "/linear"] = wl.warp(feat, hy[0]).numpy()
+            white = torch.zeros((2, 1, 52, 52))
+            white[:, :, 4:48, 4:48] = 255
+            nn = NearestWarp2dTorch(device="cpu")
+            nn.set_shape([2, 1, 52, 52], M, [2, 1, oH, oW])
+            out[key + "/nearest_white"] = nn.warp(white).numpy()
+            out[key + "/nearest"] = nn.warp(feat).numpy()
+            bc = BicubicWarp2dTorch(device="cpu")
+            bc.set_shape([2, 1, 52, 52], M, [2, 1, oH, oW])
+            out[key + "/cubic"] = bc.warp(feat).numpy()
+    for k, v in out.items():
+        assert v.dtype in (np.float64, np.int64, np.float32), (k, v.dtype)
+    np.savez_compressed(os.path.join(OUT, "g13_torch_warp.npz"), **out)
+    print("G13", len(out), {k: str(v.dtype) for k, v in list(out.items())[:6]})
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -513,7 +551,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -536,3 +574,5 @@ if __name__ == "__main__":
         g11_resize_grads()
     if "g12" in which:
         g12_downscale()
+    if "g13" in which:
+        g13_torch_warp()

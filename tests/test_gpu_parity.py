@@ -579,3 +579,48 @@ def test_streaming_sr_matches_engine(torch, eng_g):
     assert np.array_equal(st.result(i), outs[1])
     with pytest.raises(ValueError):
         st.submit(batches[0][:1])
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_torch_warp_classes_vs_reference_torch_path(torch, golden, p):
+    """A9: all seven *Warp2dTorch mirrors.  SteeringGaussian (S = 2, 4), AmplifiedLinear, Nearest and Bicubic against
+    the outputs of the reference's own torch classes (g13, resize_right2d_torch.py:346-487; float64 like theirs);
+    Bilinear / Lanczos2 / Lanczos3 exist only as numpy classes upstream and are held to those (g7)."""
+    from lerf_pytorch_amd.resize_right import resize_right2d_torch as T
+    g4, g7, g13 = golden("g4_warp.npz"), golden("g7_fixed_warp.npz"), golden("g13_torch_warp.npz")
+    dev = torch.device("cuda")
+    M = torch.tensor(g4["%s/matrix" % p], dtype=torch.float64, device=dev)
+    feat = torch.from_numpy(g4["%s/feat" % p][:2].astype(np.float32)).unsqueeze(1).to(dev)                    # [2,1,52,52]
+    hy = torch.from_numpy(g4["%s/hq" % p][:, :2].astype(np.float32) / np.float32(255)).unsqueeze(2).to(dev)   # [3,2,1,52,52]
+
+    def check(out, ref, tol):
+        assert out.dtype == torch.float64 and out.is_cuda and tuple(out.shape) == ref.shape
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=tol, equal_nan=True)
+
+    for hw in ((60, 70), (97, 41)):
+        key = "%s/%dx%d" % (p, hw[0], hw[1])
+        for S in (2, 4):
+            w = T.SteeringGaussianWarp2dTorch(support_sz=S, device=dev, max_sigma=10)
+            w.set_shape([2, 1, 52, 52], M, [2, 1, hw[0], hw[1]])
+            assert list(w.pad_vec) == list(g13[key + "/pad_S%d" % S])
+            assert w.out_shape == [2, 1, hw[0], hw[1]] and w.in_sz == [52, 52] and w.out_sz == [hw[0], hw[1]]
+            check(w.warp(feat, hy[0], hy[1], hy[2]), g13[key + "/gauss_S%d" % S], 1e-9)
+        wl = T.AmplifiedLinearWarp2dTorch(device=dev)
+        wl.set_shape([2, 1, 52, 52], M, [2, 1, hw[0], hw[1]])
+        check(wl.warp(feat, hy[0]), g13[key + "/linear"], 1e-9)
+        nn = T.NearestWarp2dTorch(device=dev)
+        nn.set_shape([2, 1, 52, 52], M, [2, 1, hw[0], hw[1]])
+        check(nn.warp(feat), g13[key + "/nearest"], 0)
+        white = torch.zeros((2, 1, 52, 52), device=dev)
+        white[:, :, 4:48, 4:48] = 255
+        check(nn.warp(white), g13[key + "/nearest_white"], 0)
+        bc = T.BicubicWarp2dTorch(device=dev)
+        bc.set_shape([2, 1, 52, 52], M, [2, 1, hw[0], hw[1]])
+        check(bc.warp(feat), g13[key + "/cubic"], 1e-9)
+    feat3 = torch.from_numpy(g4["%s/feat" % p].astype(np.float32)).unsqueeze(0).to(dev)                       # [1,3,52,52]
+    for name, cls in (("bilinear", T.BilinearWarp2dTorch), ("lanczos2", T.Lanczos2Warp2dTorch), ("lanczos3", T.Lanczos3Warp2dTorch)):
+        w = cls(device=dev)
+        w.set_shape([1, 3, 52, 52], M, [1, 3, 60, 70])
+        check(w.warp(feat3), g7["%s/%s" % (p, name)][None], 1e-9)
+    with pytest.raises(ValueError):
+        bc.warp(feat3[:, :, :50])                                                # shape other than set_shape's

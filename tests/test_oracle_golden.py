@@ -229,3 +229,27 @@ def test_downscale_antialias_golden(oracle, golden, ci):
     if "%d/linear" % ci in g:
         o = oracle.resize_params_f32(feat, hy[0], None, None, sh, sw, 2, 1, "linear")
         np.testing.assert_allclose(o, g["%d/linear" % ci], rtol=0, atol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("p", ["isc", "osc"])
+def test_torch_warp_classes_golden(oracle, golden, p):
+    """the reference's TORCH warp classes (g13: SteeringGaussian S=2/4, AmplifiedLinear, Nearest, Bicubic; float64
+    geometry) agree with the numpy restatement to float64 rounding"""
+    g4, g13 = golden("g4_warp.npz"), golden("g13_torch_warp.npz")
+    M = g4["%s/matrix" % p]
+    feat = g4["%s/feat" % p][:2].astype(np.float32)
+    h = g4["%s/hq" % p][:, :2].astype(np.float32) / np.float32(255)
+    for hw in ((60, 70), (97, 41)):
+        key = "%s/%dx%d" % (p, hw[0], hw[1])
+        for S in (2, 4):
+            geo = oracle.warp_geometry(M, (52, 52), hw, S)
+            plx, phx, ply, phy = geo["pad"]
+            assert [ply, phy, plx, phx] == list(g13[key + "/pad_S%d" % S])          # torch order: last dim first
+            out = oracle.warp_params_f32(feat, h[0], h[1], h[2], M, hw, S, 10, "gauss")
+            np.testing.assert_allclose(out, g13[key + "/gauss_S%d" % S][:, 0], rtol=0, atol=1e-9, equal_nan=True)
+        out = oracle.warp_params_f32(feat, h[0], None, None, M, hw, 2, 1, "linear")
+        np.testing.assert_allclose(out, g13[key + "/linear"][:, 0], rtol=0, atol=1e-9, equal_nan=True)
+        out = oracle.warp_params_f32(feat, None, None, None, M, hw, 1, 1, "nearest")
+        np.testing.assert_allclose(out, g13[key + "/nearest"][:, 0], rtol=0, atol=0, equal_nan=True)
+        out = oracle.warp_params_f32(feat, None, None, None, M, hw, 4, 1, "cubic")
+        np.testing.assert_allclose(out, g13[key + "/cubic"][:, 0], rtol=0, atol=1e-9, equal_nan=True)
