@@ -130,35 +130,111 @@ __host__ __device__ constexpr Off3 tile_offsets(char mode, int rot) {
 }
 
 // ---------------------------------------------------------------------------
-// simplex walk (index/weight computation only).  Keys are (LSB << 16) | axis stride so that one
-// unsigned sort orders the four axes by decreasing LSB (ties: zero weight, any order).
-// STRIDE_SCALE = bytes per LUT entry, folded into the strides so idx[] are byte offsets.
+// simplex walk (index/weight computation only).  Keys are (LSB << 16) | axis stride so that one unsigned sort orders
+// the four axes by decreasing LSB (ties: zero weight, any order).  STRIDE_SCALE = bytes per LUT entry, folded into
+// the strides so the indices are byte offsets.
+//
+// Instruction budget (gfx950 issues v_and/or/add/sub/lshr in ~2.4 cycles per wave64, every 3-operand or min/max/
+// shift-left/24-bit-multiply op in ~4.3: profiles/r01_valu_instruction_rates.txt), per lookup:
+//   keys      3 x (v_and + v_lshl_or)                       the centre key is shared by the rotations of a position
+//   sort      7 three-input ops  m = max3(a,b,c)  e = med3(a,b,c)  n = min3(a,b,c)
+//                                s0 = max(m,d)  s1 = med3(m,e,d)  s2 = med3(e,n,d)  s3 = min(n,d)
+//             instead of the 10 of a 5-comparator network
+//   indices   the walk ends at base + (all four strides), a constant: vertex 4 is an immediate offset on vertex 0 and
+//             vertex 3 = vertex 4 - stride(s3), so only s0, s1, s3 contribute an AND + ADD/SUB (s2 is needed for its
+//             LSB alone)
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (f << 16) | stride in one instruction (the compiler prefers shift-left + and + or)
+__device__ __forceinline__ unsigned make_key(unsigned f, unsigned stride) {
+    unsigned r;
+    asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(f), "s"(stride));
+    return r;
+}
+
+// LDS accesses by 32-bit LDS address.  `smem` is a link-time symbol: pointer arithmetic on it leaves one "+ smem" per
+// distinct address chain in the instruction stream (v_add 0); folding the table's LDS address into the walk's base
+// index once per position removes them, and constant parts still fold into the DS immediate offset.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
+typedef __attribute__((address_space(3))) const int8_t lds_ci8_t;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// OFF is applied as a constant element index so that it lands in the DS immediate offset
+template <int OFF = 0>
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t a) { return ((lds_cu32_t*)a)[OFF / 4]; }
+template <int OFF = 0>
+__device__ __forceinline__ int lds_ldi8(uint32_t a) { return (int)((lds_ci8_t*)a)[OFF]; }
+
+// A tile pixel is needed twice: its LSB in bits 16..19 of the sort key and its MSB as an index digit.  ds_read_u8_d16_hi
+// returns the byte in bits 16..23 (v << 16 for free; what it leaves in the low half is not relied upon), so that
+//   key = (r & 0x000F0000) | stride   one v_and_or_b32          msb = r >> 20   one v_lshrrev_b32
+// instead of v_and + v_lshl_or + v_lshrrev on a zero-extended byte.  The compiler does not track inline-asm LDS
+// loads: pixels_ready() waits for them (it names the registers so that every use is ordered behind it).
+__device__ __forceinline__ uint32_t lds_pixel_hi(uint32_t addr) {
+    uint32_t r;
+    asm volatile("ds_read_u8_d16_hi %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_pixel_hi_off(uint32_t addr) {
+    uint32_t r;
+    asm volatile("ds_read_u8_d16_hi %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ unsigned key_of(uint32_t r, unsigned stride) {
+    unsigned k;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(k) : "v"(r), "s"(0x000F0000u), "v"(stride));
+    return k;
+}
+__device__ __forceinline__ unsigned msb_of(uint32_t r) { return r >> 20; }
+
 template <int STRIDE_SCALE>
-__device__ __forceinline__ void simplex_walk(unsigned ka, int basea, int vb, int vc, int vd, int (&idx)[5], unsigned (&w)[5],
-                                             unsigned (&f)[4]) {
-    unsigned k0 = ka;
-    unsigned k1 = ((unsigned)(vb & 15) << 16) | (unsigned)(kStrideB * STRIDE_SCALE);
-    unsigned k2 = ((unsigned)(vc & 15) << 16) | (unsigned)(kStrideC * STRIDE_SCALE);
-    unsigned k3 = ((unsigned)(vd & 15) << 16) | (unsigned)(kStrideD * STRIDE_SCALE);
-    idx[0] = basea + (int)__umul24((unsigned)(vb >> 4), kStrideB * STRIDE_SCALE) +
-             (int)__umul24((unsigned)(vc >> 4), kStrideC * STRIDE_SCALE) + (vd >> 4) * STRIDE_SCALE;
-    ce_desc(k0, k1);
-    ce_desc(k2, k3);
-    ce_desc(k0, k2);
-    ce_desc(k1, k3);
-    ce_desc(k1, k2);
-    const unsigned f0 = k0 >> 16, f1 = k1 >> 16, f2 = k2 >> 16, f3 = k3 >> 16;
-    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
-    idx[1] = idx[0] + (int)(k0 & 0xFFFFu);
-    idx[2] = idx[1] + (int)(k1 & 0xFFFFu);
-    idx[3] = idx[2] + (int)(k2 & 0xFFFFu);
-    idx[4] = idx[3] + (int)(k3 & 0xFFFFu);
-    w[0] = kQ - f0;
-    w[1] = f0 - f1;
-    w[2] = f1 - f2;
-    w[3] = f2 - f3;
-    w[4] = f3;
+struct Walk {
+    static constexpr int ALL = (kStrideA + kStrideB + kStrideC + kStrideD) * STRIDE_SCALE;   // vertex 4 - vertex 0
+    int i0, i1, i2, i3m;        // byte offsets of vertices 0, 1, 2 and (vertex 3 - ALL); vertex 4 = i0 + ALL
+    unsigned f0, f1, f2, f3;    // sorted LSBs
+    // vertex n = address a(n) + constant c(n): the constant goes into the DS immediate offset
+    __device__ __forceinline__ uint32_t a(int n) const { return (uint32_t)(n == 0 ? i0 : n == 1 ? i1 : n == 2 ? i2 : n == 3 ? i3m : i0); }
+    static constexpr int c(int n) { return n >= 3 ? ALL : 0; }
+    __device__ __forceinline__ uint32_t ld32(int n) const { return n >= 3 ? lds_ld32<ALL>(a(n)) : lds_ld32<0>(a(n)); }
+    __device__ __forceinline__ int ldi8(int n) const { return n >= 3 ? lds_ldi8<ALL>(a(n)) : lds_ldi8<0>(a(n)); }
+};
+
+// ka = key of the centre pixel, basea = its MSB contribution to the index (both shared by the rotations of a position);
+// rb, rc, rd = the other three pixels as lds_pixel_hi() returned them; sb, sc, sd = the axis strides (bytes) in VGPRs
+template <int STRIDE_SCALE>
+__device__ __forceinline__ Walk<STRIDE_SCALE> simplex_walk(unsigned ka, int basea, uint32_t rb, uint32_t rc, uint32_t rd,
+                                                           unsigned sb, unsigned sc, unsigned sd) {
+    Walk<STRIDE_SCALE> W;
+    const unsigned kb = key_of(rb, sb), kc = key_of(rc, sc), kd = key_of(rd, sd);
+    // base index, Horner over the MSBs: ((b * 17 + c) * 17 + d) * scale + a-part
+    const unsigned t = __umul24(__umul24(msb_of(rb), (unsigned)kL) + msb_of(rc), (unsigned)kL) + msb_of(rd);
+    W.i0 = basea + (int)(t * STRIDE_SCALE);
+    const unsigned m = umax3(ka, kb, kc), e = umed3(ka, kb, kc), n = umin3(ka, kb, kc);
+    const unsigned s0 = m > kd ? m : kd;
+    const unsigned s1 = umed3(m, e, kd);
+    const unsigned s2 = umed3(e, n, kd);
+    const unsigned s3 = n < kd ? n : kd;
+    W.i1 = W.i0 + (int)(s0 & 0xFFFFu);
+    W.i2 = W.i1 + (int)(s1 & 0xFFFFu);
+    W.i3m = W.i0 - (int)(s3 & 0xFFFFu);
+    W.f0 = s0 >> 16; W.f1 = s1 >> 16; W.f2 = s2 >> 16; W.f3 = s3 >> 16;
+    return W;
 }
 
 // global -> LDS copy of `bytes` (rounded up to 16) by the whole workgroup; every load of a
@@ -196,31 +272,58 @@ __device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__
 // whose centres live in a source tile (pitch SP).  MODE/ROT0/NROT/RSTEP are static so
 // the neighbour offsets fold into DS immediates.  PHASE: 0 = first (store), 1 = add,
 // 2 = add and finalise with (div, bias) into `dst8`.
+// smallest (most negative) neighbour byte offset over the rotations of a phase: DS immediates are unsigned
+template <int SP>
+__host__ __device__ constexpr int min_tile_offset(char mode, int rot0, int nrot, int rstep) {
+    int m = 0;
+    for (int i = 0; i < nrot; ++i) {
+        const Off3 o = tile_offsets<SP>(mode, rot0 + i * rstep);
+        for (int k = 0; k < 3; ++k) m = o.o[k] < m ? o.o[k] : m;
+    }
+    return m;
+}
+template <int SP, char MODE, int ROT, int MINO>
+__device__ __forceinline__ void load_rotation(uint32_t base, uint32_t& rb, uint32_t& rc, uint32_t& rd) {
+    constexpr Off3 o = tile_offsets<SP>(MODE, ROT);
+    rb = lds_pixel_hi_off<o.o[0] - MINO>(base);
+    rc = lds_pixel_hi_off<o.o[1] - MINO>(base);
+    rd = lds_pixel_hi_off<o.o[2] - MINO>(base);
+}
+
+// NROT (2 or 4) lookups of one byte LUT around the pixel at LDS address `center`; lut_a = LDS address of the LUT.
+// Returns the numerator sum_rot sum_n w_n P_n (weights sum to 16 per lookup).
 template <int SP, char MODE, int ROT0, int NROT, int RSTEP>
-__device__ __forceinline__ int byte_lookups(const int8_t* lut, const uint8_t* src_center) {
-    // stage A: every pixel read of the NROT rotations
-    const int va = src_center[0];
-    int vb[NROT], vc[NROT], vd[NROT];
-#pragma unroll
-    for (int i = 0; i < NROT; ++i) {
-        const Off3 o = tile_offsets<SP>(MODE, ROT0 + i * RSTEP);
-        vb[i] = src_center[o.o[0]];
-        vc[i] = src_center[o.o[1]];
-        vd[i] = src_center[o.o[2]];
+__device__ __forceinline__ int byte_lookups(uint32_t lut_a, uint32_t center) {
+    static_assert(NROT == 2 || NROT == 4, "rotation pairs or all four");
+    constexpr int MINO = min_tile_offset<SP>(MODE, ROT0, NROT, RSTEP);
+    // stage A: every pixel read of the NROT rotations (high-half loads, see lds_pixel_hi)
+    const uint32_t base = center + (uint32_t)MINO;
+    uint32_t ra = lds_pixel_hi_off<-MINO>(base);
+    uint32_t rb[4], rc[4], rd[4];
+    load_rotation<SP, MODE, ROT0, MINO>(base, rb[0], rc[0], rd[0]);
+    load_rotation<SP, MODE, ROT0 + RSTEP, MINO>(base, rb[1], rc[1], rd[1]);
+    if constexpr (NROT == 4) {
+        load_rotation<SP, MODE, ROT0 + 2 * RSTEP, MINO>(base, rb[2], rc[2], rd[2]);
+        load_rotation<SP, MODE, ROT0 + 3 * RSTEP, MINO>(base, rb[3], rc[3], rd[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra), "+v"(rb[0]), "+v"(rc[0]), "+v"(rd[0]), "+v"(rb[1]), "+v"(rc[1]), "+v"(rd[1]), "+v"(rb[2]),
+                       "+v"(rc[2]), "+v"(rd[2]), "+v"(rb[3]), "+v"(rc[3]), "+v"(rd[3]));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra), "+v"(rb[0]), "+v"(rc[0]), "+v"(rd[0]), "+v"(rb[1]), "+v"(rc[1]), "+v"(rd[1]));
     }
     // stage B: walks
-    const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)kStrideA;
-    const int basea = (int)__umul24((unsigned)(va >> 4), kStrideA);
-    int idx[NROT][5];
-    unsigned w[NROT][5], f[NROT][4];
+    const unsigned sa = kStrideA, sb = kStrideB, sc = kStrideC, sd = kStrideD;
+    const unsigned ka = key_of(ra, sa);
+    const int basea = (int)(__umul24(msb_of(ra), kStrideA) + lut_a);      // LDS address of the base corner
+    Walk<1> W[NROT];
 #pragma unroll
-    for (int i = 0; i < NROT; ++i) simplex_walk<1>(ka, basea, vb[i], vc[i], vd[i], idx[i], w[i], f[i]);
+    for (int i = 0; i < NROT; ++i) W[i] = simplex_walk<1>(ka, basea, rb[i], rc[i], rd[i], sb, sc, sd);
     // stage C: all LUT gathers in flight together
     int e[NROT][5];
 #pragma unroll
     for (int i = 0; i < NROT; ++i)
 #pragma unroll
-        for (int n = 0; n < 5; ++n) e[i][n] = (int)lut[idx[i][n]];
+        for (int n = 0; n < 5; ++n) e[i][n] = W[i].ldi8(n);
     __builtin_amdgcn_sched_barrier(0);
     // stage D: sum_n w_n P_n = 16 P_0 + sum_n f_n (P_{n+1} - P_n)   (w_0 = 16 - f_0, w_n = f_{n-1} - f_n, w_4 = f_3):
     //          four multiply-adds and four subtractions per lookup instead of five weights + five multiply-adds
@@ -228,8 +331,10 @@ __device__ __forceinline__ int byte_lookups(const int8_t* lut, const uint8_t* sr
 #pragma unroll
     for (int i = 0; i < NROT; ++i) {
         sum0 += e[i][0];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc += __mul24((int)f[i][n], e[i][n + 1] - e[i][n]);
+        acc += __mul24((int)W[i].f0, e[i][1] - e[i][0]);
+        acc += __mul24((int)W[i].f1, e[i][2] - e[i][1]);
+        acc += __mul24((int)W[i].f2, e[i][3] - e[i][2]);
+        acc += __mul24((int)W[i].f3, e[i][4] - e[i][3]);
     }
     return acc + kQ * sum0;
 }
@@ -256,9 +361,10 @@ template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, i
 __device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src, int16_t* acc16, uint8_t* dst8,
                                            int y0g, int x0g, int sy0g, int sx0g, int H, int W, int div, int bias,
                                            int tid) {
+    const uint32_t lut_a = lds_addr(lut), src_a = lds_addr(src);
     for (int p = tid; p < NDST; p += NT) {
         int a = center_addr<DPc, SP>(p, y0g, x0g, sy0g, sx0g, H, W, nullptr);
-        int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut, src + a);
+        int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut_a, src_a + (uint32_t)a);
         if (PHASE != 0) v += (int)acc16[p];
         if (PHASE == 2)
             dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
@@ -662,7 +768,7 @@ sr_fused_kernel(Params P) {
         // per VGPR).  The position ids stay in LST and are re-read when the sums are finalised.
         constexpr int MAXP = (MAXR + 1) / 2;
         uint32_t slot2[MAXP];
-        uint32_t accA[MAXR], accB2[MAXP];
+        uint32_t accA[MAXR], accB[MAXR];
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
             const uint32_t p = lst[k * NT + tid];
@@ -670,7 +776,7 @@ sr_fused_kernel(Params P) {
             if (p != 0xFFFFu) a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr);
             if (k & 1) slot2[k >> 1] |= a << 16; else slot2[k >> 1] = a;
             accA[k] = 0;
-            if (!(k & 1)) accB2[k >> 1] = 0;
+            accB[k] = 0;
         }
         __syncthreads();
 
@@ -726,6 +832,10 @@ sr_fused_kernel(Params P) {
                     o0.o[i] = P.s2off[l][i];
                     o1.o[i] = P.s2off[l][3 + i];
                 }
+                // LDS address of the quarter piece's logical entry 0 (the piece starts at top-axis level 4 q)
+                const uint32_t qbase = lds_addr(smem + D::OFF_X) - (uint32_t)q * (4u * kStrideA * 4u);
+                const uint32_t bt_a = lds_addr(Bt);
+                const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;   // axis strides, bytes
                 const int rsq = __builtin_amdgcn_readfirstlane(ctl[8 + q]);
                 const int req = __builtin_amdgcn_readfirstlane(ctl[12 + q]);
                 __syncthreads();
@@ -743,40 +853,75 @@ sr_fused_kernel(Params P) {
                     if (k >= rsq && k < req) {
                         const uint32_t sa = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
                         if (sa != 0xFFFFu) {
-                            const uint8_t* cp = Bt + sa;
-                            // stage A: the 7 pixel reads of the two rotations
-                            const int va = cp[0];
-                            const int vb0 = cp[o0.o[0]], vc0 = cp[o0.o[1]], vd0 = cp[o0.o[2]];
-                            const int vb1 = cp[o1.o[0]], vc1 = cp[o1.o[1]], vd1 = cp[o1.o[2]];
-                            // stage B: both walks (byte offsets into the quarter piece)
-                            const int basea = (int)__umul24((unsigned)((va >> 4) - 4 * q), kStrideA * 4);
-                            const unsigned ka = ((unsigned)(va & 15) << 16) | (unsigned)(kStrideA * 4);
-                            int i0x[5], i1x[5];
-                            unsigned w0[5], w1[5], fu0[4], fu1[4];
-                            simplex_walk<4>(ka, basea, vb0, vc0, vd0, i0x, w0, fu0);
-                            simplex_walk<4>(ka, basea, vb1, vc1, vd1, i1x, w1, fu1);
+                            // stage A: the 7 pixel reads of the two rotations (high-half loads, see lds_pixel_hi)
+                            const uint32_t cpa = bt_a + sa;
+                            uint32_t ra = lds_pixel_hi(cpa);
+                            uint32_t rb0 = lds_pixel_hi(cpa + (uint32_t)o0.o[0]), rc0 = lds_pixel_hi(cpa + (uint32_t)o0.o[1]),
+                                     rd0 = lds_pixel_hi(cpa + (uint32_t)o0.o[2]);
+                            uint32_t rb1 = lds_pixel_hi(cpa + (uint32_t)o1.o[0]), rc1 = lds_pixel_hi(cpa + (uint32_t)o1.o[1]),
+                                     rd1 = lds_pixel_hi(cpa + (uint32_t)o1.o[2]);
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra), "+v"(rb0), "+v"(rc0), "+v"(rd0), "+v"(rb1), "+v"(rc1), "+v"(rd1));
+                            // stage B: both walks (LDS addresses into the quarter piece)
+                            const int basea = (int)(__umul24(msb_of(ra), kStrideA * 4) + qbase);
+                            const unsigned ka = key_of(ra, st_a);
+                            const Walk<4> W0 = simplex_walk<4>(ka, basea, rb0, rc0, rd0, st_b, st_c, st_d);
+                            const Walk<4> W1 = simplex_walk<4>(ka, basea, rb1, rc1, rd1, st_b, st_c, st_d);
                             // stage C: ten dword gathers in flight together
-                            const uint8_t* qb = smem + D::OFF_X;
                             uint32_t d0[5], d1[5];
+#if defined(LERF_EXP) && LERF_EXP == 1      // diagnostic: conflict-free gathers (one dword per lane)
 #pragma unroll
-                            for (int n = 0; n < 5; ++n) d0[n] = *reinterpret_cast<const uint32_t*>(qb + i0x[n]);
+                            for (int n = 0; n < 5; ++n) d0[n] = lds_ld32(qbase + 4 * kStrideA * 16 + lane * 4 + n * 256) + W0.a(n);
 #pragma unroll
-                            for (int n = 0; n < 5; ++n) d1[n] = *reinterpret_cast<const uint32_t*>(qb + i1x[n]);
+                            for (int n = 0; n < 5; ++n) d1[n] = lds_ld32(qbase + 4 * kStrideA * 16 + lane * 4 + n * 256 + 2048) + W1.a(n);
+#elif defined(LERF_EXP) && LERF_EXP == 2    // diagnostic: no gathers
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) d0[n] = W0.a(n);
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) d1[n] = W1.a(n);
+#else
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) d0[n] = W0.ld32(n);
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) d1[n] = W1.ld32(n);
+#endif
+#if defined(LERF_EXP) && LERF_EXP >= 4     // diagnostic: marginal cost of ten extra instructions of one class per slot
+                            {
+                                uint32_t z = (uint32_t)W0.i0;
+#pragma unroll
+                                for (int n = 0; n < 10; ++n) {
+#if LERF_EXP == 4
+                                    asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(z) : "v"(vb0));
+#elif LERF_EXP == 5
+                                    asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(z) : "v"(vb0));
+#elif LERF_EXP == 6
+                                    asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(z) : "v"(vb0), "v"(vc0));
+#elif LERF_EXP == 7
+                                    asm volatile("v_add_u32 %0, %0, %1" : "+v"(z) : "v"(vb0));
+#elif LERF_EXP == 8
+                                    asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(z) : "v"(vb0));
+#endif
+                                }
+                                if (z == 0x12345u) accA[k] += 1;
+                            }
+#endif
                             __builtin_amdgcn_sched_barrier(0);
-                            // stage D: two 24-bit MADs per corner (fields e0|e2<<16, and e1)
-                            uint32_t a = accA[k], bb = accB2[k >> 1];
+                            // stage D: two 24-bit MADs per corner: the entry is e0 | 0 << 8 | e2 << 16 | e1 << 24, and a 24-bit
+                            // multiply reads bits 0..23 only, so the (e0, e2) pair needs no mask; e1 is shifted down
+                            const unsigned w0[5] = {(unsigned)kQ - W0.f0, W0.f0 - W0.f1, W0.f1 - W0.f2, W0.f2 - W0.f3, W0.f3};
+                            const unsigned w1[5] = {(unsigned)kQ - W1.f0, W1.f0 - W1.f1, W1.f1 - W1.f2, W1.f2 - W1.f3, W1.f3};
+                            uint32_t a = accA[k], bb = accB[k];
 #pragma unroll
                             for (int n = 0; n < 5; ++n) {
-                                a += __umul24(w0[n], d0[n] & 0x00FF00FFu);
-                                bb += __umul24(w0[n], (k & 1) ? ((d0[n] >> 8) & 0x00FF0000u) : (d0[n] >> 24));
+                                a += __umul24(w0[n], d0[n]);
+                                bb += __umul24(w0[n], d0[n] >> 24);
                             }
 #pragma unroll
                             for (int n = 0; n < 5; ++n) {
-                                a += __umul24(w1[n], d1[n] & 0x00FF00FFu);
-                                bb += __umul24(w1[n], (k & 1) ? ((d1[n] >> 8) & 0x00FF0000u) : (d1[n] >> 24));
+                                a += __umul24(w1[n], d1[n]);
+                                bb += __umul24(w1[n], d1[n] >> 24);
                             }
                             accA[k] = a;
-                            accB2[k >> 1] = bb;
+                            accB[k] = bb;
                         }
                     }
                 }
@@ -794,7 +939,7 @@ sr_fused_kernel(Params P) {
                 const int div2 = kQ * 12;
                 int n0 = (int)(accA[k] & 0xFFFFu) - div2;
                 int n2 = (int)(accA[k] >> 16) - div2;
-                int n1 = (int)((k & 1) ? (accB2[k >> 1] >> 16) : (accB2[k >> 1] & 0xFFFFu)) - div2;
+                int n1 = (int)accB[k] - div2;
                 uint32_t h0 = (uint32_t)rne_div_clip255_fast(n0, div2);
                 uint32_t h1 = (uint32_t)rne_div_clip255_fast(n1, div2);
                 uint32_t h2 = (uint32_t)rne_div_clip255_fast(n2, div2);

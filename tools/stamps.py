@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["LERF_HIP_LIB"] = os.path.join(ROOT, "lerf-pytorch_amd", "liblerf_hip_stamps.so")
+os.environ.setdefault("LERF_HIP_LIB", os.path.join(ROOT, "lerf-pytorch_amd", "liblerf_hip_stamps.so"))
 
 import numpy as np
 import torch
@@ -17,20 +17,22 @@ import lerf_pytorch_amd as L
 from lerf_pytorch_amd import ops
 import bench
 
+H, W = 1080, 1920
+
 NAMES = ["in+lut0", "s1:s", "copy", "s1:c", "copy", "s1:t", "bin+slots", "s2 copies", "s2 lookups", "(s2 total)",
          "finalise", "geometry", "stage3"]
 
 
 def main():
     eng = L.LerfEngine.shipped("lerf-g")
-    geo = eng.sr_geometry((bench.H, bench.W), 2)
-    for kind in ("noise", "natural", "constant"):
+    geo = eng.sr_geometry((H, W), 2)
+    for kind in (sys.argv[1:] or ("noise", "natural", "constant")):
         if kind == "constant":
-            x = torch.full((1, bench.H, bench.W, 3), 128, dtype=torch.uint8, device="cuda")
+            x = torch.full((1, H, W, 3), 128, dtype=torch.uint8, device="cuda")
         else:
-            x = torch.from_numpy(bench.synth_frames(kind, 1, 7)).cuda()
-        tiles = ((bench.H + 63) // 64) * ((bench.W + 63) // 64)
-        ws = torch.zeros(max(tiles * 16 * 8, 4 * bench.H * bench.W * 3), dtype=torch.uint8, device="cuda")
+            x = torch.from_numpy(bench.synth_frames(kind, 1, 7, H, W)).cuda()
+        tiles = ((H + 63) // 64) * ((W + 63) // 64)
+        ws = torch.zeros(max(tiles * 16 * 8, 4 * H * W * 3), dtype=torch.uint8, device="cuda")
         for _ in range(2):
             ops.sr_fused_u8(x, eng.luts, geo, "gauss", 10.0, workspace=ws)
         torch.cuda.synchronize()
