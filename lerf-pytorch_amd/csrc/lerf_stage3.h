@@ -110,7 +110,20 @@ __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]
 #pragma clang fp contract(off)
     // the sums start from the first tap (0 + x and fma(w, v, 0) are exact, but without fast-math the compiler keeps them)
     float num, den;
-    if (GAUSS) {
+    if (GAUSS && SCALED && N == 4) {
+        // 2x2 support on an SR grid: the nearest tap lies within half a pixel on both axes, so its pre-scaled form is
+        // at most 0.5 log2(e) (25 + 25 + 50) = 72 and exp2(-72) is a normal float32 -- the denominator cannot vanish
+        // and the weights need no shift by the support's minimum (3 v_min + 4 v_sub per output saved; the relative
+        // accuracy of w = exp2(-e) is that of e either way)
+        den = __builtin_amdgcn_exp2f(-e[0]);
+        num = den * v[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) {
+            const float w = __builtin_amdgcn_exp2f(-e[k]);
+            num = __builtin_fmaf(w, v[k], num);
+            den += w;
+        }
+    } else if (GAUSS) {
         float emin = e[0];
 #pragma unroll
         for (int k = 1; k < N; ++k) emin = fminf(emin, e[k]);
