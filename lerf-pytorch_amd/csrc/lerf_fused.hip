@@ -975,11 +975,13 @@ sr_fused_kernel(Params P) {
     const int nrow = i1 - i0, ncol = j1 - j0;
 
     LERF_STAMP(11);
-    // ---- stage 3.  S = 2: consecutive output rows that start at the same source row (2 rows at x2, 3 at x3 ...)
-    //      form a row group and share their taps: one task = (row group, one 4-byte-aligned output dword column);
-    //      the tap loads, the u8 -> f32 conversions and the column terms are done once per group.
-    if constexpr (S == 2) {
-        constexpr int GMAX = 5;                                   // rows per group (scale <= 4.1 is enforced by the host)
+    // ---- stage 3.  Consecutive output rows that start at the same source row (2 rows at x2, 3 at x3 ...) form a row
+    //      group and share their taps: one task = (row group, one 4-byte-aligned output dword column); the tap loads, the
+    //      u8 -> f32 conversions and the column-only terms are done once per group, the rows pay one multiply and two
+    //      FMAs per tap.  Same code for the 2x2 and the 4x4 support.
+    {
+        constexpr int SS = S * S;
+        constexpr int GMAX = S == 2 ? 5 : 3;                      // rows per group (larger runs are split)
         int* g_grp = reinterpret_cast<int*>(g_dc + D::GEO_ROWS * S);
         const int ncolc = ncol * CH;
         const int ndw = (ncolc + 6) >> 2;
@@ -1022,49 +1024,49 @@ sr_fused_kernel(Params P) {
             for (int r = 0; r < GMAX; ++r) packed[r] = 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int xc = min(max(b0 + u, 0), ncolc - 1);
+                const int xc = min(max(b0 + u, 0), ncolc - 1);    // clamped; invalid bytes are not stored
                 const int jl = xc / CH;
                 const int c = xc - jl * CH;
                 const int lc = g_lc[jl];
-                // shared by the rows of the group: per tap (a = column offset, b = row offset)
-                float p0[4], k1[4], ty[4], v[4];
+                // shared by the rows of the group: per tap (a = column offset major, numpy meshgrid 'xy' :95-98; b = row offset)
+                float p0[SS], k1[SS], ty[SS], v[SS];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const float dy = g_dc[jl * 2 + a];
+                for (int a = 0; a < S; ++a) {
+                    const float dy = g_dc[jl * S + a];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
+                    for (int b = 0; b < S; ++b) {
                         const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                        v[a * 2 + b] = (float)(d >> 24);
+                        v[a * S + b] = (float)(d >> 24);
                         const float k0 = (float)(d & 0xFFu);
                         if (KIND == LERF_KIND_GAUSS) {
                             // column-only terms of the quadratic form: p0 <- (-2 rho) ty, ty <- ty^2 (gauss_form_cols)
                             const float tyv = s3::gauss_t_u8((float)((d >> 16) & 0xFFu), dy);
-                            p0[a * 2 + b] = s3::gauss_m2rho_u8(k0) * tyv;
-                            k1[a * 2 + b] = (float)((d >> 8) & 0xFFu);
-                            ty[a * 2 + b] = tyv * tyv;
+                            p0[a * S + b] = s3::gauss_m2rho_u8(k0) * tyv;
+                            k1[a * S + b] = (float)((d >> 8) & 0xFFu);
+                            ty[a * S + b] = tyv * tyv;
                         } else {
                             const float alpha = s3::lin_alpha_u8(k0, ms255);
-                            p0[a * 2 + b] = alpha;
-                            ty[a * 2 + b] = s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
-                            k1[a * 2 + b] = 0.0f;
+                            p0[a * S + b] = alpha;
+                            ty[a * S + b] = s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
+                            k1[a * S + b] = 0.0f;
                         }
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < GMAX; ++r) {
                     if (r < gs) {
-                        float e[4];
+                        float e[SS];
 #pragma unroll
-                        for (int a = 0; a < 2; ++a)
+                        for (int a = 0; a < S; ++a)
 #pragma unroll
-                            for (int b = 0; b < 2; ++b) {
-                                const float dx = g_dr[(il0 + r) * 2 + b];
+                            for (int b = 0; b < S; ++b) {
+                                const float dx = g_dr[(il0 + r) * S + b];
                                 if (KIND == LERF_KIND_GAUSS)
-                                    e[a * 2 + b] = s3::gauss_form_cols(s3::gauss_t_u8(k1[a * 2 + b], dx), ty[a * 2 + b], p0[a * 2 + b]);
+                                    e[a * S + b] = s3::gauss_form_cols(s3::gauss_t_u8(k1[a * S + b], dx), ty[a * S + b], p0[a * S + b]);
                                 else
-                                    e[a * 2 + b] = s3::lin_factor(p0[a * 2 + b], dx, s3::dist_class_f(dx)) * ty[a * 2 + b];
+                                    e[a * S + b] = s3::lin_factor(p0[a * S + b], dx, s3::dist_class_f(dx)) * ty[a * S + b];
                             }
-                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, 4, true, true>(e, v);
+                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, SS, true, true>(e, v);
                         bool tie;
                         packed[r] = s3::pack_u8_tie(xf, u, packed[r], &tie);
                         if (tie) tiemask |= 1u << (r * 4 + u);
@@ -1081,17 +1083,17 @@ sr_fused_kernel(Params P) {
                     const int jl = xc / CH;
                     const int c = xc - jl * CH;
                     const int lc = g_lc[jl];
-                    uint32_t dd[4];
-                    double dx64[2], dy64[2];
+                    uint32_t dd[SS];
+                    double dx64[S], dy64[S];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il0 + r) * 2 + b];
+                    for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il0 + r) * S + b];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * 2 + a];
+                    for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                    for (int a = 0; a < S; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) dd[a * 2 + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                    const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, 2>(dd, dx64, dy64, P.max_sigma));
+                        for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                    const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
 #pragma unroll
                     for (int rr = 0; rr < GMAX; ++rr)
                         if (rr == r) packed[rr] = (packed[rr] & ~(0xFFu << (8 * u))) | (r8 << (8 * u));
@@ -1110,90 +1112,6 @@ sr_fused_kernel(Params P) {
                             if (b0 + u >= 0 && b0 + u < ncolc) sr[b0 + u] = (uint8_t)(packed[r] >> (8 * u));
                     }
                 }
-            }
-        }
-    } else
-    // ---- stage 3, general support: one task = one 4-byte-aligned dword of an output row segment
-    {
-        const int ncolc = ncol * CH;
-        const int ndw = (ncolc + 6) >> 2;                         // dwords that can touch a row segment
-        const unsigned magic = (unsigned)((0x100000000ull + (unsigned)ndw - 1) / (unsigned)(ndw > 0 ? ndw : 1));
-        const float ms255 = P.max_sigma * (1.0f / 255.0f);
-        const int64_t rowpitch = (int64_t)P.oW * CH;
-        uint8_t* seg0 = outp + ((int64_t)i0 * P.oW + j0) * CH;
-        const int ntask = nrow * ndw;
-        for (int t = tid; t < ntask; t += NT) {
-            const int il = (int)__umulhi((unsigned)t, magic);
-            const int dw = t - il * ndw;
-            uint8_t* seg = seg0 + il * rowpitch;
-            const int a0 = (int)(reinterpret_cast<uintptr_t>(seg) & 3u);
-            const int b0 = dw * 4 - a0;                           // first byte of this dword, relative to the segment
-            const int lr = g_lr[il];
-            float dxr[S];
-#pragma unroll
-            for (int b = 0; b < S; ++b) dxr[b] = g_dr[il * S + b];
-            uint32_t packed = 0;
-            unsigned tiemask = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int xc = min(max(b0 + u, 0), ncolc - 1);    // clamped; invalid bytes are not stored
-                const int jl = xc / CH;
-                const int c = xc - jl * CH;
-                const int lc = g_lc[jl];
-                float e[S * S], v[S * S];
-#pragma unroll
-                for (int a = 0; a < S; ++a) {                     // column offset major (numpy meshgrid 'xy', :95-98)
-                    const float dy = g_dc[jl * S + a];
-#pragma unroll
-                    for (int b = 0; b < S; ++b) {
-                        const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                        const float dx = dxr[b];
-                        v[a * S + b] = (float)(d >> 24);
-                        const float k0 = (float)(d & 0xFFu);
-                        if (KIND == LERF_KIND_GAUSS) {
-                            e[a * S + b] = s3::gauss_form_u8(k0, (float)((d >> 8) & 0xFFu), (float)((d >> 16) & 0xFFu), dx, dy);
-                        } else {
-                            const float alpha = s3::lin_alpha_u8(k0, ms255);
-                            e[a * S + b] = s3::lin_factor(alpha, dx, s3::dist_class_f(dx)) *
-                                           s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
-                        }
-                    }
-                }
-                const float xf = s3::finish<KIND == LERF_KIND_GAUSS, S * S, true, true>(e, v);
-                bool tie;
-                packed = s3::pack_u8_tie(xf, u, packed, &tie);
-                if (tie) tiemask |= 1u << u;
-            }
-            if (tiemask != 0 && P.dis_r64 != nullptr) {
-                // rare: re-evaluate in float64 exactly as the reference does (lerf_stage3.h, tie guard)
-#pragma unroll 1
-                for (int u = 0; u < 4; ++u) {
-                    if (!((tiemask >> u) & 1u)) continue;
-                    const int xc = min(max(b0 + u, 0), ncolc - 1);
-                    const int jl = xc / CH;
-                    const int c = xc - jl * CH;
-                    const int lc = g_lc[jl];
-                    uint32_t dd[S * S];
-                    double dx64[S], dy64[S];
-#pragma unroll
-                    for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il) * S + b];
-#pragma unroll
-                    for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
-#pragma unroll
-                    for (int a = 0; a < S; ++a)
-#pragma unroll
-                        for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                    const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
-                    packed = (packed & ~(0xFFu << (8 * u))) | (r8 << (8 * u));
-                }
-            }
-            if (b0 >= 0 && b0 + 3 < ncolc) {
-                // streaming store: the output is never re-read here, keep the LUT pack resident in L2 instead
-                __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(seg + b0));
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (b0 + u >= 0 && b0 + u < ncolc) seg[b0 + u] = (uint8_t)(packed >> (8 * u));
             }
         }
     }

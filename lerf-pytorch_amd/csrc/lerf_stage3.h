@@ -110,11 +110,11 @@ __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]
 #pragma clang fp contract(off)
     // the sums start from the first tap (0 + x and fma(w, v, 0) are exact, but without fast-math the compiler keeps them)
     float num, den;
-    if (GAUSS && SCALED && N == 4) {
-        // 2x2 support on an SR grid: the nearest tap lies within half a pixel on both axes, so its pre-scaled form is
-        // at most 0.5 log2(e) (25 + 25 + 50) = 72 and exp2(-72) is a normal float32 -- the denominator cannot vanish
-        // and the weights need no shift by the support's minimum (3 v_min + 4 v_sub per output saved; the relative
-        // accuracy of w = exp2(-e) is that of e either way)
+    if (GAUSS && SCALED && (N == 4 || N == 16)) {
+        // 2x2 / 4x4 support on an SR grid (taps at left .. left+S-1 with left = ceil(g - S/2 - eps)): the nearest tap lies
+        // within half a pixel on both axes, so its pre-scaled form is at most 0.5 log2(e) (25 + 25 + 50) = 72 and
+        // exp2(-72) is a normal float32 -- the denominator cannot vanish and the weights need no shift by the support's
+        // minimum (N-1 v_min + N v_sub per output saved; the relative accuracy of w = exp2(-e) is that of e either way)
         den = __builtin_amdgcn_exp2f(-e[0]);
         num = den * v[0];
 #pragma unroll
