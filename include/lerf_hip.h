@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LERF_ABI_VERSION 2
+#define LERF_ABI_VERSION 3
 #define LERF_MAX_MODES 5          /* s, c, t, d, y  (resample/eval_lut_sr.py:12-18) */
 #define LERF_LUT_ENTRIES 83521    /* 17^4, interval = 4 (resample/eval_lut_sr.py:27-28) */
 #define LERF_MAX_SUPPORT 8
@@ -265,6 +265,18 @@ int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const fl
 int lerf_resize_bwd_f32(const float* feat, const float* h0, const float* h1, const float* h2, int N, int H, int W,
                         const lerf_sr_geo_t* geo, int kind, double max_sigma, const float* grad_out, float* grad_feat,
                         float* grad_h0, float* grad_h1, float* grad_h2, void* stream);
+
+/* ---- net -> LUT transfer (resample/transfer_to_lut.py:12-170): one hyper-network of the reference's SRNetsSWF2
+ * (resample/model.py:81-99; an SRNet = SRUnit MLP, common/network.py:40-163) evaluated on all L^4 sampled pixel
+ * tuples (L = 2^(8-interval) + 1; get_input_tensor :12-42, first pixel = slowest axis) and quantised like :117-119:
+ * lut[e][c] = int8(round_half_even(clamp(y, -1, 1) * 127)), C order [L^4][outC] -- the array the reference saves as
+ * LUT_<key>.npy (there with two trailing singleton dims, scripts.sh:19-24).
+ * weights: device, lerf_srnet_weight_floats(outC) floats: W1[64][4] b1[64] W2[64][64] b2[64] W3[64][128] b3[64]
+ * W4[64][192] b4[64] W5[64][256] b5[64] W6[outC][320] b6[outC]  (the state_dict tensors of one SRNet, flattened in
+ * module order).  y (optional, device float32 [L^4][outC]): the network outputs before quantisation.
+ * The hidden layers run on the matrix cores (float32-input MFMA: exact float32 arithmetic). */
+size_t lerf_srnet_weight_floats(int outC);
+int lerf_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut, float* y, void* stream);
 
 #ifdef __cplusplus
 }

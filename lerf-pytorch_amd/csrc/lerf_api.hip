@@ -303,6 +303,14 @@ int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_war
     return rc != LERF_OK ? rc : check_launch();
 }
 
+size_t lerf_srnet_weight_floats(int outC) { return outC >= 1 && outC <= 4 ? srnet_weight_floats(outC) : 0; }
+
+int lerf_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut, float* y, void* stream) {
+    if (!weights || !lut) return LERF_EINVAL;
+    int rc = launch_srnet_to_lut(weights, outC, interval, lut, y, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {
     // Two uses, the larger one sizes it: (a) the two-launch tile-fused path parks the stage-1 output of the batch there
     // (n frames, frame stride rounded up to 16 bytes) between s1_kernel and the stage-2/3 launch; (b) the general

@@ -68,6 +68,10 @@ int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st);
 int launch_sr_fused(const FusedArgs& a, hipStream_t st);
 bool fused_stages_supported(const FusedArgs& a);
 int launch_stages_fused(const FusedArgs& a, hipStream_t st);
+// lerf_transfer.hip
+size_t srnet_weight_floats(int outC);
+int launch_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut, float* y, hipStream_t st);
+
 int launch_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, hipStream_t st);
 int launch_warp_packed(const uint32_t* packed, int H, int W, int C, const WarpGeo& geo, int kind, float max_sigma,
                        void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, hipStream_t st);

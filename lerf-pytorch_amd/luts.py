@@ -86,6 +86,14 @@ class LutSet:
         return cls(arrays, 1 if linear else 3, modes, modes2, device)
 
     @classmethod
+    def from_arrays(cls, arrays, modes="sct", modes2="sct", device=None):
+        """From a {key: int8 [17^4, oC]} dict, e.g. the output of resample.transfer_to_lut.transfer(); the number of
+        hyper-parameter channels is read off the stage-2 tables (3 = LeRF-G, 1 = LeRF-L)."""
+        a = np.asarray(arrays["s2_{}r0".format(modes2[0])])
+        oC = int(a.reshape(a.shape[0], -1).shape[1])
+        return cls(arrays, oC, modes, modes2, device)
+
+    @classmethod
     def shipped(cls, name="lerf-g", device=None):
         """The LUTs shipped with the reference (models/lerf-g, models/lerf-l)."""
         return cls.from_dir(os.path.join(ASSET_DIR, name), linear=(name == "lerf-l"), device=device)

@@ -580,3 +580,42 @@ def load_luts(model_dir, linear=False, lut_name="LUTft", modes="sct", modes2="sc
             d["s2_{}r{}".format(mode, r)] = np.load(
                 os.path.join(model_dir, "{}_s2_{}r{}.npy".format(lut_name, mode, r))).reshape(-1, oC)
     return d
+
+
+# ----------------------------------------------------------------------------
+# net -> LUT transfer (resample/transfer_to_lut.py:12-170 driving common/network.py:40-163)
+# ----------------------------------------------------------------------------
+def transfer_inputs(interval: int = 4) -> np.ndarray:
+    """The 17^4 x 4 sampled pixel tuples of get_input_tensor (transfer_to_lut.py:12-42), float32 in [0,1]:
+    base = 0, 16, ..., 240, 255 (:14-15); column 0 (pixel a) is the slowest axis (:33-37), which is what makes
+    index = a*L^3 + b*L^2 + c*L + d in FourSimplexInterpFaster."""
+    base = np.arange(0, 257, 2 ** interval)
+    base[-1] -= 1
+    L = len(base)
+    idx = np.stack(np.meshgrid(*([np.arange(L)] * 4), indexing="ij"), axis=-1).reshape(-1, 4)
+    return (base[idx].astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+
+def srnet_forward(weights: dict, key: str, x: np.ndarray, dtype=np.float64) -> np.ndarray:
+    """One SRNet of the reference's SRNetsSWF2 (resample/model.py:81-99) on [N,4] pixel tuples (a,b,c,d):
+    SRUnit (network.py:40-71): conv1 over the 4 sampled pixels (2x2 kernel for mode s, 1x4 for c/t after the pixel
+    pick of SRNet.forward :139-152 -- either way the flattened kernel meets (a,b,c,d) in order) + ReLU, four dense
+    1x1 layers whose outputs are concatenated to their inputs (:26-37), conv6 + tanh.  Returns [N, outC] in (-1, 1).
+    `weights`: the module's state_dict as arrays (assets/models/<model>/srnets_weights.npz)."""
+    p = key + ".model."
+    h = x.astype(dtype)
+    w1 = weights[p + "conv1.conv.weight"].reshape(-1, 4).astype(dtype)
+    h = np.maximum(h @ w1.T + weights[p + "conv1.conv.bias"].astype(dtype), 0)
+    for k in (2, 3, 4, 5):
+        w = weights[p + "conv%d.conv1.conv.weight" % k].reshape(64, -1).astype(dtype)
+        f = np.maximum(h @ w.T + weights[p + "conv%d.conv1.conv.bias" % k].astype(dtype), 0)
+        h = np.concatenate([h, f], axis=1)
+    w6 = weights[p + "conv6.conv.weight"].reshape(-1, h.shape[1]).astype(dtype)
+    return np.tanh(h @ w6.T + weights[p + "conv6.conv.bias"].astype(dtype))
+
+
+def transfer_lut(weights: dict, key: str, interval: int = 4, dtype=np.float64, return_float=False):
+    """LUT_<key>.npy of transfer_to_lut.py: round(clamp(net(x), -1, 1) * 127) as int8, [17^4, outC] (:117-119)."""
+    y = srnet_forward(weights, key, transfer_inputs(interval), dtype)
+    lut = np.round(np.clip(y, -1, 1) * 127).astype(np.int8)
+    return (lut, y) if return_float else lut

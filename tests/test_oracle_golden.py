@@ -253,3 +253,26 @@ def test_torch_warp_classes_golden(oracle, golden, p):
         np.testing.assert_allclose(out, g13[key + "/nearest"][:, 0], rtol=0, atol=0, equal_nan=True)
         out = oracle.warp_params_f32(feat, None, None, None, M, hw, 4, 1, "cubic")
         np.testing.assert_allclose(out, g13[key + "/cubic"][:, 0], rtol=0, atol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("model,keys", [("lerf-g", ["s1_sr0", "s2_cr1", "s2_tr0"]), ("lerf-l", ["s1_tr0", "s2_sr1"])])
+def test_net_to_lut_transfer_golden(oracle, model, keys):
+    """the float64 restatement of SRNet + the transfer enumeration against the reference's own transfer of its shipped
+    checkpoint (g14): identical int8 LUTs except entries whose value sits within 1e-3 LUT units of a rounding boundary
+    (the reference evaluates in float32), never more than one step, a handful per LUT"""
+    from conftest import ASSETS
+    w = dict(np.load(os.path.join(ASSETS, model, "srnets_weights.npz")))
+    g = np.load(os.path.join(GOLDEN, "g14_transfer_%s.npz" % model))
+    assert np.array_equal(oracle.transfer_inputs(4)[[0, 1, 17, 83520]],
+                          np.array([[0, 0, 0, 0], [0, 0, 0, 16], [0, 0, 16, 0], [255, 255, 255, 255]], np.float32) / np.float32(255))
+    for key in keys:
+        lut, y = oracle.transfer_lut(w, key, return_float=True)
+        ref = g[key]
+        assert lut.shape == ref.shape
+        assert np.max(np.abs(y[g["probe_index"]] - g[key + "/f32"])) <= 1e-5
+        d = lut.astype(int) - ref.astype(int)
+        bad = d != 0
+        assert bad.sum() <= 8 and np.abs(d).max() <= 1
+        if bad.any():
+            amb = np.abs((y * 127) - np.floor(y * 127) - 0.5)
+            assert amb[bad].max() < 1e-3
