@@ -55,6 +55,16 @@ enum {
     LERF_KIND_LANCZOS3 = 6   /* lanczos3d (:53-57, 93-95) */
 };
 
+/* Padding rule of the IMAGE operand of stage 3 (the hyper maps are always edge-padded, :172-174): the `pad_mode` argument of
+ * the reference's resampler classes, np.pad / F.pad names in brackets (resize_right2d_numpy.py:143,208; _torch.py:189). */
+enum {
+    LERF_PAD_CONSTANT = 0,   /* zeros ["constant"] -- the default of every class and the only mode of the uint8 paths */
+    LERF_PAD_EDGE = 1,       /* ["edge" / "replicate"] */
+    LERF_PAD_REFLECT = 2,    /* ["reflect"] */
+    LERF_PAD_SYMMETRIC = 3,  /* ["symmetric"] (numpy only) */
+    LERF_PAD_WRAP = 4        /* ["wrap" / "circular"] */
+};
+
 typedef struct {
     const void* ptr;      /* device pointer */
     int dtype;            /* LERF_U8 / LERF_F32 / LERF_F64 */
@@ -92,6 +102,7 @@ typedef struct {
     const float* dis_c;      /* device [out_w*S] */
     const double* dis_r64;   /* device, optional: float64 distances for LERF_F64 outputs */
     const double* dis_c64;
+    int pad_mode;            /* LERF_PAD_*; non-constant modes: float outputs of lerf_resize only */
 } lerf_sr_geo_t;
 
 /* Homography geometry (resize_right/resize_right2d_numpy.py:306-407): evaluated
@@ -101,6 +112,7 @@ typedef struct {
     int out_h, out_w;
     double minv[9];          /* inverse of the 3x3 matrix, row major */
     int pad_r_lo, pad_r_hi, pad_c_lo, pad_c_hi;
+    int pad_mode;            /* LERF_PAD_*; non-constant modes: float outputs of lerf_warp only */
 } lerf_warp_geo_t;
 
 /* ---------------------------------------------------------------- host side */

@@ -22,6 +22,20 @@ KIND_GAUSS, KIND_LINEAR, KIND_NEAREST, KIND_CUBIC, KIND_BILINEAR, KIND_LANCZOS2,
 KINDS = {"gauss": KIND_GAUSS, "linear": KIND_LINEAR, "nearest": KIND_NEAREST, "cubic": KIND_CUBIC,
          "bilinear": KIND_BILINEAR, "lanczos2": KIND_LANCZOS2, "lanczos3": KIND_LANCZOS3}
 
+# image padding rules (include/lerf_hip.h LERF_PAD_*), by their np.pad and F.pad names
+PAD_MODES = {"constant": 0, "edge": 1, "replicate": 1, "reflect": 2, "symmetric": 3, "wrap": 4, "circular": 4}
+NUMPY_PAD_MODES = ("constant", "edge", "reflect", "symmetric", "wrap")
+TORCH_PAD_MODES = ("constant", "replicate", "reflect", "circular")
+
+
+def pad_mode_code(name, allowed):
+    """LERF_PAD_* of a pad_mode the reference's class would hand to np.pad / F.pad.  The index-remapping modes are
+    implemented; numpy's statistical ones (linear_ramp, maximum, mean, median, minimum, empty) are not."""
+    if name not in allowed:
+        raise NotImplementedError("pad_mode {!r} is not implemented (supported: {})".format(name, ", ".join(allowed)))
+    return PAD_MODES[name]
+
+
 EXPORTS = [
     "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables", "lerf_sr_axis_tables_f32",
     "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
@@ -58,6 +72,7 @@ class SrGeo(C.Structure):
         ("S", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
         ("left_r", C.c_void_p), ("dis_r", C.c_void_p), ("left_c", C.c_void_p), ("dis_c", C.c_void_p),
         ("dis_r64", C.c_void_p), ("dis_c64", C.c_void_p),
+        ("pad_mode", C.c_int),
     ]
 
 
@@ -66,6 +81,7 @@ class WarpGeo(C.Structure):
         ("S", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
         ("minv", C.c_double * 9),
         ("pad_r_lo", C.c_int), ("pad_r_hi", C.c_int), ("pad_c_lo", C.c_int), ("pad_c_hi", C.c_int),
+        ("pad_mode", C.c_int),
     ]
 
 

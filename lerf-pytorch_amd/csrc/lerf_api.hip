@@ -241,6 +241,9 @@ int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, in
     a.dis_r64 = geo->dis_r64; a.dis_c64 = geo->dis_c64;
     a.kind = kind; a.max_sigma = max_sigma;
     a.out = out->ptr; a.out_dtype = out->dtype; a.oy = out->sy; a.ox = out->sx; a.oc = out->sc;
+    a.pad_mode = geo->pad_mode;
+    if (a.pad_mode < LERF_PAD_CONSTANT || a.pad_mode > LERF_PAD_WRAP) return LERF_EINVAL;
+    if (a.pad_mode != LERF_PAD_CONSTANT && out->dtype == LERF_U8) return LERF_EUNSUPPORTED;
     int rc = launch_resize(a, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
@@ -266,6 +269,9 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int 
     memcpy(a.geo.minv, geo->minv, sizeof(a.geo.minv));
     a.geo.pad_r_lo = geo->pad_r_lo; a.geo.pad_r_hi = geo->pad_r_hi;
     a.geo.pad_c_lo = geo->pad_c_lo; a.geo.pad_c_hi = geo->pad_c_hi;
+    a.geo.pad_mode = geo->pad_mode;
+    if (geo->pad_mode < LERF_PAD_CONSTANT || geo->pad_mode > LERF_PAD_WRAP) return LERF_EINVAL;
+    if (geo->pad_mode != LERF_PAD_CONSTANT && out->dtype == LERF_U8) return LERF_EUNSUPPORTED;
     a.kind = kind; a.max_sigma = max_sigma;
     a.out = out->ptr; a.out_dtype = out->dtype; a.oy = out->sy; a.ox = out->sx; a.oc = out->sc;
     int rc = launch_warp(a, as_stream(stream));
@@ -298,6 +304,8 @@ int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_war
     g.S = geo->S; g.oH = geo->out_h; g.oW = geo->out_w;
     memcpy(g.minv, geo->minv, sizeof(g.minv));
     g.pad_r_lo = geo->pad_r_lo; g.pad_r_hi = geo->pad_r_hi; g.pad_c_lo = geo->pad_c_lo; g.pad_c_hi = geo->pad_c_hi;
+    g.pad_mode = LERF_PAD_CONSTANT;
+    if (geo->pad_mode != LERF_PAD_CONSTANT) return LERF_EUNSUPPORTED;
     int rc = launch_warp_packed(packed, H, W, C, g, kind, (float)max_sigma, out->ptr, out->dtype, out->sy, out->sx,
                                 out->sc, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();

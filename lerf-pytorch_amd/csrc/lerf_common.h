@@ -115,6 +115,30 @@ __device__ __forceinline__ SimplexPath simplex_path(int v0, int v1, int v2, int 
 
 __host__ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Source index of padded position i (unpadded coordinates, may lie outside [0, n)) under the padding rule of the IMAGE
+// operand: np.pad(input, pad_vec, mode=self.pad_mode) (resize_right/resize_right2d_numpy.py:208, :560) /
+// F.pad(input, pad_vec, mode=self.pad_mode) (resize_right2d_torch.py:189, :362).  *zero: the value is 0 (constant).
+// reflect / symmetric / wrap follow numpy for any pad width (periodic extension).
+__host__ __device__ inline int pad_index(int i, int n, int mode, bool* zero) {
+    *zero = false;
+    if (i >= 0 && i < n) return i;
+    if (mode == 1) return i < 0 ? 0 : n - 1;                          // edge / replicate
+    if (mode == 2) {                                                  // reflect (no edge repeat)
+        const int p = 2 * (n - 1);
+        if (p == 0) return 0;
+        const int m = ((i % p) + p) % p;
+        return m < n ? m : p - m;
+    }
+    if (mode == 3) {                                                  // symmetric (edge repeated)
+        const int p = 2 * n;
+        const int m = ((i % p) + p) % p;
+        return m < n ? m : p - 1 - m;
+    }
+    if (mode == 4) return ((i % n) + n) % n;                          // wrap / circular
+    *zero = true;                                                     // constant (0)
+    return i < 0 ? 0 : n - 1;
+}
+
 // Homography projection of output pixel (row i, col j) in float64, operation
 // order of resize_right/resize_right2d_numpy.py:321-339 (no FMA contraction).
 __host__ __device__ inline void project_point(const double* m, int i, int j, int H, int W, double* gr, double* gc) {

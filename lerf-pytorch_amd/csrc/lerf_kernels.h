@@ -25,12 +25,14 @@ struct ResizeArgs {
     const double* dis_r64; const double* dis_c64;
     int kind; double max_sigma;
     void* out; int out_dtype; int64_t oy, ox, oc;
+    int pad_mode;                    // LERF_PAD_* of the image operand
 };
 
 struct WarpGeo {
     int S, oH, oW;
     double minv[9];
     int pad_r_lo, pad_r_hi, pad_c_lo, pad_c_hi;
+    int pad_mode;                    // LERF_PAD_* of the image operand
 };
 
 struct WarpArgs {

@@ -216,7 +216,7 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
               const int* __restrict__ left_r, const A* __restrict__ dis_r,
               const int* __restrict__ left_c, const A* __restrict__ dis_c,
               const double* __restrict__ dis_r64, const double* __restrict__ dis_c64,
-              A max_sigma, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+              A max_sigma, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc, int pad_mode) {
     const int S = ST > 0 ? ST : S_rt;
     constexpr int MAXS = ST > 0 ? ST : LERF_MAX_SUPPORT;
     int xc = blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,8 +289,9 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
             for (int b = 0; b < MAXS; ++b) {
                 int rr = lr + b, cc = lc + a;
                 int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
-                bool inside = (rr == rcl) && (cc == ccl);
-                A val = inside ? (A)Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : (A)0;   // zero pad (:208)
+                bool zr, zc;                                                                           // image pad rule (:208)
+                const int rs = pad_index(rr, H, pad_mode, &zr), cs = pad_index(cc, W, pad_mode, &zc);
+                A val = (zr || zc) ? (A)0 : (A)Loader<TI>::pixel(feat + rs * fy + cs * fx + c * fc);
                 int64_t ho = rcl * hy + ccl * hx + c * hc;                                             // edge pad (:172-174)
                 A dx = dis_r[i * S + b], dy = dis_c[j * S + a];
                 if (KIND == LERF_KIND_GAUSS) {
@@ -316,7 +317,8 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
             for (int b = 0; b < S; ++b) {
                 int rr = lr + b, cc = lc + a;
                 int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
-                bool inside = (rr == rcl) && (cc == ccl);
+                bool zr, zc;
+                const int rs = pad_index(rr, H, pad_mode, &zr), cs = pad_index(cc, W, pad_mode, &zc);
                 int64_t ho = rcl * hy + ccl * hx + c * hc;
                 A dx = dis_r[i * S + b], dy = dis_c[j * S + a];
                 A w;
@@ -336,7 +338,7 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                     A alpha = (A)((float)max_sigma * (p0 * 2.0f - 1.0f));
                     w = lin_factor<A>(alpha, dx, dist_class(dx)) * lin_factor<A>(alpha, dy, dist_class(dy));
                 }
-                A val = inside ? (A)Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : (A)0;
+                A val = (zr || zc) ? (A)0 : (A)Loader<TI>::pixel(feat + rs * fy + cs * fx + c * fc);
                 num += w * val;
                 den += w;
             }
@@ -355,7 +357,7 @@ static int resize_dispatch_S(const ResizeArgs& a, hipStream_t st) {
                        a.fy, a.fx, a.fc, (const TH*)a.h[0], (const TH*)a.h[1], (const TH*)a.h[2], a.hy,     \
                        a.hx, a.hc, a.H, a.W, a.C, a.S, a.oH, a.oW, a.left_r, dr, a.left_c, dc,              \
                        (a.dis_r64 && a.dis_c64) ? a.dis_r64 : nullptr, (a.dis_r64 && a.dis_c64) ? a.dis_c64 : nullptr, \
-                       (A)a.max_sigma, (TO*)a.out, a.oy, a.ox, a.oc)
+                       (A)a.max_sigma, (TO*)a.out, a.oy, a.ox, a.oc, a.pad_mode)
     if (a.S == 2) LERF_RS(2);
     else if (a.S == 4) LERF_RS(4);
     else LERF_RS(0);
@@ -416,7 +418,7 @@ template <typename TI, typename TO, typename A>
 __global__ void __launch_bounds__(256)
 resize_fixed_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc, int H, int W, int C, int S, int oH, int oW,
                     const int* __restrict__ left_r, const A* __restrict__ dis_r, const int* __restrict__ left_c,
-                    const A* __restrict__ dis_c, int kind, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+                    const A* __restrict__ dis_c, int kind, TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc, int pad_mode) {
     int xc = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (xc >= oW * C) return;
@@ -432,12 +434,14 @@ resize_fixed_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t
     }
     A num = 0;
     for (int a = 0; a < S; ++a) {
-        const int cc = lc + a;
-        if (cc < 0 || cc >= W) continue;
+        bool zc;
+        const int cc = pad_index(lc + a, W, pad_mode, &zc);
+        if (zc) continue;
         A row = 0;
         for (int b = 0; b < S; ++b) {
-            const int rr = lr + b;
-            if (rr >= 0 && rr < H) row += kr[b] * (A)Loader<TI>::pixel(feat + rr * fy + cc * fx + c * fc);
+            bool zr;
+            const int rr = pad_index(lr + b, H, pad_mode, &zr);
+            if (!zr) row += kr[b] * (A)Loader<TI>::pixel(feat + rr * fy + cc * fx + c * fc);
         }
         num += kc[a] * row;
     }
@@ -451,7 +455,7 @@ static int resize_fixed_launch(const ResizeArgs& a, hipStream_t st) {
     const A* dc = sizeof(A) == 4 ? (const A*)a.dis_c : (const A*)a.dis_c64;
     if (!dr || !dc) return LERF_EINVAL;
     hipLaunchKernelGGL((resize_fixed_kernel<TI, TO, A>), grid, block, 0, st, (const TI*)a.feat, a.fy, a.fx, a.fc, a.H, a.W, a.C,
-                       a.S, a.oH, a.oW, a.left_r, dr, a.left_c, dc, a.kind, (TO*)a.out, a.oy, a.ox, a.oc);
+                       a.S, a.oH, a.oW, a.left_r, dr, a.left_c, dc, a.kind, (TO*)a.out, a.oy, a.ox, a.oc, a.pad_mode);
     return LERF_OK;
 }
 
@@ -531,7 +535,8 @@ warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 A dx = (A)dxd, dy = (A)dyd;
                 int sr = pr - g.pad_r_lo, sc_ = pc - g.pad_c_lo;       // unpadded source coordinates
                 int rcl = clampi(sr, 0, H - 1), ccl = clampi(sc_, 0, W - 1);
-                bool inside = (sr == rcl) && (sc_ == ccl);
+                bool zr, zc;                                           // image pad rule (:560)
+                const int rs = pad_index(sr, H, g.pad_mode, &zr), cs = pad_index(sc_, W, g.pad_mode, &zc);
                 int64_t ho = rcl * hy + ccl * hx + c * hc;
                 A w;
                 if (KIND == LERF_KIND_GAUSS) {
@@ -554,7 +559,7 @@ warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 } else {
                     w = (A)(fixed_kernel_1d(KIND, dxd) * fixed_kernel_1d(KIND, dyd));     // cubic2d / linear2d / lanczos
                 }
-                A val = inside ? (A)Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : (A)0;
+                A val = (zr || zc) ? (A)0 : (A)Loader<TI>::pixel(feat + rs * fy + cs * fx + c * fc);
                 num += w * val;
                 den += w;
             }

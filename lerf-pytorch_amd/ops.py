@@ -21,7 +21,8 @@ class SrGeometry:
     """Separable SR geometry (Resize2dNumpy.set_shape, resize_right2d_numpy.py:18-140)
     as two 1-D tables per axis, resident on the device."""
 
-    def __init__(self, in_hw, scale_factors=None, out_hw=None, support=2, device=None, arithmetic="f64", dis_scale=1.0):
+    def __init__(self, in_hw, scale_factors=None, out_hw=None, support=2, device=None, arithmetic="f64", dis_scale=1.0,
+                 pad_mode=0):
         """arithmetic: "f64" = the numpy classes' float64 tables (normative for the eval path); "torch32" = the
         float32 tables of the reference's torch classes (resize_right2d_torch.py:48-103), bit-equal to theirs.
         dis_scale: factor applied to the distances the weights see -- the anti-aliasing of the numpy Gaussian class
@@ -43,6 +44,7 @@ class SrGeometry:
             out_hw = (_lib.out_size(H, sh), _lib.out_size(W, sw))          # :41-45
         self.in_hw, self.out_hw, self.scales, self.S = (H, W), (int(out_hw[0]), int(out_hw[1])), (sh, sw), int(support)
         self.device = torch.device(device if device is not None else "cuda")
+        self.pad_mode = int(pad_mode)                                        # LERF_PAD_* of the image operand (:208)
         tables = {"f64": _lib.sr_axis_tables, "torch32": _lib.sr_axis_tables_f32}[arithmetic]
         lr, dr64, dr32, pr = tables(H, self.out_hw[0], sh, self.S)
         lc, dc64, dc32, pc = tables(W, self.out_hw[1], sw, self.S)
@@ -61,6 +63,7 @@ class SrGeometry:
                       dis_r64=up(h["dis_r"]), dis_c64=up(h["dis_c"]))
         g = _lib.SrGeo()
         g.S, g.out_h, g.out_w = self.S, self.out_hw[0], self.out_hw[1]
+        g.pad_mode = getattr(self, "pad_mode", 0)
         for k in ("left_r", "dis_r", "left_c", "dis_c", "dis_r64", "dis_c64"):
             setattr(g, k, self.t[k].data_ptr())
         self.struct = g
@@ -74,6 +77,7 @@ class SrGeometry:
         g.in_hw = (int(lr_rows), self.in_hw[1])
         g.out_hw = (int(out_row1 - out_row0), self.out_hw[1])
         g.scales, g.S, g.device, g.pad_vec = self.scales, self.S, self.device, self.pad_vec
+        g.pad_mode = self.pad_mode
         h = self.host
         g.host = dict(left_r=(h["left_r"][out_row0:out_row1] - lr_row0).astype(np.int32),
                       dis_r=h["dis_r"][out_row0:out_row1], dis_r32=h["dis_r32"][out_row0:out_row1],
@@ -88,7 +92,7 @@ class SrGeometry:
 class WarpGeometry:
     """Homography geometry (Warp2dNumpy.set_shape, resize_right2d_numpy.py:292-407)."""
 
-    def __init__(self, in_hw, matrix, out_hw, support=2):
+    def __init__(self, in_hw, matrix, out_hw, support=2, pad_mode=0):
         m = np.asarray(matrix.detach().cpu().numpy() if hasattr(matrix, "detach") else matrix, dtype=np.float64)
         if m.shape != (3, 3):
             raise ValueError("matrix must be 3x3")
@@ -102,6 +106,7 @@ class WarpGeometry:
         for i, v in enumerate(self.minv.reshape(9)):
             g.minv[i] = float(v)
         g.pad_r_lo, g.pad_r_hi, g.pad_c_lo, g.pad_c_hi = pads
+        g.pad_mode = self.pad_mode = int(pad_mode)                          # LERF_PAD_* of the image operand (:560)
         self.struct = g
 
     def ref(self):

@@ -25,8 +25,7 @@ class Resize2dNumpy(object):
     _scales_distances = False
 
     def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
-        if pad_mode != "constant":
-            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self._pad_code = _lib.pad_mode_code(pad_mode, _lib.NUMPY_PAD_MODES)     # np.pad(input, ..., mode=pad_mode) (:208, :560)
         self.eps = np.finfo(np.float32).eps
         self.device = device
         self.support_sz = support_sz
@@ -59,11 +58,33 @@ class Resize2dNumpy(object):
             self.min_scale_factor = min([self.scale_factors[1], self.scale_factors[0]])
             self.support_sz = ceil(self.support_sz / self.min_scale_factor)
         dis_scale = self.min_scale_factor if (self.antialias and self._scales_distances) else 1.0
-        self.geo = ops.SrGeometry(in_shape[1:], self.scale_factors[1:], out_hw, self.support_sz, dis_scale=dis_scale)
+        self.geo = ops.SrGeometry(in_shape[1:], self.scale_factors[1:], out_hw, self.support_sz, dis_scale=dis_scale,
+                                  pad_mode=self._pad_code)
         self.out_shape = [ceil(self.scale_factors[0] * in_shape[0]), self.geo.out_hw[0], self.geo.out_hw[1]]
         self.in_sz = [in_shape[1], in_shape[2]]
         self.out_sz = [self.geo.out_hw[0], self.geo.out_hw[1]]
         self.pad_vec = self.geo.pad_vec
+
+    # The dense geometry attributes get_distance leaves on the reference object (:106-140).  The kernels work from the
+    # two 1-D tables per axis; the dense maps ([oH*S, oW*S] int64 / [C, oH*S, oW*S] float64: 796 MB each at 1080p -> 4K)
+    # are materialised on access only.  Patch enumeration: numpy meshgrid 'xy' (:95-98) -- inside a patch the row
+    # offset varies along the COLUMN index.
+    def _dense(self):
+        h, S = self.geo.host, self.support_sz
+        oH, oW = self.out_sz
+        k = np.arange(S)
+        pr, pc = self.pad_vec[1][0], self.pad_vec[2][0]
+        fx = np.repeat(h["left_r"].astype(np.int64) + pr, S)[:, None] + np.tile(k, oW)[None, :]
+        fy = np.repeat(h["left_c"].astype(np.int64) + pc, S)[None, :] + np.tile(k, oH)[:, None]
+        dx = np.tile(np.repeat(h["dis_r"].reshape(-1, S), S, axis=0), (1, oW))
+        dy = np.tile(np.repeat(h["dis_c"].reshape(-1, S).T, S, axis=1), (oH, 1))
+        C0 = self.in_shape[0]
+        return fx, fy, np.broadcast_to(dx[None], (C0,) + dx.shape).copy(), np.broadcast_to(dy[None], (C0,) + dy.shape).copy()
+
+    field_of_view_x = property(lambda self: self._dense()[0])
+    field_of_view_y = property(lambda self: self._dense()[1])
+    dis_x = property(lambda self: self._dense()[2])
+    dis_y = property(lambda self: self._dense()[3])
 
     def _run(self, kind, input, hypers, max_sigma):
         x = _to_dev(input)
@@ -99,8 +120,7 @@ class Warp2dNumpy(object):
     kind = None
 
     def __init__(self, support_sz=4, device="CPU", pad_mode="constant"):
-        if pad_mode != "constant":
-            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self._pad_code = _lib.pad_mode_code(pad_mode, _lib.NUMPY_PAD_MODES)     # np.pad(input, ..., mode=pad_mode) (:208, :560)
         self.eps = np.finfo(np.float32).eps
         self.device = device
         self.support_sz = support_sz
@@ -113,7 +133,7 @@ class Warp2dNumpy(object):
         self.in_shape, self.out_shape, self.matrix = in_shape, out_shape, matrix
         self.in_sz = [in_shape[1], in_shape[2]]
         self.out_sz = [out_shape[1], out_shape[2]]
-        self.geo = ops.WarpGeometry(self.in_sz, matrix, self.out_sz, self.support_sz)
+        self.geo = ops.WarpGeometry(self.in_sz, matrix, self.out_sz, self.support_sz, pad_mode=self._pad_code)
         self.pad_vec = self.geo.pad_vec
 
     def _run(self, kind, input, hypers, max_sigma):

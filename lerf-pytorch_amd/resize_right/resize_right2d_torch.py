@@ -52,8 +52,7 @@ def _check_dev(t, name):
 
 class Resize2dTorch(object):
     def __init__(self, support_sz=4, device="GPU", pad_mode="constant"):
-        if pad_mode != "constant":
-            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self._pad_code = _lib.pad_mode_code(pad_mode, _lib.TORCH_PAD_MODES)     # F.pad(input, ..., mode=pad_mode) (:189, :362)
         self.eps = torch.finfo(torch.float32).eps
         self.device = device
         self.init_support_sz = support_sz
@@ -78,7 +77,8 @@ class Resize2dTorch(object):
         scale_factors = [1] * (4 - len(scale_factors)) + list(scale_factors)
         self.in_shape = in_shape
         self.scale_factors = [float(s) for s in scale_factors]
-        self.geo = ops.SrGeometry(in_shape[2:], self.scale_factors[2:], out_hw, self.support_sz, arithmetic="torch32")
+        self.geo = ops.SrGeometry(in_shape[2:], self.scale_factors[2:], out_hw, self.support_sz, arithmetic="torch32",
+                                  pad_mode=self._pad_code)
         self.out_shape = [ceil(self.scale_factors[0] * in_shape[0]), ceil(self.scale_factors[1] * in_shape[1]),
                           self.geo.out_hw[0], self.geo.out_hw[1]]
         pr, pc = self.geo.pad_vec[1], self.geo.pad_vec[2]
@@ -88,6 +88,28 @@ class Resize2dTorch(object):
             # vice versa (:189); harmless while both are (S/2, S/2) -- every up-sampling -- but a shifted / out-of-range
             # gather when they differ (some down-samplings).  That case is not reproduced.
             raise NotImplementedError("row pads {} != column pads {}: the reference mis-pads this geometry".format(pr, pc))
+
+    # dense geometry attributes of the reference object (:48-103), materialised on access only; torch.meshgrid 'ij'
+    # (:72-76): inside a patch the row offset varies along the ROW index; dis_* are [B, 1, oH*S, oW*S] float32
+    def _dense(self):
+        import numpy as np
+        h, S = self.geo.host, self.support_sz
+        oH, oW = self.geo.out_hw
+        k = np.arange(S)
+        pr, pc = self.geo.pad_vec[1][0], self.geo.pad_vec[2][0]
+        fx = (np.repeat(h["left_r"].astype(np.int64) + pr, S) + np.tile(k, oH))[:, None] + np.zeros((1, oW * S), np.int64)
+        fy = (np.repeat(h["left_c"].astype(np.int64) + pc, S) + np.tile(k, oW))[None, :] + np.zeros((oH * S, 1), np.int64)
+        dx = np.repeat(h["dis_r32"].reshape(-1)[:, None], oW * S, axis=1)
+        dy = np.repeat(h["dis_c32"].reshape(-1)[None, :], oH * S, axis=0)
+        B = self.in_shape[0]
+        dev = self.geo.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return t(fx), t(fy), t(dx)[None, None].repeat(B, 1, 1, 1), t(dy)[None, None].repeat(B, 1, 1, 1)
+
+    field_of_view_x = property(lambda self: self._dense()[0])
+    field_of_view_y = property(lambda self: self._dense()[1])
+    dis_x = property(lambda self: self._dense()[2])
+    dis_y = property(lambda self: self._dense()[3])
 
     def _run(self, kind, input, hypers, max_sigma):
         _check_dev(input, "input")
@@ -100,6 +122,8 @@ class Resize2dTorch(object):
             _check_dev(h, "hyper-parameter map")
             hs.append(h.reshape(B * Cn, H, W))
         if kind in ("gauss", "linear") and torch.is_grad_enabled() and any(t.requires_grad for t in [x] + hs):
+            if self._pad_code != 0:
+                raise NotImplementedError("autograd is implemented for pad_mode='constant' (what train_model.py uses)")
             out = _ResizeFn.apply(self.geo, kind, max_sigma, x, *hs)
         else:
             out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f32")
@@ -163,8 +187,7 @@ class AmplifiedLinearResize2dTorch(Resize2dTorch):
 
 class Warp2dTorch(object):
     def __init__(self, support_sz=4, device="GPU", pad_mode="constant"):
-        if pad_mode != "constant":
-            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        self._pad_code = _lib.pad_mode_code(pad_mode, _lib.TORCH_PAD_MODES)     # F.pad(input, ..., mode=pad_mode) (:189, :362)
         self.eps = torch.finfo(torch.float32).eps
         self.device = device
         self.support_sz = support_sz
@@ -176,7 +199,7 @@ class Warp2dTorch(object):
         self.in_shape, self.out_shape, self.matrix = in_shape, out_shape, matrix
         self.in_sz = [in_shape[2], in_shape[3]]
         self.out_sz = [out_shape[2], out_shape[3]]
-        self.geo = ops.WarpGeometry(self.in_sz, matrix, self.out_sz, self.support_sz)
+        self.geo = ops.WarpGeometry(self.in_sz, matrix, self.out_sz, self.support_sz, pad_mode=self._pad_code)
         pr, pc = self.geo.pad_vec[1], self.geo.pad_vec[2]
         self.pad_vec = [pc[0], pc[1], pr[0], pr[1]]                         # last dim first (:330-332)
 

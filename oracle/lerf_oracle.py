@@ -224,7 +224,30 @@ def _lin_w(alpha, dx, dy):
     return np.clip(_lin_alpha(dx, alpha), 0, None) * np.clip(_lin_alpha(dy, alpha), 0, None)
 
 
-def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss", geometry="f64"):
+def pad_source_index(i, n, mode):
+    """np.pad's source index (and validity) of padded positions i in unpadded coordinates, modes constant / edge /
+    reflect / symmetric / wrap -- what np.pad(input, pad_vec, mode=self.pad_mode) (:208, :560) amounts to per tap."""
+    i = np.asarray(i)
+    inside = (i >= 0) & (i < n)
+    if mode == "constant":
+        return np.clip(i, 0, n - 1), inside
+    if mode in ("edge", "replicate"):
+        src = np.clip(i, 0, n - 1)
+    elif mode == "reflect":
+        p = 2 * (n - 1)
+        m = np.mod(i, p) if p else np.zeros_like(i)
+        src = np.where(m < n, m, p - m)
+    elif mode == "symmetric":
+        m = np.mod(i, 2 * n)
+        src = np.where(m < n, m, 2 * n - 1 - m)
+    elif mode in ("wrap", "circular"):
+        src = np.mod(i, n)
+    else:
+        raise ValueError(mode)
+    return src, np.ones_like(inside)
+
+
+def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss", geometry="f64", pad_mode="constant"):
     """Spatially-varying SR from float32 [C,H,W] maps (the class API of
     SteeringGaussianResize2dNumpy.resize / AmplifiedLinearResize2dNumpy.resize).
 
@@ -265,7 +288,9 @@ def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss",
             cc = ly + a
             rcl = np.clip(rr, 0, H - 1)
             ccl = np.clip(cc, 0, W - 1)
-            inside = ((rr >= 0) & (rr < H))[:, None] & ((cc >= 0) & (cc < W))[None, :]
+            rs, okr = pad_source_index(rr, H, pad_mode)           # image operand: np.pad(..., mode=pad_mode)  (:208)
+            cs, okc = pad_source_index(cc, W, pad_mode)
+            inside = okr[:, None] & okc[None, :]
             dx = disx[:, b][:, None]
             dy = disy[:, a][None, :]
             if kind == "gauss":
@@ -275,7 +300,7 @@ def resize_params_f32(feat, p0, p1, p2, sh, sw, S=2, max_sigma=10, kind="gauss",
                 w = _lin_w(alpha[:, rcl][:, :, ccl], dx[None], dy[None])
             else:
                 w = (fixed_kernel(kind, dx) * fixed_kernel(kind, dy))[None]
-            val = feat[:, rcl][:, :, ccl].astype(np.float64) * inside[None]
+            val = feat[:, rs][:, :, cs].astype(np.float64) * inside[None]
             num += w * val
             den += w
     return num / den
@@ -363,14 +388,14 @@ def fixed_kernel(kind, x):
     raise ValueError(kind)
 
 
-def _warp_core(feat, params, matrix, out_hw, S, kind, max_sigma):
+def _warp_core(feat, params, matrix, out_hw, S, kind, max_sigma, pad_mode="constant"):
     feat = np.asarray(feat, dtype=np.float32)
     C, H, W = feat.shape
     oH, oW = out_hw
     geo = warp_geometry(matrix, (H, W), (oH, oW), S)
     plx, phx, ply, phy = geo["pad"]
     pad_vec = ((0, 0), (plx, phx), (ply, phy))
-    tmp_in = np.pad(feat, pad_vec, mode="constant")
+    tmp_in = np.pad(feat, pad_vec, mode=pad_mode)              # (:560)
     tmp_p = [np.pad(p, pad_vec, mode="edge") for p in params]
     num = np.zeros((C, oH, oW), np.float64)
     den = np.zeros((C, oH, oW), np.float64)
@@ -396,7 +421,7 @@ def _warp_core(feat, params, matrix, out_hw, S, kind, max_sigma):
         return num / den
 
 
-def warp_params_f32(feat, p0, p1, p2, matrix, out_hw, S=2, max_sigma=10, kind="gauss"):
+def warp_params_f32(feat, p0, p1, p2, matrix, out_hw, S=2, max_sigma=10, kind="gauss", pad_mode="constant"):
     """SteeringGaussianWarp2dNumpy.warp / AmplifiedLinearWarp2dNumpy.warp / NearestWarp2dNumpy.warp
     on float32 [C,H,W] maps; float64 [C,oH,oW] out (NaN where all weights vanish)."""
     if kind == "gauss":
@@ -409,7 +434,7 @@ def warp_params_f32(feat, p0, p1, p2, matrix, out_hw, S=2, max_sigma=10, kind="g
         params = [max_sigma * alpha]
     else:
         params = []
-    return _warp_core(feat, params, matrix, out_hw, S, kind, max_sigma)
+    return _warp_core(feat, params, matrix, out_hw, S, kind, max_sigma, pad_mode)
 
 
 def warp_u8(feat_u8, hq_u8, matrix, out_hw, S=2, max_sigma=10, kind="gauss"):

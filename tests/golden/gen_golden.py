@@ -532,6 +532,60 @@ def g13_torch_warp():
     print("G13", len(out), {k: str(v.dtype) for k, v in list(out.items())[:6]})
 
 
+def g15_pad_modes():
+    """non-default pad_mode of the resampler classes: the IMAGE operand padded by np.pad / F.pad with that mode, the hyper
+    maps edge-padded as always (resize_right2d_numpy.py:143,172-174,208; :560; resize_right2d_torch.py:189).  SR
+    Gaussian S=2/4 and linear with the numpy classes, a Gaussian warp, and the torch SR class with its F.pad modes."""
+    from resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch as SGT
+    g4 = np.load(os.path.join(OUT, "g4_warp.npz"))
+    out = {}
+    rng = np.random.default_rng(150)
+    H, W = 11, 9
+    feat = rng.integers(0, 256, (2, H, W)).astype(np.float32)
+    hq = rng.integers(0, 256, (3, 2, H, W)).astype(np.float32)
+    hy = (hq / 255.0).astype(np.float32)
+    out["feat"], out["hq"] = feat.astype(np.uint8), hq.astype(np.uint8)
+    for mode in ("edge", "reflect", "symmetric", "wrap"):
+        for S, sc in ((2, (2.0, 3.0)), (4, (1.5, 2.0))):
+            r = SteeringGaussianResize2dNumpy(support_sz=S, max_sigma=10, pad_mode=mode)
+            r.set_shape([2, H, W], scale_factors=list(sc))
+            out["sr/%s/gauss_S%d" % (mode, S)] = r.resize(feat, hy[0], hy[1], hy[2])
+        rl = AmplifiedLinearResize2dNumpy(pad_mode=mode)
+        rl.set_shape([2, H, W], scale_factors=[3.0, 2.0])
+        out["sr/%s/linear" % mode] = rl.resize(feat, hy[0])
+        for p in ("isc", "osc"):
+            f52 = g4["%s/feat" % p].astype(np.float32)
+            h52 = (g4["%s/hq" % p].astype(np.float32) / 255.0).astype(np.float32)
+            w = SteeringGaussianWarp2dNumpy(support_sz=2, max_sigma=10, pad_mode=mode)
+            w.set_shape([3, 52, 52], g4["%s/matrix" % p], [3, 60, 70])
+            out["warp/%s/%s" % (mode, p)] = w.warp(f52, h52[0], h52[1], h52[2])
+    for mode in ("replicate", "reflect", "circular"):
+        r = SGT(support_sz=2, device="cpu", max_sigma=10, pad_mode=mode)
+        r.set_shape([1, 2, H, W], scale_factors=[2.0, 2.0])
+        out["torch/%s/gauss" % mode] = r.resize(torch.tensor(feat)[None], torch.tensor(hy[0])[None], torch.tensor(hy[1])[None],
+                                                torch.tensor(hy[2])[None]).numpy()
+    np.savez_compressed(os.path.join(OUT, "g15_pad_modes.npz"), **out)
+    print("G15", len(out))
+
+
+def g16_geometry_attrs():
+    """the dense geometry attributes set_shape leaves on the SR classes (resize_right2d_numpy.py:106-140,
+    resize_right2d_torch.py:48-103): field_of_view_x/y (already shifted by the pad) and dis_x/y"""
+    from resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch as SGT
+    out = {}
+    for ci, (H, W, sh, sw, S) in enumerate([(5, 6, 2.0, 2.0, 2), (7, 4, 1.5, 3.0, 4)]):
+        r = SteeringGaussianResize2dNumpy(support_sz=S, max_sigma=10)
+        r.set_shape([3, H, W], scale_factors=[sh, sw])
+        t = SGT(support_sz=S, device="cpu", max_sigma=10)
+        t.set_shape([2, 3, H, W], scale_factors=[sh, sw])
+        out["%d/cfg" % ci] = np.array([H, W, sh, sw, S], dtype=np.float64)
+        for nm in ("field_of_view_x", "field_of_view_y", "dis_x", "dis_y"):
+            out["%d/numpy/%s" % (ci, nm)] = np.asarray(getattr(r, nm))
+            out["%d/torch/%s" % (ci, nm)] = getattr(t, nm).numpy()
+    np.savez_compressed(os.path.join(OUT, "g16_geometry_attrs.npz"), **out)
+    print("G16", {k: (v.shape, str(v.dtype)) for k, v in out.items() if k.startswith("0/")})
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -551,7 +605,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g15", "g16"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -576,3 +630,7 @@ if __name__ == "__main__":
         g12_downscale()
     if "g13" in which:
         g13_torch_warp()
+    if "g15" in which:
+        g15_pad_modes()
+    if "g16" in which:
+        g16_geometry_attrs()

@@ -624,3 +624,58 @@ def test_torch_warp_classes_vs_reference_torch_path(torch, golden, p):
         check(w.warp(feat3), g7["%s/%s" % (p, name)][None], 1e-9)
     with pytest.raises(ValueError):
         bc.warp(feat3[:, :, :50])                                                # shape other than set_shape's
+
+
+def test_pad_modes_of_the_classes(torch, golden):
+    """pad_mode != 'constant' through the class API (the reference hands it to np.pad / F.pad for the IMAGE operand,
+    resize_right2d_numpy.py:143,208,560; resize_right2d_torch.py:189): every index-remapping mode of both libraries."""
+    from lerf_pytorch_amd.resize_right import resize_right2d_numpy as N
+    from lerf_pytorch_amd.resize_right import resize_right2d_torch as T
+    g, g4 = golden("g15_pad_modes.npz"), golden("g4_warp.npz")
+    feat = g["feat"].astype(np.float32)
+    h = g["hq"].astype(np.float32) / np.float32(255)
+    for mode in ("edge", "reflect", "symmetric", "wrap"):
+        for S, sc in ((2, (2.0, 3.0)), (4, (1.5, 2.0))):
+            r = N.SteeringGaussianResize2dNumpy(support_sz=S, max_sigma=10, pad_mode=mode)
+            r.set_shape([2, 11, 9], scale_factors=list(sc))
+            np.testing.assert_allclose(r.resize(feat, h[0], h[1], h[2]), g["sr/%s/gauss_S%d" % (mode, S)], rtol=0, atol=1e-9)
+        rl = N.AmplifiedLinearResize2dNumpy(pad_mode=mode)
+        rl.set_shape([2, 11, 9], scale_factors=[3.0, 2.0])
+        np.testing.assert_allclose(rl.resize(feat, h[0]), g["sr/%s/linear" % mode], rtol=0, atol=1e-9, equal_nan=True)
+        for p in ("isc", "osc"):
+            f52 = g4["%s/feat" % p].astype(np.float32)
+            h52 = g4["%s/hq" % p].astype(np.float32) / np.float32(255)
+            w = N.SteeringGaussianWarp2dNumpy(support_sz=2, max_sigma=10, pad_mode=mode)
+            w.set_shape([3, 52, 52], g4["%s/matrix" % p], [3, 60, 70])
+            np.testing.assert_allclose(w.warp(f52, h52[0], h52[1], h52[2]), g["warp/%s/%s" % (mode, p)], rtol=0, atol=1e-9,
+                                       equal_nan=True)
+    dev = torch.device("cuda")
+    ft = torch.from_numpy(feat)[None].to(dev)
+    ht = torch.from_numpy(h)[:, None].to(dev)
+    for mode in ("replicate", "reflect", "circular"):
+        r = T.SteeringGaussianResize2dTorch(support_sz=2, device=dev, max_sigma=10, pad_mode=mode)
+        r.set_shape([1, 2, 11, 9], scale_factors=[2.0, 2.0])
+        out = r.resize(ft, ht[0], ht[1], ht[2])
+        assert np.abs(out.cpu().numpy() - g["torch/%s/gauss" % mode]).max() <= F32_OBSERVED
+    with pytest.raises(NotImplementedError):
+        N.SteeringGaussianResize2dNumpy(pad_mode="linear_ramp")
+    with pytest.raises(NotImplementedError):
+        T.SteeringGaussianResize2dTorch(pad_mode="symmetric")              # not an F.pad mode
+
+
+def test_set_shape_dense_geometry_attributes(torch, golden):
+    """field_of_view_x/y and dis_x/y as the reference's set_shape leaves them (g16), numpy and torch classes"""
+    from lerf_pytorch_amd.resize_right import resize_right2d_numpy as N
+    from lerf_pytorch_amd.resize_right import resize_right2d_torch as T
+    g = golden("g16_geometry_attrs.npz")
+    for ci in (0, 1):
+        H, W, sh, sw, S = g["%d/cfg" % ci]
+        r = N.SteeringGaussianResize2dNumpy(support_sz=int(S), max_sigma=10)
+        r.set_shape([3, int(H), int(W)], scale_factors=[sh, sw])
+        t = T.SteeringGaussianResize2dTorch(support_sz=int(S), device=torch.device("cuda"), max_sigma=10)
+        t.set_shape([2, 3, int(H), int(W)], scale_factors=[sh, sw])
+        for nm in ("field_of_view_x", "field_of_view_y", "dis_x", "dis_y"):
+            a, ref = getattr(r, nm), g["%d/numpy/%s" % (ci, nm)]
+            assert a.dtype == ref.dtype and np.array_equal(a, ref), nm
+            b, ref = getattr(t, nm), g["%d/torch/%s" % (ci, nm)]
+            assert b.is_cuda and tuple(b.shape) == ref.shape and np.array_equal(b.cpu().numpy(), ref), nm

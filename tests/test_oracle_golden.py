@@ -276,3 +276,25 @@ def test_net_to_lut_transfer_golden(oracle, model, keys):
         if bad.any():
             amb = np.abs((y * 127) - np.floor(y * 127) - 0.5)
             assert amb[bad].max() < 1e-3
+
+
+def test_pad_modes_golden(oracle, golden):
+    """non-default pad_mode of the reference's classes (g15): image operand padded with np.pad's edge / reflect /
+    symmetric / wrap, hyper maps edge-padded as always; numpy SR (S = 2, 4, linear), numpy warp, torch SR."""
+    g, g4 = golden("g15_pad_modes.npz"), golden("g4_warp.npz")
+    feat = g["feat"].astype(np.float32)
+    h = g["hq"].astype(np.float32) / np.float32(255)
+    for mode in ("edge", "reflect", "symmetric", "wrap"):
+        for S, sc in ((2, (2.0, 3.0)), (4, (1.5, 2.0))):
+            o = oracle.resize_params_f32(feat, h[0], h[1], h[2], sc[0], sc[1], S, 10, "gauss", pad_mode=mode)
+            np.testing.assert_allclose(o, g["sr/%s/gauss_S%d" % (mode, S)], rtol=0, atol=1e-9)
+        o = oracle.resize_params_f32(feat, h[0], None, None, 3.0, 2.0, 2, 1, "linear", pad_mode=mode)
+        np.testing.assert_allclose(o, g["sr/%s/linear" % mode], rtol=0, atol=1e-9, equal_nan=True)
+        for p in ("isc", "osc"):
+            f52 = g4["%s/feat" % p].astype(np.float32)
+            h52 = g4["%s/hq" % p].astype(np.float32) / np.float32(255)
+            o = oracle.warp_params_f32(f52, h52[0], h52[1], h52[2], g4["%s/matrix" % p], (60, 70), 2, 10, "gauss", pad_mode=mode)
+            np.testing.assert_allclose(o, g["warp/%s/%s" % (mode, p)], rtol=0, atol=1e-9, equal_nan=True)
+    for mode in ("replicate", "reflect", "circular"):
+        o = oracle.resize_params_f32(feat, h[0], h[1], h[2], 2.0, 2.0, 2, 10, "gauss", geometry="torch32", pad_mode=mode)
+        assert np.abs(o - g["torch/%s/gauss" % mode][0]).max() <= 5e-4          # the reference's own float32 arithmetic
