@@ -159,10 +159,12 @@ int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_
  * rot90 and /q: integer numerators (value*16) of the 4-simplex interpolation
  * of `lut` ([17^4][oC] int8) over 4 pixels sampled at offsets (dy[k], dx[k])
  * from each of the h x w positions of the uint8 image `img` (coordinates are
- * clamped to [0,img_h-1] x [0,img_w-1]).  out: int16 [C][oC][h][w]. */
+ * clamped to [0,img_h-1] x [0,img_w-1]).  out: int16 [C][oC][h][w].
+ * interval: the LUT's sampling interval (:27-28; q = 2^interval, L = 2^(8-interval) + 1 levels per axis, `lut` has
+ * L^4 rows, numerators are value * q); 4 for every shipped LUT, 1..7 accepted. */
 int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C,
                         int h, int w, const int8_t dy[4], const int8_t dx[4],
-                        const int8_t* lut, int oC, int16_t* out, void* stream);
+                        const int8_t* lut, int oC, int interval, int16_t* out, void* stream);
 
 /* LUT pack for the tile-fused kernel (modes "sct"/"sct" only): the stage-1
  * LUTs padded to 16-byte multiples, and the stage-2 LUTs as one uint32 per

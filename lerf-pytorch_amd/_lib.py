@@ -109,7 +109,7 @@ def lib():
     L.lerf_invert3x3.argtypes = [C.c_void_p, C.c_void_p]
     L.lerf_warp_pads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lerf_lut_interp_i16.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lerf_fused_lutpack_bytes.restype = C.c_size_t
     L.lerf_fused_lutpack_bytes.argtypes = [C.c_int]
     L.lerf_fused_lutpack_build.argtypes = [C.POINTER(Luts), C.c_void_p, C.c_void_p]

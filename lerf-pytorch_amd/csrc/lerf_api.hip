@@ -174,14 +174,14 @@ int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_
 }
 
 int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4],
-                        const int8_t dx[4], const int8_t* lut, int oC, int16_t* out, void* stream) {
+                        const int8_t dx[4], const int8_t* lut, int oC, int interval, int16_t* out, void* stream) {
     if (!plane_ok(img) || img->dtype != LERF_U8 || !lut || !out || !dy || !dx) return LERF_EINVAL;
     if (img_h < 1 || img_w < 1 || C < 1 || h < 1 || w < 1) return LERF_EINVAL;
     Offsets4 off;
     memcpy(off.dy, dy, 4);
     memcpy(off.dx, dx, 4);
     int rc = launch_lut_interp((const uint8_t*)img->ptr, img->sy, img->sx, img->sc, img_h, img_w, C, h, w, off, lut,
-                               oC, out, as_stream(stream));
+                               oC, interval, out, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
 

@@ -45,9 +45,63 @@ lut_interp_kernel(const uint8_t* __restrict__ img, int64_t sy, int64_t sx, int64
     }
 }
 
+// the same pass for any sampling interval (resample/eval_lut_sr.py:27-28: q = 2^interval, L = 2^(8-interval) + 1);
+// the shipped LUTs and every fused path use interval 4, this one serves the function mirror for the others
+template <int OC>
+__global__ void __launch_bounds__(256)
+lut_interp_any_kernel(const uint8_t* __restrict__ img, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C, int h,
+                      int w, Offsets4 off, const int8_t* __restrict__ lut, int interval, int16_t* __restrict__ out) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    int c = blockIdx.z;
+    if (x >= w) return;
+    const int q = 1 << interval, L = (1 << (8 - interval)) + 1;
+    const int stride[4] = {L * L * L, L * L, L, 1};
+    unsigned key[4];
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int yy = clampi(y + off.dy[k], 0, img_h - 1);
+        int xx = clampi(x + off.dx[k], 0, img_w - 1);
+        const int v = img[yy * sy + xx * sx + c * sc];
+        idx += (v >> interval) * stride[k];
+        key[k] = ((unsigned)(v & (q - 1)) << 24) | (unsigned)stride[k];      // L^3 <= 129^3 < 2^24
+    }
+    ce_desc(key[0], key[1]);
+    ce_desc(key[2], key[3]);
+    ce_desc(key[0], key[2]);
+    ce_desc(key[1], key[3]);
+    ce_desc(key[1], key[2]);
+    int f[5], id[5];
+    id[0] = idx;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        f[n] = (int)(key[n] >> 24);
+        id[n + 1] = id[n] + (int)(key[n] & 0xFFFFFFu);
+    }
+    f[4] = 0;
+#pragma unroll
+    for (int oc = 0; oc < OC; ++oc) {
+        int acc = (q - f[0]) * (int)lut[(int64_t)id[0] * OC + oc];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc += (f[n] - f[n + 1]) * (int)lut[(int64_t)id[n + 1] * OC + oc];
+        out[(((int64_t)c * OC + oc) * h + y) * w + x] = (int16_t)acc;
+    }
+}
+
 int launch_lut_interp(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C,
-                      int h, int w, Offsets4 off, const int8_t* lut, int oC, int16_t* out, hipStream_t st) {
+                      int h, int w, Offsets4 off, const int8_t* lut, int oC, int interval, int16_t* out, hipStream_t st) {
     dim3 block(256), grid((w + 255) / 256, h, C);
+    if (interval != 4) {
+        if (interval < 1 || interval > 7) return LERF_EUNSUPPORTED;
+        if (oC == 1)
+            hipLaunchKernelGGL(lut_interp_any_kernel<1>, grid, block, 0, st, img, sy, sx, sc, img_h, img_w, C, h, w, off, lut, interval, out);
+        else if (oC == 3)
+            hipLaunchKernelGGL(lut_interp_any_kernel<3>, grid, block, 0, st, img, sy, sx, sc, img_h, img_w, C, h, w, off, lut, interval, out);
+        else
+            return LERF_EUNSUPPORTED;
+        return LERF_OK;
+    }
     if (oC == 1)
         hipLaunchKernelGGL(lut_interp_kernel<1>, grid, block, 0, st, img, sy, sx, sc, img_h, img_w, C, h, w, off, lut, out);
     else if (oC == 3)

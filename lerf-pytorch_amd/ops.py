@@ -129,13 +129,15 @@ def _out_dtype(name):
 
 
 # --------------------------------------------------------------------------- A1
-def lut_interp_i16(img_u8_chw, h, w, dy, dx, lut_i8):
-    """int16 numerators [C,oC,h,w] of one LUT pass (FourSimplexInterpFaster core)."""
+def lut_interp_i16(img_u8_chw, h, w, dy, dx, lut_i8, interval=4):
+    """int16 numerators [C,oC,h,w] (value * 2^interval) of one LUT pass (FourSimplexInterpFaster core)."""
     torch = _torch()
     if img_u8_chw.dtype != torch.uint8 or img_u8_chw.dim() != 3:
         raise ValueError("img must be uint8 [C,H,W]")
-    if lut_i8.dtype != torch.int8 or lut_i8.dim() != 2 or lut_i8.shape[0] != _lib.LERF_LUT_ENTRIES:
-        raise ValueError("lut must be int8 [17^4,oC]")
+    if not 1 <= int(interval) <= 7:
+        raise ValueError("interval must be 1..7")
+    if lut_i8.dtype != torch.int8 or lut_i8.dim() != 2 or lut_i8.shape[0] != (2 ** (8 - int(interval)) + 1) ** 4:
+        raise ValueError("lut must be int8 [L^4,oC] with L = 2^(8-interval) + 1")
     img = img_u8_chw.contiguous()
     lut = lut_i8.contiguous()
     Cn, Hp, Wp = img.shape
@@ -145,7 +147,7 @@ def lut_interp_i16(img_u8_chw, h, w, dy, dx, lut_i8):
     dx = np.ascontiguousarray(dx, dtype=np.int8)
     p = _planes_chw(img)
     _lib.check(_lib.lib().lerf_lut_interp_i16(C.byref(p), Hp, Wp, Cn, int(h), int(w), dy.ctypes.data, dx.ctypes.data,
-                                              lut.data_ptr(), oC, out.data_ptr(), _lib.current_stream()),
+                                              lut.data_ptr(), oC, int(interval), out.data_ptr(), _lib.current_stream()),
                "lerf_lut_interp_i16")
     return out
 

@@ -63,8 +63,9 @@ def rotated_offsets(mode: str, r: int):
     return offs
 
 
-def simplex_numer(lut: np.ndarray, v: np.ndarray) -> np.ndarray:
-    """4-simplex interpolation numerators (value*16), exact integers.
+def simplex_numer(lut: np.ndarray, v: np.ndarray, interval: int = 4) -> np.ndarray:
+    """4-simplex interpolation numerators (value * 2^interval), exact integers; interval = 4 for the shipped LUTs
+    (q = 2^interval, L = 2^(8-interval) + 1 levels per axis, eval_lut_sr.py:27-28).
 
     lut: int [L**4, oC]; v: int [4, ...] pixel values of a, b, c, d (0..255).
     Returns int32 [..., oC].  Equivalent to the 24 ordered cases of
@@ -73,13 +74,15 @@ def simplex_numer(lut: np.ndarray, v: np.ndarray) -> np.ndarray:
     """
     lut = np.asarray(lut).astype(np.int32)
     v = np.asarray(v).astype(np.int32)
-    m = v >> 4
-    f = v & 15
-    idx = m[0] * STRIDES[0] + m[1] * STRIDES[1] + m[2] * STRIDES[2] + m[3]
+    q, lv = 2 ** interval, 2 ** (8 - interval) + 1
+    strides = (lv ** 3, lv ** 2, lv, 1)
+    m = v >> interval
+    f = v & (q - 1)
+    idx = m[0] * strides[0] + m[1] * strides[1] + m[2] * strides[2] + m[3]
     order = np.argsort(-f, axis=0, kind="stable")
     fs = np.take_along_axis(f, order, axis=0)
-    st = np.asarray(STRIDES, dtype=np.int32)[order]
-    acc = (Q - fs[0])[..., None] * lut[idx]
+    st = np.asarray(strides, dtype=np.int32)[order]
+    acc = (q - fs[0])[..., None] * lut[idx]
     for n in range(4):
         idx = idx + st[n]
         wn = fs[n] - (fs[n + 1] if n < 3 else 0)
@@ -87,7 +90,7 @@ def simplex_numer(lut: np.ndarray, v: np.ndarray) -> np.ndarray:
     return acc.astype(np.int32)
 
 
-def lut_interp_numer(lut: np.ndarray, img: np.ndarray, mode: str, r: int) -> np.ndarray:
+def lut_interp_numer(lut: np.ndarray, img: np.ndarray, mode: str, r: int, interval: int = 4) -> np.ndarray:
     """One (LUT, mode, rotation) pass over a whole image, unrotated frame.
 
     img: integer [H, W, C]; returns int32 [H, W, C, oC] = 16 * the value that
@@ -100,7 +103,7 @@ def lut_interp_numer(lut: np.ndarray, img: np.ndarray, mode: str, r: int) -> np.
     vals = []
     for dy, dx in rotated_offsets(mode, r):
         vals.append(img[np.clip(yy + dy, 0, H - 1), np.clip(xx + dx, 0, W - 1)])
-    return simplex_numer(lut, np.stack(vals, axis=0))
+    return simplex_numer(lut, np.stack(vals, axis=0), interval)
 
 
 def _rne_div(n: np.ndarray, d: int) -> np.ndarray:

@@ -586,6 +586,28 @@ def g16_geometry_attrs():
     print("G16", {k: (v.shape, str(v.dtype)) for k, v in out.items() if k.startswith("0/")})
 
 
+def g17_intervals():
+    """FourSimplexInterpFaster with sampling intervals other than the shipped 4 (eval_lut_sr.py:27-28): random int8 LUTs"""
+    out = {}
+    rng = np.random.default_rng(170)
+    img = rng.integers(0, 256, (13, 11, 2)).astype(np.float32)
+    out["img"] = img.astype(np.uint8)
+    for interval, oC in ((5, 3), (6, 1), (3, 1), (7, 3)):
+        L = 2 ** (8 - interval) + 1
+        lut = rng.integers(-128, 128, (L ** 4, oC)).astype(np.int8)
+        out["lut/%d" % interval] = lut
+        for mode in "sct":
+            pad = mode_pad_dict[mode]
+            for r in (0, 3):
+                rot = np.rot90(img, r)
+                h, w, _ = rot.shape
+                img_in = np.pad(rot, ((0, pad), (0, pad), (0, 0)), mode="edge").transpose((2, 0, 1))
+                out["out/%d/%s/%d" % (interval, mode, r)] = FourSimplexInterpFaster(lut.astype(np.float32), img_in, h, w, interval,
+                                                                                  4 - r, upscale=1, mode=mode, oC=oC)
+    np.savez_compressed(os.path.join(OUT, "g17_intervals.npz"), **out)
+    print("G17", len(out))
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -605,7 +627,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g15", "g16", "g17"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -634,3 +656,5 @@ if __name__ == "__main__":
         g15_pad_modes()
     if "g16" in which:
         g16_geometry_attrs()
+    if "g17" in which:
+        g17_intervals()

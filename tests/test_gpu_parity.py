@@ -679,3 +679,24 @@ def test_set_shape_dense_geometry_attributes(torch, golden):
             assert a.dtype == ref.dtype and np.array_equal(a, ref), nm
             b, ref = getattr(t, nm), g["%d/torch/%s" % (ci, nm)]
             assert b.is_cuda and tuple(b.shape) == ref.shape and np.array_equal(b.cpu().numpy(), ref), nm
+
+
+@pytest.mark.parametrize("interval", [3, 5, 6, 7])
+def test_four_simplex_interp_other_intervals(golden, interval):
+    """FourSimplexInterpFaster drop-in with interval != 4 (q = 2^interval, L = 2^(8-interval)+1, eval_lut_sr.py:27-28)"""
+    from lerf_pytorch_amd.resample.eval_lut_sr import FourSimplexInterpFaster, mode_pad_dict
+    g = golden("g17_intervals.npz")
+    img = g["img"].astype(np.float32)
+    lut = g["lut/%d" % interval]
+    oC = lut.shape[1]
+    for mode in "sct":
+        pad = mode_pad_dict[mode]
+        for r in (0, 3):
+            rot = np.rot90(img, r)
+            h, w, _ = rot.shape
+            img_in = np.pad(rot, ((0, pad), (0, pad), (0, 0)), mode="edge").transpose((2, 0, 1))
+            out = FourSimplexInterpFaster(lut.astype(np.float32), img_in, h, w, interval, 4 - r, upscale=1, mode=mode, oC=oC)
+            ref = g["out/%d/%s/%d" % (interval, mode, r)]
+            assert out.dtype == np.float64 and np.array_equal(out, ref)
+    with pytest.raises(ValueError):
+        FourSimplexInterpFaster(lut.astype(np.float32), img_in, h, w, 9, 0, mode="s", oC=oC)

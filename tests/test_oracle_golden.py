@@ -298,3 +298,17 @@ def test_pad_modes_golden(oracle, golden):
     for mode in ("replicate", "reflect", "circular"):
         o = oracle.resize_params_f32(feat, h[0], h[1], h[2], 2.0, 2.0, 2, 10, "gauss", geometry="torch32", pad_mode=mode)
         assert np.abs(o - g["torch/%s/gauss" % mode][0]).max() <= 5e-4          # the reference's own float32 arithmetic
+
+
+@pytest.mark.parametrize("interval", [3, 5, 6, 7])
+def test_lut_interp_other_intervals(oracle, golden, interval):
+    """the LUT pass at sampling intervals other than the shipped 4 (g17, the reference's FourSimplexInterpFaster)"""
+    g = golden("g17_intervals.npz")
+    img = g["img"]
+    lut = g["lut/%d" % interval]
+    for mode in "sct":
+        for r in (0, 3):
+            num = oracle.lut_interp_numer(lut, img, mode, r, interval)            # [H,W,C,oC], value * 2^interval
+            ref = g["out/%d/%s/%d" % (interval, mode, r)]                          # [C*oC, H, W], already rotated back
+            mine = num.transpose(2, 3, 0, 1).reshape(ref.shape) / float(2 ** interval)
+            assert np.array_equal(mine, ref)
