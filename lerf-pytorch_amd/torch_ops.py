@@ -1,112 +1,109 @@
-"""`torch.ops.lerf.*`: dispatcher-visible wrappers over the C ABI (forward only).
+"""`torch.ops.lerf.*`: the hot path as PyTorch dispatcher ops.
 
-LUT sets are registered once (`register_luts`) and referred to by handle, since an op schema
-carries tensors and scalars only:
+The schemas and the device kernels' launchers are registered in C++ (`csrc/lerf_torch.cpp`, TORCH_LIBRARY /
+TORCH_LIBRARY_IMPL under the HIP backend's dispatch key) in `liblerf_torch.so`, which this module loads.  On top of
+that it attaches what is naturally Python: the fake (meta) kernels for shape inference / torch.compile tracing and the
+autograd formulas of the two float resamplers (their backward is itself an op, `lerf::resize_backward`).  There is no
+CPU kernel: CPU tensors are refused by the dispatcher, and a missing library raises here.
 
-    h = torch_ops.register_luts(LutSet.shipped("lerf-g"))
-    out = torch.ops.lerf.sr_fused(img_u8, h, 2.0, 2.0, 2, 10.0)
-    feat, hq = torch.ops.lerf.lut_stages(img_u8, h)
-    out = torch.ops.lerf.resize_gauss(feat_f32, rho, sx, sy, 2.0, 2.0, 2, 10.0)
-    out = torch.ops.lerf.resize_linear(feat_f32, alpha, 2.0, 2.0, 1.0)
-    out = torch.ops.lerf.warp_fused(img_u8, h, M_3x3_f64, 2160, 3840, 2, 10.0)
+    s1, s2, pack = torch_ops.lut_args(LutSet.shipped("lerf-g"))
+    out      = torch.ops.lerf.sr_fused(img_u8, s1, s2, pack, 2.0, 2.0, 2, 10.0)
+    feat, hq = torch.ops.lerf.lut_stages(img_u8, s1, s2)
+    out      = torch.ops.lerf.resize_gauss(feat_f32, rho, sx, sy, 2.0, 2.0, 2, 10.0)       # differentiable
+    out      = torch.ops.lerf.resize_linear(feat_f32, alpha, 2.0, 2.0, 1.0)                # differentiable
+    out      = torch.ops.lerf.warp_fused(img_u8, s1, s2, pack, M_3x3_f64, 2160, 3840, 2, 10.0)
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
-from . import ops
+from . import _lib
 
-_LUTS = []
-_GEO = {}
-
-
-def register_luts(lutset) -> int:
-    _LUTS.append(lutset)
-    return len(_LUTS) - 1
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblerf_torch.so")
+if not os.path.exists(LIB_PATH):
+    raise _lib.LerfError("liblerf_torch.so not found at %s -- build it with `python __graft_entry__.py`" % LIB_PATH)
+_lib.lib()                                   # liblerf_hip.so first (the op library links against it)
+torch.ops.load_library(LIB_PATH)
 
 
-def _geo(hw, sh, sw, support, device):
-    key = (int(hw[0]), int(hw[1]), float(sh), float(sw), int(support), str(device))
-    if key not in _GEO:
-        _GEO[key] = ops.SrGeometry(hw, [sh, sw], None, support, device)
-    return _GEO[key]
+def lut_args(lutset):
+    """(luts_s1, luts_s2, pack) of a LutSet in the order the ops expect (modes "sct")."""
+    if lutset.modes != "sct" or lutset.modes2 != "sct":
+        raise ValueError("the dispatcher ops cover the shipped mode set 'sct'/'sct'")
+    t = lutset.tensors
+    s1 = [t["s1_%sr0" % m] for m in "sct"]
+    s2 = [t["s2_%sr%d" % (m, r)] for m in "sct" for r in (0, 1)]
+    return s1, s2, t.get("fused_pack")
 
 
-@torch.library.custom_op("lerf::lut_stages", mutates_args=(), device_types="cuda")
-def lut_stages(img: torch.Tensor, luts: int) -> tuple[torch.Tensor, torch.Tensor]:
-    return ops.lut_stages(img, _LUTS[luts])
+def _out_hw(h, w, sh, sw):
+    return _lib.out_size(h, sh), _lib.out_size(w, sw)
 
 
-@lut_stages.register_fake
-def _(img, luts):
-    oC = _LUTS[luts].oC
+@torch.library.register_fake("lerf::lut_stages")
+def _(img, luts_s1, luts_s2):
+    oC = luts_s2[0].numel() // _lib.LERF_LUT_ENTRIES
     return torch.empty_like(img), img.new_empty(tuple(img.shape) + (oC,))
 
 
-@torch.library.custom_op("lerf::sr_fused", mutates_args=(), device_types="cuda")
-def sr_fused(img: torch.Tensor, luts: int, scale_h: float, scale_w: float, support: int, max_sigma: float) -> torch.Tensor:
-    L = _LUTS[luts]
-    linear = L.oC == 1
-    geo = _geo(img.shape[-3:-1], scale_h, scale_w, 2 if linear else support, img.device)
-    return ops.sr_fused_u8(img, L, geo, "linear" if linear else "gauss", 1.0 if linear else max_sigma)   # a fresh tensor
-
-
-@sr_fused.register_fake
-def _(img, luts, scale_h, scale_w, support, max_sigma):
-    from ._lib import out_size
+@torch.library.register_fake("lerf::sr_fused")
+def _(img, luts_s1, luts_s2, pack, scale_h, scale_w, support, max_sigma):
     shp = list(img.shape)
-    shp[-3], shp[-2] = out_size(shp[-3], scale_h), out_size(shp[-2], scale_w)
+    shp[-3], shp[-2] = _out_hw(shp[-3], shp[-2], scale_h, scale_w)
     return img.new_empty(shp)
 
 
-@torch.library.custom_op("lerf::resize_gauss", mutates_args=(), device_types="cuda")
-def resize_gauss(feat: torch.Tensor, rho: torch.Tensor, sigma_x: torch.Tensor, sigma_y: torch.Tensor,
-                 scale_h: float, scale_w: float, support: int, max_sigma: float) -> torch.Tensor:
-    B, C, H, W = feat.shape
-    geo = _geo((H, W), scale_h, scale_w, support, feat.device)
-    r = lambda t: t.reshape(B * C, H, W)
-    out = ops.resize_planar(r(feat), [r(rho), r(sigma_x), r(sigma_y)], geo, "gauss", max_sigma, out="f32")
-    return out.reshape(B, C, geo.out_hw[0], geo.out_hw[1])
-
-
-@resize_gauss.register_fake
-def _(feat, rho, sigma_x, sigma_y, scale_h, scale_w, support, max_sigma):
-    from ._lib import out_size
-    B, C, H, W = feat.shape
-    return feat.new_empty((B, C, out_size(H, scale_h), out_size(W, scale_w)), dtype=torch.float32)
-
-
-@torch.library.custom_op("lerf::resize_linear", mutates_args=(), device_types="cuda")
-def resize_linear(feat: torch.Tensor, alpha: torch.Tensor, scale_h: float, scale_w: float, max_sigma: float) -> torch.Tensor:
-    B, C, H, W = feat.shape
-    geo = _geo((H, W), scale_h, scale_w, 2, feat.device)
-    out = ops.resize_planar(feat.reshape(B * C, H, W), [alpha.reshape(B * C, H, W)], geo, "linear", max_sigma, out="f32")
-    return out.reshape(B, C, geo.out_hw[0], geo.out_hw[1])
-
-
-@resize_linear.register_fake
-def _(feat, alpha, scale_h, scale_w, max_sigma):
-    from ._lib import out_size
-    B, C, H, W = feat.shape
-    return feat.new_empty((B, C, out_size(H, scale_h), out_size(W, scale_w)), dtype=torch.float32)
-
-
-@torch.library.custom_op("lerf::warp_fused", mutates_args=(), device_types="cuda")
-def warp_fused(img: torch.Tensor, luts: int, matrix: torch.Tensor, out_h: int, out_w: int, support: int,
-               max_sigma: float) -> torch.Tensor:
-    """uint8 [H,W,3] -> uint8 [out_h,out_w,3]: LUT stages (tile-fused kernel) + homographic resampling, the body of
-    eltr._worker in resample/eval_lut_warp.py:100-222.  `matrix`: 3x3 float64 (input -> output coordinates)."""
-    L = _LUTS[luts]
-    linear = L.oC == 1
-    H, W, Cn = img.shape
-    geo = ops.WarpGeometry((H, W), matrix, (out_h, out_w), 2 if linear else support)
-    kind, ms = ("linear", 1.0) if linear else ("gauss", max_sigma)
-    if Cn == 3 and L.struct.fused_pack is not None:
-        return ops.warp_packed(ops.stages_packed(img, L), geo, kind, ms, out="u8")
-    feat, hq = ops.lut_stages(img, L)
-    return ops.warp_hwc_u8(feat, hq, geo, kind, ms, out="u8")
-
-
-@warp_fused.register_fake
-def _(img, luts, matrix, out_h, out_w, support, max_sigma):
+@torch.library.register_fake("lerf::warp_fused")
+def _(img, luts_s1, luts_s2, pack, matrix, out_h, out_w, support, max_sigma):
     return img.new_empty((out_h, out_w, img.shape[2]))
+
+
+@torch.library.register_fake("lerf::resize_gauss")
+def _(feat, rho, sigma_x, sigma_y, scale_h, scale_w, support, max_sigma):
+    B, C, H, W = feat.shape
+    return feat.new_empty((B, C) + _out_hw(H, W, scale_h, scale_w))
+
+
+@torch.library.register_fake("lerf::resize_linear")
+def _(feat, alpha, scale_h, scale_w, max_sigma):
+    B, C, H, W = feat.shape
+    return feat.new_empty((B, C) + _out_hw(H, W, scale_h, scale_w))
+
+
+@torch.library.register_fake("lerf::resize_backward")
+def _(kind, grad_out, feat, h0, h1, h2, scale_h, scale_w, support, max_sigma):
+    return tuple(torch.empty_like(feat) for _ in range(4))
+
+
+# ---- autograd of the float resamplers: what autograd derives for SteeringGaussianResize2dTorch.resize /
+#      AmplifiedLinearResize2dTorch.resize (resize_right2d_torch.py:154-247), computed by lerf_resize_bwd_f32
+def _gauss_setup(ctx, inputs, output):
+    feat, rho, sx, sy, sh, sw, S, ms = inputs
+    ctx.save_for_backward(feat, rho, sx, sy)
+    ctx.meta = (sh, sw, S, ms)
+
+
+def _gauss_backward(ctx, grad_out):
+    feat, rho, sx, sy = ctx.saved_tensors
+    sh, sw, S, ms = ctx.meta
+    gx, g0, g1, g2 = torch.ops.lerf.resize_backward(0, grad_out.contiguous(), feat, rho, sx, sy, sh, sw, S, ms)
+    return gx, g0, g1, g2, None, None, None, None
+
+
+def _linear_setup(ctx, inputs, output):
+    feat, alpha, sh, sw, ms = inputs
+    ctx.save_for_backward(feat, alpha)
+    ctx.meta = (sh, sw, ms)
+
+
+def _linear_backward(ctx, grad_out):
+    feat, alpha = ctx.saved_tensors
+    sh, sw, ms = ctx.meta
+    gx, g0, _, _ = torch.ops.lerf.resize_backward(1, grad_out.contiguous(), feat, alpha, alpha, alpha, sh, sw, 2, ms)
+    return gx, g0, None, None, None
+
+
+torch.library.register_autograd("lerf::resize_gauss", _gauss_backward, setup_context=_gauss_setup)
+torch.library.register_autograd("lerf::resize_linear", _linear_backward, setup_context=_linear_setup)

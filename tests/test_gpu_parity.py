@@ -334,38 +334,88 @@ def test_strip_partition_single_gpu(torch, eng_g, H, W, scale, world):
     assert torch.equal(torch.cat(parts, dim=0), full)
 
 
-def test_torch_custom_ops(torch, eng_g):
+def test_torch_custom_ops(torch, eng_g, oracle, luts_g):
+    """torch.ops.lerf.* (C++ TORCH_LIBRARY registration) against the ORACLE, not against the engine"""
     from lerf_pytorch_amd import torch_ops
-    h = torch_ops.register_luts(eng_g.luts)
+    s1, s2, pack = torch_ops.lut_args(eng_g.luts)
     rng = np.random.default_rng(3)
-    x = torch.from_numpy(rng.integers(0, 256, (48, 40, 3), dtype=np.uint8)).cuda()
-    out = torch.ops.lerf.sr_fused(x, h, 2.0, 2.0, 2, 10.0)
-    assert torch.equal(out, eng_g.sr(x, 2))
-    feat, hq = torch.ops.lerf.lut_stages(x, h)
-    f2, h2 = eng_g.stages(x)
-    assert torch.equal(feat, f2) and torch.equal(hq, h2)
+    img = rng.integers(0, 256, (48, 40, 3), dtype=np.uint8)
+    x = torch.from_numpy(img).cuda()
+    of, oh, _, o8 = oracle.sr_pipeline(img, luts_g, 2, 2, return_all=True)
+    out = torch.ops.lerf.sr_fused(x, s1, s2, pack, 2.0, 2.0, 2, 10.0)
+    assert np.array_equal(out.cpu().numpy(), o8)
+    assert np.array_equal(torch.ops.lerf.sr_fused(x, s1, s2, None, 2.0, 2.0, 2, 10.0).cpu().numpy(), o8)      # no pack: direct kernels
+    outb = torch.ops.lerf.sr_fused(torch.stack([x, x]), s1, s2, pack, 2.0, 2.0, 2, 10.0)
+    assert tuple(outb.shape) == (2, 96, 80, 3) and torch.equal(outb[1], out)
+    feat, hq = torch.ops.lerf.lut_stages(x, s1, s2)
+    assert np.array_equal(feat.cpu().numpy(), of) and np.array_equal(hq.cpu().numpy(), oh)
     fe = feat.permute(2, 0, 1).float().unsqueeze(0)
     hy = (hq.float() / 255).permute(3, 2, 0, 1).unsqueeze(1)
     o = torch.ops.lerf.resize_gauss(fe, hy[0], hy[1], hy[2], 2.0, 2.0, 2, 10.0)
     assert o.shape == (1, 3, 96, 80)
-    assert (o[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).int() - out.int()).abs().max() <= 1
-    M = torch.tensor([[2.05, 0.12, 3.0], [-0.08, 1.95, 4.0], [1.5e-4, -1.0e-4, 1.0]], dtype=torch.float64)
-    w = torch.ops.lerf.warp_fused(x, h, M, 90, 70, 2, 10.0)
-    assert torch.equal(w, eng_g.warp(x, M, (90, 70), return_mask=False)[0])
+    ref = oracle.resize_params_f32(fe[0].cpu().numpy(), hy[0, 0].cpu().numpy(), hy[1, 0].cpu().numpy(), hy[2, 0].cpu().numpy(),
+                                   2.0, 2.0, 2, 10, "gauss", geometry="torch32")
+    assert np.abs(o[0].cpu().numpy() - ref).max() <= 1e-4
+    M = np.array([[2.05, 0.12, 3.0], [-0.08, 1.95, 4.0], [1.5e-4, -1.0e-4, 1.0]])
+    w = torch.ops.lerf.warp_fused(x, s1, s2, pack, torch.tensor(M, dtype=torch.float64), 90, 70, 2, 10.0)
+    assert np.array_equal(w.cpu().numpy(), oracle.warp_pipeline(img, luts_g, M, (90, 70)))
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.lerf.sr_fused(x.cpu(), [t.cpu() for t in s1], [t.cpu() for t in s2], None, 2.0, 2.0, 2, 10.0)   # no CPU kernel
+    with pytest.raises(RuntimeError):
+        torch.ops.lerf.sr_fused(x.float(), s1, s2, pack, 2.0, 2.0, 2, 10.0)
 
 
-def test_torch_custom_ops_linear(torch, eng_l):
-    from lerf_pytorch_amd import ops, torch_ops
-    h = torch_ops.register_luts(eng_l.luts)
+def test_torch_custom_ops_linear(torch, eng_l, oracle, luts_l):
+    from lerf_pytorch_amd import torch_ops
+    s1, s2, pack = torch_ops.lut_args(eng_l.luts)
     rng = np.random.default_rng(4)
-    x = torch.from_numpy(rng.integers(0, 256, (30, 44, 3), dtype=np.uint8)).cuda()
-    assert torch.equal(torch.ops.lerf.sr_fused(x, h, 1.5, 2.0, 2, 10.0), eng_l.sr(x, (1.5, 2.0)))
-    feat, hq = torch.ops.lerf.lut_stages(x, h)
+    img = rng.integers(0, 256, (30, 44, 3), dtype=np.uint8)
+    x = torch.from_numpy(img).cuda()
+    out = torch.ops.lerf.sr_fused(x, s1, s2, pack, 1.5, 2.0, 2, 10.0)
+    assert np.array_equal(out.cpu().numpy(), oracle.sr_pipeline(img, luts_l, 1.5, 2.0, linear=True))
+    feat, hq = torch.ops.lerf.lut_stages(x, s1, s2)
     fe = feat.permute(2, 0, 1).float().unsqueeze(0)
     al = (hq.float() / 255).permute(3, 2, 0, 1)[0].unsqueeze(0)
     o = torch.ops.lerf.resize_linear(fe, al, 1.5, 2.0, 1.0)
-    geo = ops.SrGeometry((30, 44), [1.5, 2.0], None, 2)
-    assert torch.equal(o[0], ops.resize_planar(fe[0], [al[0]], geo, "linear", 1.0, out="f32"))
+    ref = oracle.resize_params_f32(fe[0].cpu().numpy(), al[0].cpu().numpy(), None, None, 1.5, 2.0, 2, 1, "linear", geometry="torch32")
+    assert np.abs(o[0].cpu().numpy() - ref).max() <= 1e-4
+
+
+def test_torch_custom_ops_autograd(torch):
+    """gradients of torch.ops.lerf.resize_{gauss,linear} == the class path, which tests/test_gpu_train.py pins to the
+    reference's autograd (g11); schema / fake-kernel consistency through torch.library.opcheck"""
+    from lerf_pytorch_amd import torch_ops  # noqa: F401
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(21)
+    feat = torch.tensor(rng.random((2, 1, 9, 8)) * 255, dtype=torch.float32, device=dev, requires_grad=True)
+    hs = [torch.tensor(rng.random((2, 1, 9, 8)), dtype=torch.float32, device=dev, requires_grad=True) for _ in range(3)]
+    from lerf_pytorch_amd.resize_right.resize_right2d_torch import AmplifiedLinearResize2dTorch, SteeringGaussianResize2dTorch
+    wgt = torch.tensor(rng.random((2, 1, 18, 24)), dtype=torch.float32, device=dev)
+    # op path
+    (torch.ops.lerf.resize_gauss(feat, hs[0], hs[1], hs[2], 2.0, 3.0, 2, 10.0) * wgt).sum().backward()
+    got = [feat.grad.clone()] + [h.grad.clone() for h in hs]
+    for t in [feat] + hs:
+        t.grad = None
+    # class path (golden-tested against the reference's autograd in tests/test_gpu_train.py)
+    r = SteeringGaussianResize2dTorch(support_sz=2, device=dev, max_sigma=10)
+    r.set_shape([2, 1, 9, 8], scale_factors=[2.0, 3.0])
+    (r.resize(feat, hs[0], hs[1], hs[2]) * wgt).sum().backward()
+    want = [feat.grad.clone()] + [h.grad.clone() for h in hs]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    for t in [feat] + hs:
+        t.grad = None
+    (torch.ops.lerf.resize_linear(feat, hs[0], 2.0, 3.0, 1.0) * wgt).sum().backward()
+    got = [feat.grad.clone(), hs[0].grad.clone()]
+    feat.grad = None
+    hs[0].grad = None
+    rl = AmplifiedLinearResize2dTorch(device=dev)
+    rl.set_shape([2, 1, 9, 8], scale_factors=[2.0, 3.0])
+    (rl.resize(feat, hs[0]) * wgt).sum().backward()
+    for a, b in zip(got, [feat.grad, hs[0].grad]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    # finite-difference spot check of the op's gradient w.r.t. one hyper-parameter entry
+    torch.library.opcheck(torch.ops.lerf.resize_linear, (feat.detach(), hs[0].detach(), 2.0, 3.0, 1.0), test_utils=("test_schema", "test_faketensor"))
 
 
 def test_full_frame_bytes_equal_cpu_oracle(torch, eng_g, luts_g):
