@@ -88,7 +88,7 @@ def _oracle_luts(model):
     return lerf_oracle.load_luts(os.path.join(ROOT, "lerf-pytorch_amd", "assets", "models", model), linear=model == "lerf-l")
 
 
-def cpu_baseline_sr(frames_u8, model, sh, sw, budget_s=12.0, threads=None, max_n=64):
+def cpu_baseline_sr(frames_u8, model, sh, sw, budget_s=12.0, threads=None, max_n=64, S=2):
     """C port of the oracle (oracle/lerf_oracle.c, OpenMP) on this host, bounded sample.  threads=1: one core."""
     from oracle import c_oracle
     luts = _oracle_luts(model)
@@ -99,7 +99,7 @@ def cpu_baseline_sr(frames_u8, model, sh, sw, budget_s=12.0, threads=None, max_n
     n = 0
     out = None
     while True:
-        out = c_oracle.sr_u8(frames_u8[n % len(frames_u8)], luts, sh, sw, linear=model == "lerf-l")
+        out = c_oracle.sr_u8(frames_u8[n % len(frames_u8)], luts, sh, sw, S=S, linear=model == "lerf-l")
         n += 1
         if time.perf_counter() - t0 >= budget_s or n >= max_n:
             break
@@ -143,16 +143,17 @@ def _free_port():
 def spawn_ranks(n):
     """GPU-free parent: start n copies of this command, one rank per GPU, and relay rank 0's JSON line.
     Nothing in this process has touched HIP (torch is not even imported), so no re-exec hazard exists."""
+    import tempfile
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
+    out0_file = tempfile.TemporaryFile()                        # rank 0's stdout (a pipe read would block on a hung rank)
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
                    LERF_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
+                                      stdout=out0_file if r == 0 else subprocess.DEVNULL))
     rcs = [None] * n
     deadline = time.time() + 3600
     while any(rc is None for rc in rcs):
@@ -166,6 +167,8 @@ def spawn_ranks(n):
                     rcs[i] = p.wait()
             break
         time.sleep(0.05)
+    out0_file.seek(0)
+    out0 = out0_file.read().decode()
     sys.stdout.write(out0)
     sys.stdout.flush()
     bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
@@ -432,7 +435,7 @@ def main():
                                          "mask_mismatches": int((mk != cpu_mask).sum())}
         else:
             budget = 12.0 if cfg != 5 else 20.0
-            cb, cpu_out, n_cpu = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=budget)
+            cb, cpu_out, n_cpu = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=budget, S=S)
             res["cpu_baseline"] = cb
             if cfg == 2 and S == 2:
                 # one core, on the 256x256 tile of BASELINE config 1 (a 1080p frame takes about a minute on one core)
