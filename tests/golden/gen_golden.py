@@ -608,6 +608,26 @@ def g17_intervals():
     print("G17", len(out))
 
 
+def g18_modes_dy():
+    """the sampling patterns no shipped model uses, 'd' (dilated 2x2) and 'y' (eval_lut_sr.py:43-61), through the reference's
+    FourSimplexInterpFaster with a shipped stage-2 LUT (oC = 3) and a stage-1 LUT (oC = 1), all four rotations"""
+    out = {}
+    luts = load_lutdict("lerf-g", 3)
+    rng = np.random.default_rng(180)
+    img = rng.integers(0, 256, (15, 12, 2)).astype(np.float32)
+    out["img"] = img.astype(np.uint8)
+    for mode in "dy":
+        pad = mode_pad_dict[mode]
+        for key, oC in (("s1_sr0", 1), ("s2_tr1", 3)):
+            for r in range(4):
+                rot = np.rot90(img, r)
+                h, w, _ = rot.shape
+                img_in = np.pad(rot, ((0, pad), (0, pad), (0, 0)), mode="edge").transpose((2, 0, 1))
+                out["%s/%s/%d" % (mode, key, r)] = FourSimplexInterpFaster(luts[key], img_in, h, w, 4, 4 - r, upscale=1, mode=mode, oC=oC)
+    np.savez_compressed(os.path.join(OUT, "g18_modes_dy.npz"), **out)
+    print("G18", len(out))
+
+
 def g6_torch():
     out = {}
     for ci, (H, W, s) in enumerate([(24, 20, 2), (12, 16, 4), (20, 18, 2.5)]):
@@ -627,7 +647,7 @@ def g6_torch():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g15", "g16", "g17", "g18"]
     if "g1" in which:
         g1_lut_stages()
     if "g23" in which:
@@ -658,3 +678,5 @@ if __name__ == "__main__":
         g16_geometry_attrs()
     if "g17" in which:
         g17_intervals()
+    if "g18" in which:
+        g18_modes_dy()

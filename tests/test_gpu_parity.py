@@ -750,3 +750,32 @@ def test_four_simplex_interp_other_intervals(golden, interval):
             assert out.dtype == np.float64 and np.array_equal(out, ref)
     with pytest.raises(ValueError):
         FourSimplexInterpFaster(lut.astype(np.float32), img_in, h, w, 9, 0, mode="s", oC=oC)
+
+
+@pytest.mark.parametrize("mode", ["d", "y"])
+def test_four_simplex_interp_modes_d_y(torch, golden, oracle, luts_g, mode):
+    """the 'd' / 'y' sampling patterns: the function mirror against the reference (g18), and a whole LUT stage pair with
+    modes "sdy" through the general-mode kernels against the oracle"""
+    from lerf_pytorch_amd.resample.eval_lut_sr import FourSimplexInterpFaster, mode_pad_dict
+    import lerf_pytorch_amd as L
+    g = golden("g18_modes_dy.npz")
+    img = g["img"].astype(np.float32)
+    pad = mode_pad_dict[mode]
+    for key, oC in (("s1_sr0", 1), ("s2_tr1", 3)):
+        for r in range(4):
+            rot = np.rot90(img, r)
+            h, w, _ = rot.shape
+            img_in = np.pad(rot, ((0, pad), (0, pad), (0, 0)), mode="edge").transpose((2, 0, 1))
+            out = FourSimplexInterpFaster(luts_g[key].astype(np.float32), img_in, h, w, 4, 4 - r, upscale=1, mode=mode, oC=oC)
+            assert np.array_equal(out, g["%s/%s/%d" % (mode, key, r)])
+    # a model whose mode set contains the pattern (LUT contents borrowed from the shipped tables)
+    arrays = {"s1_sr0": luts_g["s1_sr0"], "s1_%sr0" % mode: luts_g["s1_cr0"], "s2_sr0": luts_g["s2_sr0"], "s2_sr1": luts_g["s2_sr1"],
+              "s2_%sr0" % mode: luts_g["s2_tr0"], "s2_%sr1" % mode: luts_g["s2_tr1"]}
+    modes = "s" + mode
+    eng = L.LerfEngine(L.LutSet(arrays, 3, modes, modes))
+    rng = np.random.default_rng(181)
+    x = rng.integers(0, 256, (37, 29, 3), dtype=np.uint8)
+    feat, hq = eng.stages(x)
+    of, oh = oracle.lut_stages(x, arrays, 3, modes, modes)
+    assert np.array_equal(feat, of) and np.array_equal(hq, oh)
+    assert np.array_equal(eng.sr(x, 2), oracle.sr_pipeline(x, arrays, 2, 2, modes=modes, modes2=modes))

@@ -312,3 +312,14 @@ def test_lut_interp_other_intervals(oracle, golden, interval):
             ref = g["out/%d/%s/%d" % (interval, mode, r)]                          # [C*oC, H, W], already rotated back
             mine = num.transpose(2, 3, 0, 1).reshape(ref.shape) / float(2 ** interval)
             assert np.array_equal(mine, ref)
+
+
+@pytest.mark.parametrize("mode", ["d", "y"])
+def test_lut_interp_modes_d_y(oracle, golden, luts_g, mode):
+    """sampling patterns 'd' and 'y' (no shipped model uses them) against the reference's FourSimplexInterpFaster (g18)"""
+    g = golden("g18_modes_dy.npz")
+    for key in ("s1_sr0", "s2_tr1"):
+        for r in range(4):
+            num = oracle.lut_interp_numer(luts_g[key], g["img"], mode, r)
+            ref = g["%s/%s/%d" % (mode, key, r)]
+            assert np.array_equal(num.transpose(2, 3, 0, 1).reshape(ref.shape) / 16.0, ref)
