@@ -26,9 +26,22 @@ for r in range(8):
     lg = geo.row_slice(plan.ylo, plan.yhi - plan.ylo, plan.i0, plan.i1)
     o = ops.sr_fused_u8(ext, eng.luts, lg, "gauss", 10.0)
     torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(5): ops.sr_fused_u8(ext, eng.luts, lg, "gauss", 10.0, out=o.unsqueeze(0))
+    for _ in range(5): ops.sr_fused_u8(ext, eng.luts, lg, "gauss", 10.0, out=o)
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t) / 5)
     parts.append(o)
 print("8 strips stitched == full frame:", bool(torch.equal(torch.cat(parts, 0), out[0])))
 print("per-strip kernel time (270 LR rows + halo): %.3f ms max, %.3f ms mean -> one frame over 8 GPUs ~ %.1f Mpix/s + halo exchange"
       % (max(ts) * 1e3, np.mean(ts) * 1e3, 4320 * 7680 / max(ts) / 1e6))
+
+# the same with the 8 frames of a bench step in ONE launch per rank (bench.py --config 5 --mode strips): rank 3's strips
+x8 = torch.from_numpy(rng.integers(0, 256, (8, 2160, 3840, 3), dtype=np.uint8)).cuda()
+plan = ldist.StripPlan(2160, 8, 3, 2, geo.host["left_r"])
+ext8 = x8[:, plan.ylo:plan.yhi].contiguous()
+lg = geo.row_slice(plan.ylo, plan.yhi - plan.ylo, plan.i0, plan.i1)
+o8 = ops.sr_fused_u8(ext8, eng.luts, lg, "gauss", 10.0)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(5): ops.sr_fused_u8(ext8, eng.luts, lg, "gauss", 10.0, out=o8)
+torch.cuda.synchronize(); d8 = (time.perf_counter() - t) / 5
+full8 = 8 * dt / B
+print("8 frames, one rank's strips in one launch: %.3f ms vs 1/8 of the whole-frame batch %.3f ms -> strong-scaling efficiency of the "
+      "compute part %.0f %% (%.1f Gpix/s over 8 GPUs before the halo exchange)" % (d8 * 1e3, full8 / 8 * 1e3, 100 * full8 / 8 / d8, 8 * 4320 * 7680 / d8 / 1e9))

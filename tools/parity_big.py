@@ -11,7 +11,7 @@ for model, linear in (("lerf-g", False), ("lerf-l", True)):
     eng = L.LerfEngine.shipped(model)
     luts = O.load_luts(os.path.join(ROOT, "lerf-pytorch_amd/assets/models", model), linear=linear)
     for kind, seed, scale in (("noise", 11, 2), ("noise", 12, 2), ("natural", 13, 2), ("noise", 14, 3), ("natural", 15, 1.5)):
-        img = bench.synth_frames(kind, 1, seed)[0]
+        img = bench.synth_frames(kind, 1, seed, 1080, 1920)[0]
         if scale != 2: img = img[:540, :960]
         out = eng.sr(img, scale)
         ref = c_oracle.sr_u8(img, luts, scale, scale, linear=linear)
