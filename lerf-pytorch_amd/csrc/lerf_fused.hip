@@ -323,19 +323,7 @@ __device__ __forceinline__ int byte_lookups(uint32_t lut_a, uint32_t center) {
 #pragma unroll
     for (int i = 0; i < NROT; ++i)
 #pragma unroll
-#if defined(LERF_EXP) && LERF_EXP == 9        // diagnostic: conflict-free stage-1 gathers (same instruction count + one add)
-        for (int n = 0; n < 5; ++n) e[i][n] = lds_ldi8<0>(lut_a + ((threadIdx.x & 63u) << 2) + n * 256 + i * 2048) + (int)W[i].a(n);
-#elif defined(LERF_EXP) && LERF_EXP == 10     // diagnostic: half the stage-1 gathers (vertices 0..2 only... timing only)
-        for (int n = 0; n < 5; ++n) e[i][n] = (n < 3 && (i & 1) == 0) || n < 2 ? W[i].ldi8(n) : (int)W[i].a(n);
-#elif defined(LERF_EXP) && LERF_EXP == 11     // diagnostic: aligned dword gathers + byte extraction instead of byte gathers
-        for (int n = 0; n < 5; ++n) {
-            const uint32_t a_ = W[i].a(n) + (n >= 3 ? Walk<1>::ALL : 0);
-            const uint32_t d_ = lds_ld32<0>(a_ & ~3u);
-            e[i][n] = (int)(int8_t)(__builtin_amdgcn_alignbyte(d_, d_, a_) & 0xFFu);
-        }
-#else
         for (int n = 0; n < 5; ++n) e[i][n] = W[i].ldi8(n);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // stage D: sum_n w_n P_n = 16 P_0 + sum_n f_n (P_{n+1} - P_n)   (w_0 = 16 - f_0, w_n = f_{n-1} - f_n, w_4 = f_3):
     //          four multiply-adds and four subtractions per lookup instead of five weights + five multiply-adds
