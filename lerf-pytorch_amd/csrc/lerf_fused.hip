@@ -357,13 +357,16 @@ __device__ __forceinline__ int center_addr(int p, int y0g, int x0g, int sy0g, in
     return (cy - sy0g) * SP + (cx - sx0g) * CH + c;
 }
 
-template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, int PHASE>
+// SKIP_OUTSIDE: positions outside the frame are not evaluated (callers that never read them: s1_kernel)
+template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, int PHASE, bool SKIP_OUTSIDE = false>
 __device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src, int16_t* acc16, uint8_t* dst8,
                                            int y0g, int x0g, int sy0g, int sx0g, int H, int W, int div, int bias,
                                            int tid) {
     const uint32_t lut_a = lds_addr(lut), src_a = lds_addr(src);
     for (int p = tid; p < NDST; p += NT) {
-        int a = center_addr<DPc, SP>(p, y0g, x0g, sy0g, sx0g, H, W, nullptr);
+        bool in = true;
+        int a = center_addr<DPc, SP>(p, y0g, x0g, sy0g, sx0g, H, W, SKIP_OUTSIDE ? &in : nullptr);
+        if (SKIP_OUTSIDE && !in) continue;
         int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut_a, src_a + (uint32_t)a);
         if (PHASE != 0) v += (int)acc16[p];
         if (PHASE == 2)
@@ -676,14 +679,23 @@ sr_fused_kernel(Params P) {
         for (int i = tid; i < MAXR * NT / 2; i += NT) reinterpret_cast<uint32_t*>(lst)[i] = 0xFFFFFFFFu;
         constexpr int KH = (D::NH + NT - 1) / NT;
         constexpr int PW = KH * 64;
-        uint32_t qpack = 0;                     // 2 bits per owned position
+        // Positions of the hyper region that lie outside the frame (tiles on the right / bottom edge, the halo ring of edge
+        // tiles) are not looked up at all: stage 3 reads them as replicas of the clamped position (edge-padded hyper maps,
+        // zero image), which fill_outside() below copies once the in-frame values exist.  A 28-row strip tile or the
+        // last tile row of a 1080-row frame then costs what its in-frame part costs.
+        uint32_t qpack = 0, spack = 0;          // 2 bits per owned position + 1 skip bit
         {
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
                 const int p = wave * PW + k * 64 + lane;
                 int q = 4;
-                if (p < D::NH) q = Bt[center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr)] >> 6;
+                if (p < D::NH) {
+                    bool in = true;
+                    const int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, &in);
+                    if (in) q = Bt[a] >> 6;
+                }
+                spack |= (uint32_t)(q == 4) << k;
                 qpack |= (uint32_t)(q & 3) << (2 * k);
                 c0 += __popcll(__ballot(q == 0));
                 c1 += __popcll(__ballot(q == 1));
@@ -745,7 +757,7 @@ sr_fused_kernel(Params P) {
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
                 const int p = wave * PW + k * 64 + lane;
-                const int q = p < D::NH ? (int)((qpack >> (2 * k)) & 3u) : 4;
+                const int q = ((spack >> k) & 1u) ? 4 : (int)((qpack >> (2 * k)) & 3u);
                 const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2),
                                          m3 = __ballot(q == 3);
                 // destination of this lane under each quarter (mbcnt adds the wave's running base), then one select:
@@ -949,6 +961,17 @@ sr_fused_kernel(Params P) {
                 uint32_t fv = inside ? (uint32_t)Bt[a] : 0u;      // zero-padded image outside the frame (:208)
                 Dt[p] = h0 | (h1 << 8) | (h2 << 16) | (fv << 24);
             }
+        }
+    }
+
+    if (!EMIT && KIND == LERF_KIND_GAUSS && Hc >= 0) {
+        // fill_outside: out-of-frame positions of the hyper region = the clamped position's hyper bytes, image byte 0
+        __syncthreads();
+        for (int p = tid; p < D::NH; p += NT) {
+            const int ry = p / D::HP, r3 = p - ry * D::HP, rx = r3 / CH, c = r3 - rx * CH;
+            const int gy = hy0 + ry, gx = hx0 + rx;
+            const int cy = clampi(gy, 0, H - 1), cx = clampi(gx, 0, W - 1);
+            if (cy != gy || cx != gx) Dt[p] = Dt[(cy - hy0) * D::HP + (cx - hx0) * CH + c] & 0x00FFFFFFu;
         }
     }
 
@@ -1165,16 +1188,16 @@ s1_kernel(Params P) {
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
         __syncthreads();
         LERF_S1_LOAD(P.pack + 1 * LUT_PAD);
-        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
+        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         LERF_S1_STORE();
         __syncthreads();
         LERF_S1_LOAD(P.pack + 2 * LUT_PAD);
-        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
+        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         LERF_S1_STORE();
         __syncthreads();
-        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
+        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
     }
     // the block's rows to P.feat
