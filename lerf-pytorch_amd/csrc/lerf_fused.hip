@@ -776,16 +776,25 @@ sr_fused_kernel(Params P) {
         }
         __syncthreads();
         // slots -> registers.  Per slot: the feat-tile address of its clamped centre (16 bits, two slots per
-        // VGPR; 0xFFFF = padding) and three 16-bit accumulators (accA: e0 | e2 << 16; accB: e1, two slots
+        // VGPR; 0xFFFF = round without any position in this wave) and three 16-bit accumulators (accA: e0 | e2 << 16; accB: e1, two slots
         // per VGPR).  The position ids stay in LST and are re-read when the sums are finalised.
         constexpr int MAXP = (MAXR + 1) / 2;
         uint32_t slot2[MAXP];
         uint32_t accA[MAXR], accB[MAXR];
+        uint32_t wrounds = 0;                 // bit k: this wave has a real position in round k (wave-uniform)
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
             const uint32_t p = lst[k * NT + tid];
             uint32_t a = 0xFFFFu;
             if (p != 0xFFFFu) a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr);
+            // padding lanes of a partly filled wave repeat the wave's first real position (same quarter, same LDS words:
+            // broadcast reads) into accumulators nobody reads, so the lookup loop needs no per-lane test
+            const unsigned long long real = __ballot(p != 0xFFFFu);
+            if (real != 0ull) {
+                const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)a, (int)__builtin_ctzll(real));
+                if (p == 0xFFFFu) a = a1;
+                wrounds |= 1u << k;
+            }
             if (k & 1) slot2[k >> 1] |= a << 16; else slot2[k >> 1] = a;
             accA[k] = 0;
             accB[k] = 0;
@@ -850,6 +859,9 @@ sr_fused_kernel(Params P) {
                 const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;   // axis strides, bytes
                 const int rsq = __builtin_amdgcn_readfirstlane(ctl[8 + q]);
                 const int req = __builtin_amdgcn_readfirstlane(ctl[12 + q]);
+                // rounds [rsq, req) of this quarter in which this wave holds a real position: one scalar bit test per
+                // unrolled round instead of two range compares and a padding compare
+                const uint32_t act = wrounds & ((1u << req) - 1u) & ~((1u << rsq) - 1u);
                 __syncthreads();
                 if (ph + 1 < nph) {
                     const int qi2 = (ph + 1) / 6;
@@ -862,9 +874,9 @@ sr_fused_kernel(Params P) {
                 (void)t_look;
 #pragma unroll
                 for (int k = 0; k < MAXR; ++k) {
-                    if (k >= rsq && k < req) {
+                    if ((act >> k) & 1u) {
                         const uint32_t sa = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
-                        if (sa != 0xFFFFu) {
+                        {
                             // stage A: the 7 pixel reads of the two rotations (high-half loads, see lds_pixel_hi)
                             const uint32_t cpa = bt_a + sa;
                             uint32_t ra = lds_pixel_hi(cpa);
