@@ -357,22 +357,44 @@ __device__ __forceinline__ int center_addr(int p, int y0g, int x0g, int sy0g, in
     return (cy - sy0g) * SP + (cx - sx0g) * CH + c;
 }
 
-// SKIP_OUTSIDE: positions outside the frame are not evaluated (callers that never read them: s1_kernel)
+// SKIP_OUTSIDE: positions outside the frame are not evaluated (callers that never read them: s1_kernel).
+// Interior tiles (H < 0, a workgroup-uniform fact) take a loop of their own: a scalar trip count and no clamping or
+// frame tests, instead of a per-position interior branch, a vector loop condition and an inside-the-frame mask.
+template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, int PHASE>
+__device__ __forceinline__ void byte_position(uint32_t lut_a, uint32_t center, int16_t* acc16, uint8_t* dst8, int p, int div, int bias) {
+    int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut_a, center);
+    if (PHASE != 0) v += (int)acc16[p];
+    if (PHASE == 2)
+        dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
+    else
+        acc16[p] = (int16_t)v;
+}
 template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, int PHASE, bool SKIP_OUTSIDE = false>
 __device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src, int16_t* acc16, uint8_t* dst8,
                                            int y0g, int x0g, int sy0g, int sx0g, int H, int W, int div, int bias,
                                            int tid) {
     const uint32_t lut_a = lds_addr(lut), src_a = lds_addr(src);
+    if (H < 0) {
+        constexpr int FULL = NDST / NT, TAIL = NDST - FULL * NT;
+        const uint32_t org = src_a + (uint32_t)((y0g - sy0g) * SP + (x0g - sx0g) * CH);
+#pragma unroll 1
+        for (int k = 0; k < FULL; ++k) {
+            const int p = tid + k * NT;
+            const int ry = p / DPc;
+            byte_position<NDST, DPc, SP, MODE, ROT0, NROT, RSTEP, PHASE>(lut_a, org + (uint32_t)(ry * (SP - DPc) + p), acc16, dst8, p, div, bias);
+        }
+        if (TAIL > 0 && tid < TAIL) {
+            const int p = tid + FULL * NT;
+            const int ry = p / DPc;
+            byte_position<NDST, DPc, SP, MODE, ROT0, NROT, RSTEP, PHASE>(lut_a, org + (uint32_t)(ry * (SP - DPc) + p), acc16, dst8, p, div, bias);
+        }
+        return;
+    }
     for (int p = tid; p < NDST; p += NT) {
         bool in = true;
         int a = center_addr<DPc, SP>(p, y0g, x0g, sy0g, sx0g, H, W, SKIP_OUTSIDE ? &in : nullptr);
         if (SKIP_OUTSIDE && !in) continue;
-        int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut_a, src_a + (uint32_t)a);
-        if (PHASE != 0) v += (int)acc16[p];
-        if (PHASE == 2)
-            dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
-        else
-            acc16[p] = (int16_t)v;
+        byte_position<NDST, DPc, SP, MODE, ROT0, NROT, RSTEP, PHASE>(lut_a, src_a + (uint32_t)a, acc16, dst8, p, div, bias);
     }
 }
 
