@@ -33,6 +33,7 @@
 // the pixels of that bin with all 64 lanes busy.  Per-pixel accumulators stay
 // in VGPRs across phases (two packed 16-bit fields + one).
 #include <string.h>
+#include <type_traits>
 
 #include "lerf_kernels.h"
 #include "lerf_stage3.h"
@@ -1056,29 +1057,43 @@ sr_fused_kernel(Params P) {
                 if (start) g_grp[ng + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = il;
                 ng += __popcll(m);
             }
+            if (lane == 0) g_grp[ng] = nrow;
+            // every group of the tile the same size (integer scale factors, away from the frame's top and bottom): the
+            // task loop then runs with that size as a compile-time constant, without a row test per tap set
+            const int g0 = ng > 0 ? g_grp[1] - g_grp[0] : 0;
+            bool same = true;
+            for (int base = 0; base < ng; base += 64) {
+                const int idx = base + lane;
+                if (idx < ng && g_grp[idx + 1] - g_grp[idx] != g0) same = false;
+            }
+            const bool uniform = __ballot(!same) == 0ull;
             if (lane == 0) {
-                g_grp[ng] = nrow;
                 ctl[21] = ng;
+                ctl[22] = uniform ? g0 : 0;
             }
         }
         __syncthreads();
         const int ngrp = ctl[21];
+        const int gsame = __builtin_amdgcn_readfirstlane(ctl[22]);
         const unsigned magic = (unsigned)((0x100000000ull + (unsigned)ndw - 1) / (unsigned)(ndw > 0 ? ndw : 1));
         const float ms255 = P.max_sigma * (1.0f / 255.0f);
         const int ntask = ngrp * ndw;
+        auto run_tasks = [&](auto gs_const) {
+        constexpr int GS = decltype(gs_const)::value;          // rows per group, 0 = read it per group
+        constexpr int GN = GS > 0 ? GS : GMAX;
         for (int t = tid; t < ntask; t += NT) {
             const int g = (int)__umulhi((unsigned)t, magic);
             const int dw = t - g * ndw;
             const int il0 = g_grp[g];
-            const int gs = g_grp[g + 1] - il0;
+            const int gs = GS > 0 ? GS : g_grp[g + 1] - il0;
             uint8_t* seg = seg0 + il0 * rowpitch;
             const int a0 = (int)(reinterpret_cast<uintptr_t>(seg) & 3u);
             const int b0 = dw * 4 - a0;
             const int lr = g_lr[il0];
-            uint32_t packed[GMAX];
+            uint32_t packed[GN];
             unsigned tiemask = 0;                                 // bit r*4+u
 #pragma unroll
-            for (int r = 0; r < GMAX; ++r) packed[r] = 0;
+            for (int r = 0; r < GN; ++r) packed[r] = 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int xc = min(max(b0 + u, 0), ncolc - 1);    // clamped; invalid bytes are not stored
@@ -1110,7 +1125,7 @@ sr_fused_kernel(Params P) {
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < GMAX; ++r) {
+                for (int r = 0; r < GN; ++r) {
                     if (r < gs) {
                         float e[SS];
 #pragma unroll
@@ -1133,7 +1148,7 @@ sr_fused_kernel(Params P) {
             if (tiemask != 0 && P.dis_r64 != nullptr) {
                 // rare: re-evaluate in float64 exactly as the reference does (lerf_stage3.h, tie guard)
 #pragma unroll 1
-                for (int q = 0; q < GMAX * 4; ++q) {
+                for (int q = 0; q < GN * 4; ++q) {
                     if (!((tiemask >> q) & 1u)) continue;
                     const int r = q >> 2, u = q & 3;
                     const int xc = min(max(b0 + u, 0), ncolc - 1);
@@ -1152,12 +1167,12 @@ sr_fused_kernel(Params P) {
                         for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
                     const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
 #pragma unroll
-                    for (int rr = 0; rr < GMAX; ++rr)
+                    for (int rr = 0; rr < GN; ++rr)
                         if (rr == r) packed[rr] = (packed[rr] & ~(0xFFu << (8 * u))) | (r8 << (8 * u));
                 }
             }
 #pragma unroll
-            for (int r = 0; r < GMAX; ++r) {
+            for (int r = 0; r < GN; ++r) {
                 if (r < gs) {
                     uint8_t* sr = seg + r * rowpitch;
                     if (b0 >= 0 && b0 + 3 < ncolc) {
@@ -1171,6 +1186,14 @@ sr_fused_kernel(Params P) {
                 }
             }
         }
+        };
+        // the constant-size variants cover the integer scale factors (x2 -> 2 rows per group, ...); anything else reads
+        // the group size per task
+        constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
+        if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});
+        else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{});
+        else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{});
+        else run_tasks(std::integral_constant<int, 0>{});
     }
 #ifdef LERF_STAMPS
     __syncthreads();

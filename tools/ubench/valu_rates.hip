@@ -10,6 +10,7 @@ template <int OP>
 __global__ void __launch_bounds__(1024) k(uint32_t* out, int iters, uint32_t seed) {
     uint32_t r0 = threadIdx.x + seed, r1 = r0 * 3, r2 = r0 * 5, r3 = r0 * 7, r4 = r0 * 11, r5 = r0 * 13, r6 = r0 * 17, r7 = r0 * 19;
     uint32_t b = seed | 0x3f800001u, c = seed * 7 + 3;
+    unsigned long long m64 = 0x5555555555555555ull * seed;
     for (int i = 0; i < iters; ++i) {
 #define ONE(n)                                                                                                   \
         if (OP == 0) asm volatile("v_max_u32 %0, %0, %1" : "+v"(r##n) : "v"(b));                                   \
@@ -57,10 +58,16 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, int iters, uint32_t see
         if (OP == 42) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(r##n));                                           \
         if (OP == 43) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(r##n) : "v"(b)); \
         if (OP == 44) asm volatile("v_mul_u32_u24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(r##n) : "v"(b)); \
-        if (OP == 45) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(r##n) : "v"(b), "v"(c));
+        if (OP == 45) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(r##n) : "v"(b), "v"(c));                      \
+        if (OP == 46) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r##n) : "v"(b), "s"(m64));             \
+        if (OP == 47) asm volatile("v_cmp_gt_f32_e64 %0, |%1|, %2" : "=s"(m64) : "v"(r##n), "v"(b));               \
+        if (OP == 48) asm volatile("v_max_f32 %0, |%0|, %1" : "+v"(r##n) : "v"(b));                                \
+        if (OP == 49) asm volatile("v_cmp_gt_f32_e64 %1, |%0|, %2\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "+v"(r##n), "=s"(m64) : "v"(b)); \
+        if (OP == 50) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(r##n) : "v"(b));                          \
+        if (OP == 51) asm volatile("v_mad_u64_u32 %0, %3, %1, %2, %0" : "+v"(rr##n) : "v"(b), "v"(c), "s"(m64));
         uint64_t rr0 = r0, rr1 = r1, rr2 = r2, rr3 = r3, rr4 = r4, rr5 = r5, rr6 = r6, rr7 = r7, bb = b, cc = c;
         REP8(ONE) REP8(ONE) REP8(ONE) REP8(ONE)
-        if (OP == 14) { r0 = (uint32_t)rr0; r1 = (uint32_t)rr1; r2 = (uint32_t)rr2; r3 = (uint32_t)rr3; r4 = (uint32_t)rr4; r5 = (uint32_t)rr5; r6 = (uint32_t)rr6; r7 = (uint32_t)rr7; }
+        if (OP == 14 || OP == 51) { r0 = (uint32_t)rr0; r1 = (uint32_t)rr1; r2 = (uint32_t)rr2; r3 = (uint32_t)rr3; r4 = (uint32_t)rr4; r5 = (uint32_t)rr5; r6 = (uint32_t)rr6; r7 = (uint32_t)rr7; }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
 }
@@ -95,6 +102,7 @@ int main() {
     run<31>("v_and_or_b32", d); run<32>("v_lshl_add_u32", d); run<33>("v_dot4_u32_u8", d); run<34>("v_rcp_f32", d);
     run<35>("v_add_f32", d); run<36>("v_sub_f32", d); run<37>("v_min_f32", d); run<38>("v_cvt_f32_ubyte0", d);
     run<39>("v_ashrrev_i32", d); run<40>("v_mov_b32", d); run<41>("v_rndne_f32", d); run<42>("v_cvt_u32_f32", d);
+    run<46>("v_cndmask_b32_e64 sgpr mask", d); run<47>("v_cmp_gt_f32_e64 -> sgpr", d); run<48>("v_max_f32 |abs|", d); run<49>("v_cmp + v_cndmask pair (2 instr)", d); run<50>("v_cvt_pk_u8_f32", d); run<51>("v_mad_u64_u32", d);
     run<43>("v_add_u32_sdwa", d); run<44>("v_mul_u32_u24_sdwa", d); run<45>("v_min3_f32", d);
     return 0;
 }
