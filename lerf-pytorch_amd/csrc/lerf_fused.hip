@@ -22,16 +22,16 @@
 //        that pixels with (centre >> 6) == q can touch, 5*4913 dwords = 96 KB
 //   C    input tile u8 (78x78x3)        stage 1 only
 //   ACC  int16 partial sums             stage 1 (and stage 2 of LeRF-L)
-//   LST  pixel lists sorted by quarter  stage 2 (LeRF-G), transient
+//   LST  pixel lists sorted by bin      stage 2 (LeRF-G), transient (under the piece, which waits in registers)
 //   D    (hq0,hq1,hq2,feat) dwords      stage 3, overlays LUT
 //
 // Stage 2 of LeRF-G keeps the whole 3-channel LUT entry in one dword, so one
 // simplex walk (index sort + 5 LDS gathers) serves all three hyper channels.
 // The full packed LUT (326 KB) cannot live in LDS; pixels are therefore binned
 // by the top two bits of their centre value (which select the slowest LUT axis
-// for every mode and rotation), and each (LUT, quarter) phase processes only
-// the pixels of that bin with all 64 lanes busy.  Per-pixel accumulators stay
-// in VGPRs across phases (two packed 16-bit fields + one).
+// for every mode and rotation), and each (LUT, bin) phase processes only the
+// pixels of that bin with all 64 lanes busy.  Per-pixel accumulators stay in
+// VGPRs across phases (two packed 16-bit fields + one).
 #include <string.h>
 #include <type_traits>
 
@@ -47,10 +47,18 @@ constexpr int TH = 64, TW = 64;    // LR tile
 constexpr int CH = 3;              // channels (RGB frames)
 constexpr int R1 = 3, R2 = 3;      // stage radii for modes s,c,t
 constexpr int LUT_PAD = 83584;     // padded entries per LUT in the pack (16-B multiple)
-constexpr int QSTRIDE = 4 * kStrideA;        // entries between quarter origins
-constexpr int QENTRIES = 5 * kStrideA;       // entries a quarter piece holds
-constexpr int QPIECE_BYTES = 24 * NT * 4;     // one stage-2 quarter piece in the pack / in LDS: 96 KiB (24565 dwords used)
-constexpr int MAXR = 17;           // max slot rounds: ceil(NH/1024) + 4 (S=4: 13872/1024 -> 14 + 3)
+// Stage-2 bins: a pixel-channel goes by the top-axis level (high nibble) of its centre value, which selects the slowest
+// LUT axis for every mode and rotation.  Bin b covers the levels [bin_lo(b), bin_lo(b + 1)); its piece of a packed LUT is
+// those levels plus the one above (the simplex walk steps up once).
+constexpr int NBIN = 4;
+__host__ __device__ constexpr int bin_lo(int b) { return 4 * b; }
+__device__ __forceinline__ uint32_t bin_of_level(uint32_t msb) { return msb >> 2; }
+constexpr int PIECE_LEVELS = 5;                               // levels per piece
+constexpr int PIECE_ENTRIES = PIECE_LEVELS * kStrideA;
+constexpr int NSLAB = (PIECE_ENTRIES * 4 + 16 * NT - 1) / (16 * NT);   // 16 bytes per thread and slab
+constexpr int PIECE_BYTES = NSLAB * 16 * NT;                  // one piece in the pack (96 KiB, 24565 dwords used)
+constexpr int PIECE_BLOCKS = (PIECE_ENTRIES * 4 + 1023) / 1024;      // 1-KiB blocks of a piece that hold data
+constexpr int PIECE_LDS = PIECE_BLOCKS * 1024;                // what a piece occupies in LDS
 
 template <int S>
 struct Dims {
@@ -68,10 +76,14 @@ struct Dims {
     static constexpr int OFF_C = OFF_LUT + LUT_PAD;
     static constexpr int OFF_ACC = OFF_C + up16(NI);
     static constexpr int END1 = OFF_ACC + up16(NF * 2);
-    // stage 2 quarter path
-    static constexpr int SZ_Q = QPIECE_BYTES;
-    static constexpr int OFF_LST = OFF_X + SZ_Q;
-    static constexpr int END2 = OFF_LST + MAXR * NT * 2;
+    // stage 2, LeRF-G: one piece.  The position lists, the per-thread list cursors and the wave x bin table only live
+    // between the binning and the first piece store (the first piece waits in registers) and overlay the piece.
+    static constexpr int MAXR = (NH + NBIN * 63 + NT - 1) / NT;   // slot rounds: every bin padded to whole waves (14)
+    static constexpr int OFF_LST = OFF_X;
+    static constexpr int OFF_CNT = OFF_LST + MAXR * NT * 2;
+    static constexpr int OFF_TAB = OFF_CNT + NBIN * NT * 2;
+    static_assert(OFF_TAB + NW * NBIN * 4 <= OFF_X + PIECE_LDS, "binning scratch fits under the piece");
+    static constexpr int END2 = OFF_X + PIECE_LDS;
     // stage 3
     static constexpr int OFF_D = OFF_X;
     // S = 2: the tile geometry is staged at kernel start (its table look-ups overlap the input load) into a
@@ -693,125 +705,136 @@ sr_fused_kernel(Params P) {
             if (p < D::NH) Dt[p] = tmp[k];
         }
     } else {
-        // ---- stage 2, LeRF-G: packed 3-channel LUT quarters, pixels binned by centre >> 6
+        // ---- stage 2, LeRF-G: packed 3-channel LUT pieces, pixels binned by the top-axis level of their centre
+        constexpr int MAXR = D::MAXR;
         uint16_t* lst = reinterpret_cast<uint16_t*>(smem + D::OFF_LST);
-        // Binning without atomics: wave w owns positions [w*PW, (w+1)*PW); per-wave counts per quarter
-        // go through LDS, one thread turns them into segment bases (each quarter padded to a multiple
-        // of NT so that a slot round never mixes quarters), then every wave scatters its ids in order.
-        // ctl[0..3] totals, ctl[8..11] first round, ctl[12..15] end round, ctl[32 + w*4 + q] wave counts/bases
-        for (int i = tid; i < MAXR * NT / 2; i += NT) reinterpret_cast<uint32_t*>(lst)[i] = 0xFFFFFFFFu;
-        constexpr int KH = (D::NH + NT - 1) / NT;
-        constexpr int PW = KH * 64;
+        uint16_t* cnt = reinterpret_cast<uint16_t*>(smem + D::OFF_CNT);      // [bin][thread] list cursors
+        int* tab = reinterpret_cast<int*>(smem + D::OFF_TAB);                // [wave][bin] counts, then list bases
+        // Counting sort of the hyper-region positions by bin, every bin padded to whole waves: list entry i belongs to
+        // slot round i / NT of thread i % NT, so a 64-entry chunk (one wave in one round) never mixes bins.
+        // ctl[32 + b] first chunk of bin b, ctl[40 + b] one past its last, ctl[48 + i] i-th non-empty bin, ctl[56] their number.
         // Positions of the hyper region that lie outside the frame (tiles on the right / bottom edge, the halo ring of edge
         // tiles) are not looked up at all: stage 3 reads them as replicas of the clamped position (edge-padded hyper maps,
         // zero image), which fill_outside() below copies once the in-frame values exist.  A 28-row strip tile or the
         // last tile row of a 1080-row frame then costs what its in-frame part costs.
-        uint32_t qpack = 0, spack = 0;          // 2 bits per owned position + 1 skip bit
+        for (int i = tid; i < MAXR * NT / 2; i += NT) reinterpret_cast<uint32_t*>(lst)[i] = 0xFFFFFFFFu;
+        constexpr int KH = (D::NH + NT - 1) / NT;
+        static_assert(KH <= 15 && NBIN <= 4 && NW == 16, "nibble counts, one byte field per bin, one lane per (wave, bin)");
+        uint32_t qlo = 0, qhi = 0;              // 4 bits per owned position p = tid * KH + k: its bin, 15 = not looked up (thread-major lists = position order)
+        uint32_t xa, xb;                        // per-thread counts of bins (0, 1) and (2, 3), two 16-bit fields per register
         {
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            uint32_t hist = 0;                  // one byte per bin
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-                const int p = wave * PW + k * 64 + lane;
-                int q = 4;
+                const int p = tid * KH + k;
+                uint32_t q = 15;
                 if (p < D::NH) {
                     bool in = true;
                     const int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, &in);
-                    if (in) q = Bt[a] >> 6;
+                    if (in) q = bin_of_level((uint32_t)Bt[a] >> 4);
                 }
-                spack |= (uint32_t)(q == 4) << k;
-                qpack |= (uint32_t)(q & 3) << (2 * k);
-                c0 += __popcll(__ballot(q == 0));
-                c1 += __popcll(__ballot(q == 1));
-                c2 += __popcll(__ballot(q == 2));
-                c3 += __popcll(__ballot(q == 3));
+                if (k < 8) qlo |= q << (4 * k); else qhi |= q << (4 * (k - 8));
+                hist += q < NBIN ? 1u << (8 * q) : 0u;
             }
-            if (lane == 0) {
-                ctl[32 + wave * 4 + 0] = c0;
-                ctl[32 + wave * 4 + 1] = c1;
-                ctl[32 + wave * 4 + 2] = c2;
-                ctl[32 + wave * 4 + 3] = c3;
-            }
+            xa = (hist & 0xFFu) | ((hist << 8) & 0xFF0000u);
+            xb = ((hist >> 16) & 0xFFu) | ((hist >> 8) & 0xFF0000u);
+        }
+        // wave-inclusive scans of the packed count pairs (row shifts + the two row broadcasts of the DPP unit)
+        auto wave_scan = [](uint32_t v) {
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31
+            return v;
+        };
+        const uint32_t ia = wave_scan(xa), ib = wave_scan(xb);
+        if (lane == 63) {
+            int* t = tab + wave * 4;
+            t[0] = (int)(ia & 0xFFFFu); t[1] = (int)(ia >> 16); t[2] = (int)(ib & 0xFFFFu); t[3] = (int)(ib >> 16);
         }
         __syncthreads();
         if (wave == 0) {
-            // lane = q * 16 + w: scan the 16 wave counts of every quarter inside its 16-lane group
-            static_assert(NW == 16, "one 16-lane group per quarter");
-            const int q = lane >> 4, w = lane & 15;
-            const int c = ctl[32 + w * 4 + q];
-            int incl = c;
+            // lane = w * 4 + b
+            const int bb = lane & 3, w = lane >> 2;
+            const int c = tab[w * 4 + bb];
+            int incl = c;                                        // scan over the waves of a bin: lanes 4 apart
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const int up = __shfl_up(incl, d, 16);
-                if (w >= d) incl += up;
+            for (int d = 4; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
             }
-            const int t0 = __shfl(incl, 15), t1 = __shfl(incl, 31), t2 = __shfl(incl, 47), t3 = __shfl(incl, 63);
-            const int r0 = (t0 + NT - 1) / NT, r1 = (t1 + NT - 1) / NT, r2 = (t2 + NT - 1) / NT, r3 = (t3 + NT - 1) / NT;
-            const int first = q == 0 ? 0 : (q == 1 ? r0 : (q == 2 ? r0 + r1 : r0 + r1 + r2));
-            const int mine = q == 0 ? r0 : (q == 1 ? r1 : (q == 2 ? r2 : r3));
-            ctl[32 + w * 4 + q] = first * NT + incl - c;                // exclusive prefix over waves
+            const int total = __shfl(incl, 60 + bb);
+            const int padded = (total + 63) & ~63;
+            int start = padded;                                  // scan over the bins: 4 neighbouring lanes
+#pragma unroll
+            for (int d = 1; d < 4; d <<= 1) {
+                const int up = __shfl_up(start, d, 4);
+                if (bb >= d) start += up;
+            }
+            start -= padded;
+            tab[w * 4 + bb] = start + incl - c;                  // list base of (wave, bin)
+            const unsigned long long ne = __ballot(w == 0 && total > 0);
             if (w == 0) {
-                ctl[q] = q == 0 ? t0 : (q == 1 ? t1 : (q == 2 ? t2 : t3));
-                ctl[8 + q] = first;                                     // first round of the quarter
-                ctl[12 + q] = first + mine;                             // one past its last round
+                ctl[32 + bb] = start >> 6;
+                ctl[40 + bb] = (start + padded) >> 6;
+                if (total > 0) ctl[48 + __popcll(ne & ((1ull << bb) - 1ull))] = bb;
+                if (bb == 0) ctl[56] = __popcll(ne);
             }
         }
         __syncthreads();
-        static_assert(QENTRIES * 4 <= QPIECE_BYTES, "piece = 6 x uint4 per thread");
-        uint4 pr0, pr1, pr2, pr3, pr4, pr5;
-        pr0 = pr1 = pr2 = pr3 = pr4 = pr5 = make_uint4(0, 0, 0, 0);
-#define LERF_PRE_LOAD(SRC)                                                                         \
-        do {                                                                                       \
-            const uint4* s_ = reinterpret_cast<const uint4*>(SRC) + (wave * 64 + lane);            \
-            pr0 = s_[0]; pr1 = s_[NT]; pr2 = s_[2 * NT]; pr3 = s_[3 * NT]; pr4 = s_[4 * NT]; pr5 = s_[5 * NT]; \
-        } while (0)
-        const uint8_t* s2q = P.pack + 3 * LUT_PAD;          // [LUT l][quarter q][QPIECE_BYTES], blocks pre-permuted
+        // The next piece rides in registers behind the lookups of the current one: NSLAB x 16 bytes per thread.
+        uint4 pr[NSLAB];
+#pragma unroll
+        for (int i = 0; i < NSLAB; ++i) pr[i] = make_uint4(0, 0, 0, 0);
+        const uint8_t* s2p = P.pack + 3 * LUT_PAD;          // [LUT l][bin b][PIECE_BYTES], blocks pre-permuted
+        auto pre_load = [&](int l, int bq) {
+            const uint4* s_ = reinterpret_cast<const uint4*>(s2p + ((size_t)l * NBIN + bq) * PIECE_BYTES) + (wave * 64 + lane);
+#pragma unroll
+            for (int i = 0; i < NSLAB; ++i) pr[i] = s_[i * NT];
+        };
+        const int nbins = __builtin_amdgcn_readfirstlane(ctl[56]);
+        const int nph = nbins * 6;
+        if (nph > 0) pre_load(0, __builtin_amdgcn_readfirstlane(ctl[48]));      // in flight during the scatter and the slot set-up
         {
-            // first piece (LUT 0 of the first non-empty quarter): in flight during the scatter and the slot set-up
-            const int t0 = __builtin_amdgcn_readfirstlane(ctl[0]), t1 = __builtin_amdgcn_readfirstlane(ctl[1]),
-                      t2 = __builtin_amdgcn_readfirstlane(ctl[2]);
-            const int q0 = t0 > 0 ? 0 : (t1 > 0 ? 1 : (t2 > 0 ? 2 : 3));
-            LERF_PRE_LOAD(s2q + (size_t)q0 * QPIECE_BYTES);
-        }
-        {
-            int cur0 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 0]);
-            int cur1 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 1]);
-            int cur2 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 2]);
-            int cur3 = __builtin_amdgcn_readfirstlane(ctl[32 + wave * 4 + 3]);
+            // list cursors of this thread: base of (wave, bin) + the counts of the lanes below
+            const int* t = tab + wave * 4;
+            const uint32_t ea = ia - xa, eb = ib - xb;
+            cnt[0 * NT + tid] = (uint16_t)(t[0] + (ea & 0xFFFFu));
+            cnt[1 * NT + tid] = (uint16_t)(t[1] + (ea >> 16));
+            cnt[2 * NT + tid] = (uint16_t)(t[2] + (eb & 0xFFFFu));
+            cnt[3 * NT + tid] = (uint16_t)(t[3] + (eb >> 16));
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-                const int p = wave * PW + k * 64 + lane;
-                const int q = ((spack >> k) & 1u) ? 4 : (int)((qpack >> (2 * k)) & 3u);
-                const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2),
-                                         m3 = __ballot(q == 3);
-                // destination of this lane under each quarter (mbcnt adds the wave's running base), then one select:
-                // the masks and bases stay scalar operands instead of being moved into VGPRs for a 64-bit select
-                const int o0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, (unsigned)cur0));
-                const int o1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, (unsigned)cur1));
-                const int o2 = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, (unsigned)cur2));
-                const int o3 = __builtin_amdgcn_mbcnt_hi((unsigned)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m3, (unsigned)cur3));
-                const int o = q == 0 ? o0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
-                if (q < 4) lst[o] = (uint16_t)p;
-                cur0 += __popcll(m0);
-                cur1 += __popcll(m1);
-                cur2 += __popcll(m2);
-                cur3 += __popcll(m3);
+                const uint32_t q = k < 8 ? (qlo >> (4 * k)) & 0xFu : (qhi >> (4 * (k - 8))) & 0xFu;
+                if (q < NBIN) {
+                    uint16_t* c = cnt + q * NT + tid;
+                    const uint16_t v = *c;
+                    *c = (uint16_t)(v + 1);
+                    lst[v] = (uint16_t)(tid * KH + k);
+                }
             }
         }
         __syncthreads();
-        // slots -> registers.  Per slot: the feat-tile address of its clamped centre (16 bits, two slots per
-        // VGPR; 0xFFFF = round without any position in this wave) and three 16-bit accumulators (accA: e0 | e2 << 16; accB: e1, two slots
-        // per VGPR).  The position ids stay in LST and are re-read when the sums are finalised.
+        // slots -> registers.  Per slot: the feat-tile address of its centre (16 bits, two slots per VGPR) and three
+        // 16-bit accumulators (accA: e0 | e2 << 16; accB: e1).  Padding lanes of a partly filled wave repeat the wave's
+        // first real position (same bin, same LDS words: broadcast reads) into accumulators nobody reads, so the lookup
+        // loop needs no per-lane test; `vmask` remembers which slots are real, and the position id comes back out of the
+        // address when the sums are finalised (listed positions are inside the frame: the address is not clamped).
         constexpr int MAXP = (MAXR + 1) / 2;
         uint32_t slot2[MAXP];
         uint32_t accA[MAXR], accB[MAXR];
         uint32_t wrounds = 0;                 // bit k: this wave has a real position in round k (wave-uniform)
+        uint32_t vmask = 0;                   // bit k: this lane's slot k is real
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
             const uint32_t p = lst[k * NT + tid];
             uint32_t a = 0xFFFFu;
-            if (p != 0xFFFFu) a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr);
-            // padding lanes of a partly filled wave repeat the wave's first real position (same quarter, same LDS words:
-            // broadcast reads) into accumulators nobody reads, so the lookup loop needs no per-lane test
+            if (p != 0xFFFFu) {
+                a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr);
+                vmask |= 1u << k;
+            }
             const unsigned long long real = __ballot(p != 0xFFFFu);
             if (real != 0ull) {
                 const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)a, (int)__builtin_ctzll(real));
@@ -822,167 +845,126 @@ sr_fused_kernel(Params P) {
             accA[k] = 0;
             accB[k] = 0;
         }
-        __syncthreads();
+        __syncthreads();                      // the lists are dead: the first piece may land on them
 
         LERF_STAMP(7);
-        // phases = (non-empty quarter) x (6 LUTs).  The next piece is fetched into registers while the
-        // current one is being used, so the L2 latency of the piece copies hides behind the lookups.
-        int nph = 0;
-        {
-            int nq = 0;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int c = __builtin_amdgcn_readfirstlane(ctl[qq]);
-                if (c > 0) {
-                    if (tid == 0) ctl[24 + nq] = qq;
-                    ++nq;
-                }
-            }
-            nph = nq * 6;
-        }
-        __syncthreads();
-        // The piece travels as 6 x 16 bytes per thread (wave w, iteration i: 1-KiB block B = 16 i + w of the piece,
-        // lane L its bytes 16 L..16 L+15) and is stored with ds_write_addtid_b32 (address = M0 + offset + 4*lane, no
-        // address VGPR: 128 B/clk/CU against 79 for ds_write_b128).  addtid puts component c of all lanes at
-        // block + 256 c + 4 L, so the pack holds every block pre-permuted (global dword 4L+c = logical dword 64c+L)
-        // and LDS ends up in natural order.  M0 = the wave's block column; the 16-bit offset reaches 4 iterations.
+        // The piece travels as NSLAB x 16 bytes per thread (wave w, slab i: 1-KiB block B = 16 i + w of the piece, lane L
+        // its bytes 16 L..16 L+15) and is stored with ds_write_addtid_b32 (address = M0 + offset + 4*lane, no address
+        // VGPR: 128 B/clk/CU against 79 for ds_write_b128).  addtid puts component c of all lanes at block + 256 c + 4 L,
+        // so the pack holds every block pre-permuted (global dword 4L+c = logical dword 64c+L) and LDS ends up in
+        // natural order.  M0 = the wave's block column; the 16-bit offset reaches 4 slabs.
 #define LERF_ADDTID(V, OFF) asm volatile("ds_write_addtid_b32 %0 offset:" #OFF :: "v"(V) : "memory")
 #define LERF_ADDTID4(R, OFF0, OFF1, OFF2, OFF3) \
         LERF_ADDTID(R.x, OFF0); LERF_ADDTID(R.y, OFF1); LERF_ADDTID(R.z, OFF2); LERF_ADDTID(R.w, OFF3)
-#define LERF_PRE_STORE(DST_OFFSET)                                                                 \
-        do {                                                                                       \
-            const uint32_t m0a_ = __builtin_amdgcn_readfirstlane((uint32_t)(DST_OFFSET) + (uint32_t)wave * 1024u); \
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(m0a_) : "memory");                    \
-            LERF_ADDTID4(pr0, 0, 256, 512, 768);                                                   \
-            LERF_ADDTID4(pr1, 16384, 16640, 16896, 17152);                                         \
-            LERF_ADDTID4(pr2, 32768, 33024, 33280, 33536);                                         \
-            LERF_ADDTID4(pr3, 49152, 49408, 49664, 49920);                                         \
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(m0a_ + 65536u) : "memory");           \
-            LERF_ADDTID4(pr4, 0, 256, 512, 768);                                                   \
-            LERF_ADDTID4(pr5, 16384, 16640, 16896, 17152);                                         \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
-        } while (0)
-        for (int ph = 0; ph < nph; ++ph) {
-            {
-                const int qi = ph / 6;
-                const int l = ph - qi * 6;                       // LUT l = mode (l>>1), rotation parity (l&1)
-                const int q = __builtin_amdgcn_readfirstlane(ctl[24 + qi]);
-                const unsigned long long t_copy = LERF_NOW();
-                (void)t_copy;
-                LERF_PRE_STORE(D::OFF_X);
-                Off3 o0, o1;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    o0.o[i] = P.s2off[l][i];
-                    o1.o[i] = P.s2off[l][3 + i];
-                }
-                // LDS address of the quarter piece's logical entry 0 (the piece starts at top-axis level 4 q)
-                const uint32_t qbase = lds_addr(smem + D::OFF_X) - (uint32_t)q * (4u * kStrideA * 4u);
-                const uint32_t bt_a = lds_addr(Bt);
-                const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;   // axis strides, bytes
-                const int rsq = __builtin_amdgcn_readfirstlane(ctl[8 + q]);
-                const int req = __builtin_amdgcn_readfirstlane(ctl[12 + q]);
-                // rounds [rsq, req) of this quarter in which this wave holds a real position: one scalar bit test per
-                // unrolled round instead of two range compares and a padding compare
-                const uint32_t act = wrounds & ((1u << req) - 1u) & ~((1u << rsq) - 1u);
-                __syncthreads();
-                if (ph + 1 < nph) {
-                    const int qi2 = (ph + 1) / 6;
-                    const int l2 = (ph + 1) - qi2 * 6;
-                    const int q2 = __builtin_amdgcn_readfirstlane(ctl[24 + qi2]);
-                    LERF_PRE_LOAD(s2q + ((size_t)l2 * 4 + q2) * QPIECE_BYTES);
-                }
-                LERF_STAMP_ADD(8, t_copy);
-                const unsigned long long t_look = LERF_NOW();
-                (void)t_look;
-#pragma unroll
-                for (int k = 0; k < MAXR; ++k) {
-                    if ((act >> k) & 1u) {
-                        const uint32_t sa = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
-                        {
-                            // stage A: the 7 pixel reads of the two rotations (high-half loads, see lds_pixel_hi)
-                            const uint32_t cpa = bt_a + sa;
-                            uint32_t ra = lds_pixel_hi(cpa);
-                            uint32_t rb0 = lds_pixel_hi(cpa + (uint32_t)o0.o[0]), rc0 = lds_pixel_hi(cpa + (uint32_t)o0.o[1]),
-                                     rd0 = lds_pixel_hi(cpa + (uint32_t)o0.o[2]);
-                            uint32_t rb1 = lds_pixel_hi(cpa + (uint32_t)o1.o[0]), rc1 = lds_pixel_hi(cpa + (uint32_t)o1.o[1]),
-                                     rd1 = lds_pixel_hi(cpa + (uint32_t)o1.o[2]);
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra), "+v"(rb0), "+v"(rc0), "+v"(rd0), "+v"(rb1), "+v"(rc1), "+v"(rd1));
-                            // stage B: both walks (LDS addresses into the quarter piece)
-                            const int basea = (int)(__umul24(msb_of(ra), kStrideA * 4) + qbase);
-                            const unsigned ka = key_of(ra, st_a);
-                            const Walk<4> W0 = simplex_walk<4>(ka, basea, rb0, rc0, rd0, st_b, st_c, st_d);
-                            const Walk<4> W1 = simplex_walk<4>(ka, basea, rb1, rc1, rd1, st_b, st_c, st_d);
-                            // stage C: ten dword gathers in flight together
-                            uint32_t d0[5], d1[5];
-#if defined(LERF_EXP) && LERF_EXP == 1      // diagnostic: conflict-free gathers (one dword per lane)
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) d0[n] = lds_ld32(qbase + 4 * kStrideA * 16 + lane * 4 + n * 256) + W0.a(n);
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) d1[n] = lds_ld32(qbase + 4 * kStrideA * 16 + lane * 4 + n * 256 + 2048) + W1.a(n);
-#elif defined(LERF_EXP) && LERF_EXP == 2    // diagnostic: no gathers
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) d0[n] = W0.a(n);
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) d1[n] = W1.a(n);
-#else
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) d0[n] = W0.ld32(n);
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) d1[n] = W1.ld32(n);
-#endif
-#if defined(LERF_EXP) && LERF_EXP >= 4     // diagnostic: marginal cost of ten extra instructions of one class per slot
-                            {
-                                uint32_t z = (uint32_t)W0.i0;
-#pragma unroll
-                                for (int n = 0; n < 10; ++n) {
-#if LERF_EXP == 4
-                                    asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(z) : "v"(vb0));
-#elif LERF_EXP == 5
-                                    asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(z) : "v"(vb0));
-#elif LERF_EXP == 6
-                                    asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(z) : "v"(vb0), "v"(vc0));
-#elif LERF_EXP == 7
-                                    asm volatile("v_add_u32 %0, %0, %1" : "+v"(z) : "v"(vb0));
-#elif LERF_EXP == 8
-                                    asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(z) : "v"(vb0));
-#endif
-                                }
-                                if (z == 0x12345u) accA[k] += 1;
-                            }
-#endif
-                            __builtin_amdgcn_sched_barrier(0);
-                            // stage D: two 24-bit MADs per corner: the entry is e0 | 0 << 8 | e2 << 16 | e1 << 24, and a 24-bit
-                            // multiply reads bits 0..23 only, so the (e0, e2) pair needs no mask; e1 is shifted down
-                            const unsigned w0[5] = {(unsigned)kQ - W0.f0, W0.f0 - W0.f1, W0.f1 - W0.f2, W0.f2 - W0.f3, W0.f3};
-                            const unsigned w1[5] = {(unsigned)kQ - W1.f0, W1.f0 - W1.f1, W1.f1 - W1.f2, W1.f2 - W1.f3, W1.f3};
-                            uint32_t a = accA[k], bb = accB[k];
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) {
-                                a += __umul24(w0[n], d0[n]);
-                                bb += __umul24(w0[n], d0[n] >> 24);
-                            }
-#pragma unroll
-                            for (int n = 0; n < 5; ++n) {
-                                a += __umul24(w1[n], d1[n]);
-                                bb += __umul24(w1[n], d1[n] >> 24);
-                            }
-                            accA[k] = a;
-                            accB[k] = bb;
-                        }
-                    }
-                }
-                __syncthreads();
-                LERF_STAMP_ADD(9, t_look);
+#define LERF_SET_M0(V) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(V) : "memory")
+        auto pre_store = [&]() {
+            const uint32_t m0a = __builtin_amdgcn_readfirstlane((uint32_t)D::OFF_X + (uint32_t)wave * 1024u);
+            // slab i holds blocks 16 i + wave: the last slab is partial (blocks beyond PIECE_BLOCKS carry no data)
+#define LERF_SLAB_OK(I) ((I) < NSLAB && (16 * (I) + 15 < PIECE_BLOCKS || 16 * (I) + wave < PIECE_BLOCKS))
+            LERF_SET_M0(m0a);
+            if (LERF_SLAB_OK(0)) { LERF_ADDTID4(pr[0], 0, 256, 512, 768); }
+            if (LERF_SLAB_OK(1)) { LERF_ADDTID4(pr[1 < NSLAB ? 1 : 0], 16384, 16640, 16896, 17152); }
+            if (LERF_SLAB_OK(2)) { LERF_ADDTID4(pr[2 < NSLAB ? 2 : 0], 32768, 33024, 33280, 33536); }
+            if (LERF_SLAB_OK(3)) { LERF_ADDTID4(pr[3 < NSLAB ? 3 : 0], 49152, 49408, 49664, 49920); }
+            if (NSLAB > 4) {
+                LERF_SET_M0(m0a + 65536u);
+                if (LERF_SLAB_OK(4)) { LERF_ADDTID4(pr[4 < NSLAB ? 4 : 0], 0, 256, 512, 768); }
+                if (LERF_SLAB_OK(5)) { LERF_ADDTID4(pr[5 < NSLAB ? 5 : 0], 16384, 16640, 16896, 17152); }
+                if (LERF_SLAB_OK(6)) { LERF_ADDTID4(pr[6 < NSLAB ? 6 : 0], 32768, 33024, 33280, 33536); }
+                if (LERF_SLAB_OK(7)) { LERF_ADDTID4(pr[7 < NSLAB ? 7 : 0], 49152, 49408, 49664, 49920); }
             }
+            if (NSLAB > 8) {
+                LERF_SET_M0(m0a + 131072u);
+                if (LERF_SLAB_OK(8)) { LERF_ADDTID4(pr[8 < NSLAB ? 8 : 0], 0, 256, 512, 768); }
+            }
+            static_assert(NSLAB <= 9, "three M0 windows");
+#undef LERF_SLAB_OK
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // phases = (non-empty bin) x (6 LUTs).  The next piece is fetched into registers while the current one is being
+        // used, so the L2 latency of the piece copies hides behind the lookups.
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        for (int ph = 0; ph < nph; ++ph) {
+            const int bi = ph / 6;
+            const int l = ph - bi * 6;                       // LUT l = mode (l>>1), rotation parity (l&1)
+            const int bq = __builtin_amdgcn_readfirstlane(ctl[48 + bi]);
+            const unsigned long long t_copy = LERF_NOW();
+            (void)t_copy;
+            pre_store();
+            Off3 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                o0.o[i] = P.s2off[l][i];
+                o1.o[i] = P.s2off[l][3 + i];
+            }
+            // LDS address of the piece's logical entry 0 (the piece starts at top-axis level bin_lo(bq))
+            const uint32_t qbase = lds_addr(smem + D::OFF_X) - (uint32_t)bin_lo(bq) * (kStrideA * 4u);
+            const uint32_t bt_a = lds_addr(Bt);
+            const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;   // axis strides, bytes
+            // this wave's rounds of the bin: chunk 16 k + wave inside [cs, ce); one scalar bit test per unrolled round
+            const int cs = __builtin_amdgcn_readfirstlane(ctl[32 + bq]), ce = __builtin_amdgcn_readfirstlane(ctl[40 + bq]);
+            const int klo = cs > wv ? (cs - wv + 15) >> 4 : 0, khi = ce > wv ? (ce - wv + 15) >> 4 : 0;
+            const uint32_t act = wrounds & ((1u << khi) - 1u) & ~((1u << klo) - 1u);
+            __syncthreads();
+            if (ph + 1 < nph) {
+                const int bi2 = (ph + 1) / 6;
+                pre_load((ph + 1) - bi2 * 6, __builtin_amdgcn_readfirstlane(ctl[48 + bi2]));
+            }
+            LERF_STAMP_ADD(8, t_copy);
+            const unsigned long long t_look = LERF_NOW();
+            (void)t_look;
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k) {
+                if ((act >> k) & 1u) {
+                    const uint32_t sa = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
+                    // stage A: the 7 pixel reads of the two rotations (high-half loads, see lds_pixel_hi)
+                    const uint32_t cpa = bt_a + sa;
+                    uint32_t ra = lds_pixel_hi(cpa);
+                    uint32_t rb0 = lds_pixel_hi(cpa + (uint32_t)o0.o[0]), rc0 = lds_pixel_hi(cpa + (uint32_t)o0.o[1]),
+                             rd0 = lds_pixel_hi(cpa + (uint32_t)o0.o[2]);
+                    uint32_t rb1 = lds_pixel_hi(cpa + (uint32_t)o1.o[0]), rc1 = lds_pixel_hi(cpa + (uint32_t)o1.o[1]),
+                             rd1 = lds_pixel_hi(cpa + (uint32_t)o1.o[2]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra), "+v"(rb0), "+v"(rc0), "+v"(rd0), "+v"(rb1), "+v"(rc1), "+v"(rd1));
+                    // stage B: both walks (LDS addresses into the piece)
+                    const int basea = (int)(__umul24(msb_of(ra), kStrideA * 4) + qbase);
+                    const unsigned ka = key_of(ra, st_a);
+                    const Walk<4> W0 = simplex_walk<4>(ka, basea, rb0, rc0, rd0, st_b, st_c, st_d);
+                    const Walk<4> W1 = simplex_walk<4>(ka, basea, rb1, rc1, rd1, st_b, st_c, st_d);
+                    // stage C: ten dword gathers in flight together
+                    uint32_t d0[5], d1[5];
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) d0[n] = W0.ld32(n);
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) d1[n] = W1.ld32(n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // stage D: two 24-bit MADs per corner: the entry is e0 | 0 << 8 | e2 << 16 | e1 << 24, and a 24-bit
+                    // multiply reads bits 0..23 only, so the (e0, e2) pair needs no mask; e1 is shifted down
+                    const unsigned w0[5] = {(unsigned)kQ - W0.f0, W0.f0 - W0.f1, W0.f1 - W0.f2, W0.f2 - W0.f3, W0.f3};
+                    const unsigned w1[5] = {(unsigned)kQ - W1.f0, W1.f0 - W1.f1, W1.f1 - W1.f2, W1.f2 - W1.f3, W1.f3};
+                    uint32_t a = accA[k], bb = accB[k];
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) {
+                        a += __umul24(w0[n], d0[n]);
+                        bb += __umul24(w0[n], d0[n] >> 24);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) {
+                        a += __umul24(w1[n], d1[n]);
+                        bb += __umul24(w1[n], d1[n] >> 24);
+                    }
+                    accA[k] = a;
+                    accB[k] = bb;
+                }
+            }
+            __syncthreads();
+            LERF_STAMP_ADD(9, t_look);
         }
         LERF_STAMP(10);
         // finalise: hq = rne(clip(N/192 + 127)); entries are biased by +128 -> 12 lookups * 16 * 128 = 24576
         //           N + 127*192 = field - 24576 + 24384 = field - 192
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
-            const uint32_t p = lst[k * NT + tid];
-            if (p != 0xFFFFu) {
+            if ((vmask >> k) & 1u) {
                 const int div2 = kQ * 12;
                 int n0 = (int)(accA[k] & 0xFFFFu) - div2;
                 int n2 = (int)(accA[k] >> 16) - div2;
@@ -990,11 +972,11 @@ sr_fused_kernel(Params P) {
                 uint32_t h0 = (uint32_t)rne_div_clip255_fast(n0, div2);
                 uint32_t h1 = (uint32_t)rne_div_clip255_fast(n1, div2);
                 uint32_t h2 = (uint32_t)rne_div_clip255_fast(n2, div2);
-                bool inside = true;
-                int a = (int)((k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu));   // interior tile: the slot's own address
-                if (Hc >= 0) a = center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, &inside);
-                uint32_t fv = inside ? (uint32_t)Bt[a] : 0u;      // zero-padded image outside the frame (:208)
-                Dt[p] = h0 | (h1 << 8) | (h2 << 16) | (fv << 24);
+                // feat-tile address -> hyper-region position: row (ry + R2) of pitch FP -> row ry of pitch HP, R2 pixels left
+                const uint32_t a = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
+                const uint32_t row = a / (uint32_t)D::FP;
+                const uint32_t p = a - row * (uint32_t)(D::FP - D::HP) - (uint32_t)(R2 * D::HP + R2 * CH);
+                Dt[p] = h0 | (h1 << 8) | (h2 << 16) | ((uint32_t)Bt[a] << 24);
             }
         }
     }
@@ -1279,10 +1261,9 @@ s1_kernel(Params P) {
 
 #undef LERF_S1_LOAD
 #undef LERF_S1_STORE
-#undef LERF_PRE_LOAD
-#undef LERF_PRE_STORE
 #undef LERF_ADDTID
 #undef LERF_ADDTID4
+#undef LERF_SET_M0
 
 }  // namespace fused
 
@@ -1376,28 +1357,28 @@ int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
 }
 
 // fused LUT pack: [n1 x LUT_PAD int8 stage-1 LUTs][stage-2 LUTs], stage 2 as
-//   oC == 3: 6 x LUT_PAD uint32 (biased bytes e0+128 | e2+128 << 16 | e1+128 << 24), order s_r0, s_r1, c_r0, ...
+//   oC == 3: 6 x NBIN pieces of PIECE_BYTES (dwords of biased bytes e0+128 | e2+128 << 16 | e1+128 << 24), order s_r0, s_r1, c_r0, ...
 //   oC == 1: 6 x LUT_PAD int8
 size_t fused_lutpack_bytes(int oC) {
-    return (size_t)3 * fused::LUT_PAD + (oC == 3 ? (size_t)6 * 4 * fused::QPIECE_BYTES : (size_t)6 * fused::LUT_PAD);
+    return (size_t)3 * fused::LUT_PAD + (oC == 3 ? (size_t)6 * fused::NBIN * fused::PIECE_BYTES : (size_t)6 * fused::LUT_PAD);
 }
 
-// stage-2 LUT (3 channels) -> 4 quarter pieces of biased-byte dwords (e0+128 | e2+128 << 16 | e1+128 << 24);
-// quarter q = LUT entries [q*QSTRIDE, q*QSTRIDE + QENTRIES); every 1-KiB block pre-permuted for the
+// stage-2 LUT (3 channels) -> NBIN pieces of biased-byte dwords (e0+128 | e2+128 << 16 | e1+128 << 24); piece b = LUT
+// entries [bin_lo(b) * kStrideA, + PIECE_ENTRIES) (zero beyond the LUT); every 1-KiB block pre-permuted for the
 // 16-byte-load / ds_write_addtid_b32 transfer: block dword 4L+c holds logical dword 64c+L.
-__global__ void pack_s2_quarters_kernel(const int8_t* __restrict__ src, uint32_t* __restrict__ dst) {
+__global__ void pack_s2_pieces_kernel(const int8_t* __restrict__ src, uint32_t* __restrict__ dst) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;      // dword inside a piece
-    const int q = blockIdx.y;
-    if (p >= fused::QPIECE_BYTES / 4) return;
+    const int b = blockIdx.y;
+    if (p >= fused::PIECE_BYTES / 4) return;
     const int B = p >> 8, r = p & 255, L = r >> 2, c = r & 3;
     const int J = B * 256 + c * 64 + L;
+    const int i = fused::bin_lo(b) * kStrideA + J;
     uint32_t d = 0;
-    if (J < fused::QENTRIES) {
-        const int i = q * fused::QSTRIDE + J;
+    if (J < fused::PIECE_ENTRIES && i < LERF_LUT_ENTRIES) {
         d = (uint32_t)((int)src[i * 3 + 0] + 128) | ((uint32_t)((int)src[i * 3 + 2] + 128) << 16) |
             ((uint32_t)((int)src[i * 3 + 1] + 128) << 24);
     }
-    dst[(size_t)q * (fused::QPIECE_BYTES / 4) + p] = d;
+    dst[(size_t)b * (fused::PIECE_BYTES / 4) + p] = d;
 }
 
 __global__ void pack_bytes_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst) {
@@ -1419,8 +1400,8 @@ int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st) {
             if (!L->s2[m][r]) return LERF_EINVAL;
             int l = m * 2 + r;
             if (L->oC == 3)
-                hipLaunchKernelGGL(pack_s2_quarters_kernel, dim3((fused::QPIECE_BYTES / 4 + 255) / 256, 4), block, 0, st,
-                                   L->s2[m][r], (uint32_t*)(s2 + (size_t)l * 4 * fused::QPIECE_BYTES));
+                hipLaunchKernelGGL(pack_s2_pieces_kernel, dim3((fused::PIECE_BYTES / 4 + 255) / 256, fused::NBIN), block, 0, st,
+                                   L->s2[m][r], (uint32_t*)(s2 + (size_t)l * fused::NBIN * fused::PIECE_BYTES));
             else
                 hipLaunchKernelGGL(pack_bytes_kernel, grid, block, 0, st, L->s2[m][r],
                                    (int8_t*)(s2 + (size_t)l * fused::LUT_PAD));

@@ -29,6 +29,30 @@ __device__ __forceinline__ void slot(uint32_t cpa, const Off3& o0, const Off3& o
     const Walk<4> W0 = simplex_walk<4>(ka, basea, rb0, rc0, rd0, st_b, st_c, st_d);
     const Walk<4> W1 = simplex_walk<4>(ka, basea, rb1, rc1, rd1, st_b, st_c, st_d);
     uint32_t d0[5], d1[5];
+    if (V == 8 || V == 9) {
+        asm volatile("ds_read_b32 %0, %1" : "=v"(d0[0]) : "v"(W0.a(0)));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(d0[1]) : "v"(W0.a(1)));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(d0[2]) : "v"(W0.a(2)));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d0[3]) : "v"(W0.a(3)), "n"(Walk<4>::ALL));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d0[4]) : "v"(W0.a(4)), "n"(Walk<4>::ALL));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(d1[0]) : "v"(W1.a(0)));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(d1[1]) : "v"(W1.a(1)));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(d1[2]) : "v"(W1.a(2)));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d1[3]) : "v"(W1.a(3)), "n"(Walk<4>::ALL));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d1[4]) : "v"(W1.a(4)), "n"(Walk<4>::ALL));
+        const unsigned w0[5] = {(unsigned)kQ - W0.f0, W0.f0 - W0.f1, W0.f1 - W0.f2, W0.f2 - W0.f3, W0.f3};
+        const unsigned w1[5] = {(unsigned)kQ - W1.f0, W1.f0 - W1.f1, W1.f1 - W1.f2, W1.f2 - W1.f3, W1.f3};
+        uint32_t a = accA, bb = accB;
+        if (V == 8) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]));
+#pragma unroll
+        for (int n = 0; n < 5; ++n) { a += __umul24(w0[n], d0[n]); bb += __umul24(w0[n], d0[n] >> 24); }
+        if (V == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]));
+#pragma unroll
+        for (int n = 0; n < 5; ++n) { a += __umul24(w1[n], d1[n]); bb += __umul24(w1[n], d1[n] >> 24); }
+        accA = a; accB = bb;
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 5; ++n) d0[n] = V == 2 ? W0.a(n) : (V == 5 || V == 7) ? lds_ld32(qbase + (threadIdx.x & 63) * 4 + n * 256 + (W0.a(n) >> 30)) : W0.ld32(n);
 #pragma unroll
@@ -251,6 +275,9 @@ int main() {
     run<0, 1024>("slot as in the kernel", d, c);
     run<1, 1024>("no round / padding tests", d, c);
     run<2, 1024>("no LDS (loads -> register arithmetic)", d, c);
+    run<8, 1024>("asm gathers, waits at 5 and 0", d, c);
+    run<9, 1024>("asm gathers, one wait", d, c);
+    run<1, 1024>("no round / padding tests (again)", d, c);
     run<5, 1024>("conflict-free gathers", d, c);
     run<6, 1024>("consecutive pixel addresses", d, c);
     run<7, 1024>("both", d, c);
