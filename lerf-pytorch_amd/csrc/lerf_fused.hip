@@ -18,8 +18,8 @@
 // LDS plan (dynamic, one array; sizes for S=2 / S=4)
 //   B    feat tile u8                   (72x72x3 = 15.5 KB / 74x74x3)     all stages
 //   LUT  stage 1: one int8 LUT          83.5 KB
-//        stage 2 (LeRF-G): a QUARTER of one packed LUT = the 5 top-axis levels
-//        that pixels with (centre >> 6) == q can touch, 5*4913 dwords = 96 KB
+//        stage 2 (LeRF-G): a THIRD of one packed LUT = the 7 top-axis levels that pixels whose
+//        centre level lies in the bin can touch, 7*4913 dwords = 134 KB
 //   C    input tile u8 (78x78x3)        stage 1 only
 //   ACC  int16 partial sums             stage 1 (and stage 2 of LeRF-L)
 //   LST  pixel lists sorted by bin      stage 2 (LeRF-G), transient (under the piece, which waits in registers)
@@ -28,7 +28,7 @@
 // Stage 2 of LeRF-G keeps the whole 3-channel LUT entry in one dword, so one
 // simplex walk (index sort + 5 LDS gathers) serves all three hyper channels.
 // The full packed LUT (326 KB) cannot live in LDS; pixels are therefore binned
-// by the top two bits of their centre value (which select the slowest LUT axis
+// by the level of their centre value (which selects the slowest LUT axis
 // for every mode and rotation), and each (LUT, bin) phase processes only the
 // pixels of that bin with all 64 lanes busy.  Per-pixel accumulators stay in
 // VGPRs across phases (two packed 16-bit fields + one).
@@ -50,13 +50,22 @@ constexpr int LUT_PAD = 83584;     // padded entries per LUT in the pack (16-B m
 // Stage-2 bins: a pixel-channel goes by the top-axis level (high nibble) of its centre value, which selects the slowest
 // LUT axis for every mode and rotation.  Bin b covers the levels [bin_lo(b), bin_lo(b + 1)); its piece of a packed LUT is
 // those levels plus the one above (the simplex walk steps up once).
-constexpr int NBIN = 4;
+#ifndef LERF_NBIN
+#define LERF_NBIN 3
+#endif
+constexpr int NBIN = LERF_NBIN;
+#if LERF_NBIN == 4      // four bins of 4 levels, 5-level pieces of 96 KiB (24 phases per tile): the measured alternative
 __host__ __device__ constexpr int bin_lo(int b) { return 4 * b; }
 __device__ __forceinline__ uint32_t bin_of_level(uint32_t msb) { return msb >> 2; }
 constexpr int PIECE_LEVELS = 5;                               // levels per piece
+#else                   // three bins of 6, 5 and 5 levels, 7-level pieces of 134 KiB that fill the LDS: 18 longer phases
+__host__ __device__ constexpr int bin_lo(int b) { return b == 0 ? 0 : (b == 1 ? 6 : (b == 2 ? 11 : 16)); }
+__device__ __forceinline__ uint32_t bin_of_level(uint32_t msb) { return (msb >= 6u ? 1u : 0u) + (msb >= 11u ? 1u : 0u); }
+constexpr int PIECE_LEVELS = 7;
+#endif
 constexpr int PIECE_ENTRIES = PIECE_LEVELS * kStrideA;
 constexpr int NSLAB = (PIECE_ENTRIES * 4 + 16 * NT - 1) / (16 * NT);   // 16 bytes per thread and slab
-constexpr int PIECE_BYTES = NSLAB * 16 * NT;                  // one piece in the pack (96 KiB, 24565 dwords used)
+constexpr int PIECE_BYTES = NSLAB * 16 * NT;                  // one piece in the pack (144 KiB, 34391 dwords used)
 constexpr int PIECE_BLOCKS = (PIECE_ENTRIES * 4 + 1023) / 1024;      // 1-KiB blocks of a piece that hold data
 constexpr int PIECE_LDS = PIECE_BLOCKS * 1024;                // what a piece occupies in LDS
 
@@ -81,8 +90,8 @@ struct Dims {
     static constexpr int MAXR = (NH + NBIN * 63 + NT - 1) / NT;   // slot rounds: every bin padded to whole waves (14)
     static constexpr int OFF_LST = OFF_X;
     static constexpr int OFF_CNT = OFF_LST + MAXR * NT * 2;
-    static constexpr int OFF_TAB = OFF_CNT + NBIN * NT * 2;
-    static_assert(OFF_TAB + NW * NBIN * 4 <= OFF_X + PIECE_LDS, "binning scratch fits under the piece");
+    static constexpr int OFF_TAB = OFF_CNT + 4 * NT * 2;          // the scratch is laid out for four bins
+    static_assert(OFF_TAB + NW * 4 * 4 <= OFF_X + PIECE_LDS, "binning scratch fits under the piece");
     static constexpr int END2 = OFF_X + PIECE_LDS;
     // stage 3
     static constexpr int OFF_D = OFF_X;
@@ -874,8 +883,8 @@ sr_fused_kernel(Params P) {
                 if (LERF_SLAB_OK(7)) { LERF_ADDTID4(pr[7 < NSLAB ? 7 : 0], 49152, 49408, 49664, 49920); }
             }
             if (NSLAB > 8) {
-                LERF_SET_M0(m0a + 131072u);
-                if (LERF_SLAB_OK(8)) { LERF_ADDTID4(pr[8 < NSLAB ? 8 : 0], 0, 256, 512, 768); }
+                LERF_SET_M0(m0a + 81920u);       // slab 5's base: M0 stays below 128 KiB, the offset field supplies the rest
+                if (LERF_SLAB_OK(8)) { LERF_ADDTID4(pr[8 < NSLAB ? 8 : 0], 49152, 49408, 49664, 49920); }
             }
             static_assert(NSLAB <= 9, "three M0 windows");
 #undef LERF_SLAB_OK
