@@ -893,32 +893,36 @@ sr_fused_kernel(Params P) {
         // phases = (non-empty bin) x (6 LUTs).  The next piece is fetched into registers while the current one is being
         // used, so the L2 latency of the piece copies hides behind the lookups.
         const int wv = __builtin_amdgcn_readfirstlane(wave);
+        // per-bin scalars, refreshed when a bin's first LUT comes up (kept loop-carried on purpose: loop-invariant code
+        // motion out of an inner per-LUT loop would park every round's slot address in a register of its own)
+        int bq = 0, bq_next = 0, l = 0, bi = 0;
+        uint32_t act = 0, qbase = 0;
         for (int ph = 0; ph < nph; ++ph) {
-            const int bi = ph / 6;
-            const int l = ph - bi * 6;                       // LUT l = mode (l>>1), rotation parity (l&1)
-            const int bq = __builtin_amdgcn_readfirstlane(ctl[48 + bi]);
+            if (l == 0) {
+                // its level range, and this wave's rounds: chunk 16 k + wave inside [cs, ce) -- one scalar bit test per
+                // unrolled round
+                bq = __builtin_amdgcn_readfirstlane(ctl[48 + bi]);
+                bq_next = bi + 1 < nbins ? __builtin_amdgcn_readfirstlane(ctl[48 + bi + 1]) : 0;
+                const int cs = __builtin_amdgcn_readfirstlane(ctl[32 + bq]), ce = __builtin_amdgcn_readfirstlane(ctl[40 + bq]);
+                const int klo = cs > wv ? (cs - wv + 15) >> 4 : 0, khi = ce > wv ? (ce - wv + 15) >> 4 : 0;
+                act = wrounds & ((1u << khi) - 1u) & ~((1u << klo) - 1u);
+                // LDS address of the piece's logical entry 0 (the piece starts at top-axis level bin_lo(bq))
+                qbase = lds_addr(smem + D::OFF_X) - (uint32_t)bin_lo(bq) * (kStrideA * 4u);
+            }
             const unsigned long long t_copy = LERF_NOW();
             (void)t_copy;
             pre_store();
-            Off3 o0, o1;
+            Off3 o0, o1;                                     // LUT l = mode (l>>1), rotation parity (l&1)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 o0.o[i] = P.s2off[l][i];
                 o1.o[i] = P.s2off[l][3 + i];
             }
-            // LDS address of the piece's logical entry 0 (the piece starts at top-axis level bin_lo(bq))
-            const uint32_t qbase = lds_addr(smem + D::OFF_X) - (uint32_t)bin_lo(bq) * (kStrideA * 4u);
             const uint32_t bt_a = lds_addr(Bt);
             const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;   // axis strides, bytes
-            // this wave's rounds of the bin: chunk 16 k + wave inside [cs, ce); one scalar bit test per unrolled round
-            const int cs = __builtin_amdgcn_readfirstlane(ctl[32 + bq]), ce = __builtin_amdgcn_readfirstlane(ctl[40 + bq]);
-            const int klo = cs > wv ? (cs - wv + 15) >> 4 : 0, khi = ce > wv ? (ce - wv + 15) >> 4 : 0;
-            const uint32_t act = wrounds & ((1u << khi) - 1u) & ~((1u << klo) - 1u);
             __syncthreads();
-            if (ph + 1 < nph) {
-                const int bi2 = (ph + 1) / 6;
-                pre_load((ph + 1) - bi2 * 6, __builtin_amdgcn_readfirstlane(ctl[48 + bi2]));
-            }
+            if (l < 5) pre_load(l + 1, bq);
+            else if (bi + 1 < nbins) pre_load(0, bq_next);
             LERF_STAMP_ADD(8, t_copy);
             const unsigned long long t_look = LERF_NOW();
             (void)t_look;
@@ -967,6 +971,7 @@ sr_fused_kernel(Params P) {
             }
             __syncthreads();
             LERF_STAMP_ADD(9, t_look);
+            if (++l == 6) { l = 0; ++bi; }
         }
         LERF_STAMP(10);
         // finalise: hq = rne(clip(N/192 + 127)); entries are biased by +128 -> 12 lookups * 16 * 128 = 24576
