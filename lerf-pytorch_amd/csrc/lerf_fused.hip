@@ -103,6 +103,14 @@ struct Dims {
     static constexpr int GEO_ROWS = 320;                          // max owned output rows / cols per tile (scale <= 4.9)
     static constexpr int SZ_GEO = 2 * GEO_ROWS * (4 + 4 * S) + (GEO_ROWS + 16) * 4;   // + row-group table
     static constexpr int END3 = OFF_GEO + SZ_GEO;
+    // stage 3: queue of the outputs that sit on a rounding tie (re-evaluated in float64 after the task loop, all lanes
+    // busy, instead of one lane at a time inside it); over the dead LUT piece, behind D (and behind the late geometry of S = 4)
+#ifndef LERF_TQ_CAP
+#define LERF_TQ_CAP 2048          // (a build with a capacity of 8 exercises the full-queue fallback in the parity tests)
+#endif
+    static constexpr int TQ_CAP = LERF_TQ_CAP;
+    static constexpr int OFF_TQ = GEO_EARLY ? OFF_D + up16(NH * 4) : END3;
+    static_assert(OFF_TQ + TQ_CAP * 4 <= OFF_X + PIECE_LDS, "tie queue fits under the piece");
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int LDS_BYTES = cmax(END1, cmax(END2, END3)) + 512;  // + small control block
     static constexpr int OFF_CTL = LDS_BYTES - 512;
@@ -1066,6 +1074,7 @@ sr_fused_kernel(Params P) {
             if (lane == 0) {
                 ctl[21] = ng;
                 ctl[22] = uniform ? g0 : 0;
+                ctl[23] = 0;
             }
         }
         __syncthreads();
@@ -1074,6 +1083,8 @@ sr_fused_kernel(Params P) {
         const unsigned magic = (unsigned)((0x100000000ull + (unsigned)ndw - 1) / (unsigned)(ndw > 0 ? ndw : 1));
         const float ms255 = P.max_sigma * (1.0f / 255.0f);
         const int ntask = ngrp * ndw;
+        uint32_t* tq = reinterpret_cast<uint32_t*>(smem + D::OFF_TQ);
+        int* tq_count = ctl + 23;                               // zeroed with the group table below
         auto run_tasks = [&](auto gs_const) {
         constexpr int GS = decltype(gs_const)::value;          // rows per group, 0 = read it per group
         constexpr int GN = GS > 0 ? GS : GMAX;
@@ -1142,12 +1153,18 @@ sr_fused_kernel(Params P) {
                 }
             }
             if (tiemask != 0 && P.dis_r64 != nullptr) {
-                // rare: re-evaluate in float64 exactly as the reference does (lerf_stage3.h, tie guard)
+                // rare: the output is re-evaluated in float64 exactly as the reference does (lerf_stage3.h, tie guard)
 #pragma unroll 1
                 for (int q = 0; q < GN * 4; ++q) {
                     if (!((tiemask >> q) & 1u)) continue;
                     const int r = q >> 2, u = q & 3;
                     const int xc = min(max(b0 + u, 0), ncolc - 1);
+                    // queued for the pass behind the task loop; only a full queue is worked off on the spot
+                    const int slot = atomicAdd(tq_count, 1);
+                    if (slot < D::TQ_CAP) {
+                        tq[slot] = ((uint32_t)(il0 + r) << 16) | (uint32_t)xc;
+                        continue;
+                    }
                     const int jl = xc / CH;
                     const int c = xc - jl * CH;
                     const int lc = g_lc[jl];
@@ -1190,6 +1207,31 @@ sr_fused_kernel(Params P) {
         else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{});
         else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{});
         else run_tasks(std::integral_constant<int, 0>{});
+        // ---- tie pass: the queued outputs in float64, one per lane; each patches its byte behind the task loop's
+        //      dword stores (drained and fenced by the barrier)
+        if (P.dis_r64 != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int nq = min(*tq_count, D::TQ_CAP);
+            for (int i = tid; i < nq; i += NT) {
+                const uint32_t e = tq[i];
+                const int il = (int)(e >> 16), xc = (int)(e & 0xFFFFu);
+                const int jl = xc / CH;
+                const int c = xc - jl * CH;
+                const int lr = g_lr[il], lc = g_lc[jl];
+                uint32_t dd[SS];
+                double dx64[S], dy64[S];
+#pragma unroll
+                for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il) * S + b];
+#pragma unroll
+                for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
+#pragma unroll
+                for (int a = 0; a < S; ++a)
+#pragma unroll
+                    for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                seg0[il * rowpitch + xc] = (uint8_t)s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
+            }
+        }
     }
 #ifdef LERF_STAMPS
     __syncthreads();
