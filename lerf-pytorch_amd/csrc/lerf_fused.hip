@@ -1098,7 +1098,13 @@ sr_fused_kernel(Params P) {
             const int b0 = dw * 4 - a0;
             const int lr = g_lr[il0];
             uint32_t packed[GN];
-            unsigned tiemask = 0;                                 // bit r*4+u
+            // tie detection: the 2x2 kernels keep every output's distance from its rounded value and a running maximum
+            // (one v_max per output, the ties are looked for only when the maximum says there is one); the 4x4 kernel has
+            // no registers for that and sets a bit per output
+            constexpr bool DIST = S == 2;
+            float dist[DIST ? GN * 4 : 1];                        // [r*4+u]
+            float dmax = 0.0f;
+            unsigned tiebits = 0;                                 // bit r*4+u
 #pragma unroll
             for (int r = 0; r < GN; ++r) packed[r] = 0;
 #pragma unroll
@@ -1146,13 +1152,24 @@ sr_fused_kernel(Params P) {
                                     e[a * S + b] = s3::lin_factor(p0[a * S + b], dx, s3::dist_class_f(dx)) * ty[a * S + b];
                             }
                         const float xf = s3::finish<KIND == LERF_KIND_GAUSS, SS, true, true>(e, v);
-                        bool tie;
-                        packed[r] = s3::pack_u8_tie(xf, u, packed[r], &tie);
-                        if (tie) tiemask |= 1u << (r * 4 + u);
+                        if (DIST) {
+                            packed[r] = s3::pack_u8_dist(xf, u, packed[r], &dist[DIST ? r * 4 + u : 0]);
+                            dmax = __builtin_fmaxf(dmax, __builtin_fabsf(dist[DIST ? r * 4 + u : 0]));
+                        } else {
+                            bool tie;
+                            packed[r] = s3::pack_u8_tie(xf, u, packed[r], &tie);
+                            if (tie) tiebits |= 1u << (r * 4 + u);
+                        }
                     }
                 }
             }
-            if (tiemask != 0 && P.dis_r64 != nullptr) {
+            if ((DIST ? dmax > 0.5f - s3::kTieEps : tiebits != 0) && P.dis_r64 != nullptr) {
+                unsigned tiemask = tiebits;
+                if (DIST) {
+#pragma unroll
+                    for (int q = 0; q < GN * 4; ++q)
+                        if ((GS > 0 || (q >> 2) < gs) && __builtin_fabsf(dist[DIST ? q : 0]) > 0.5f - s3::kTieEps) tiemask |= 1u << q;
+                }
                 // rare: the output is re-evaluated in float64 exactly as the reference does (lerf_stage3.h, tie guard)
 #pragma unroll 1
                 for (int q = 0; q < GN * 4; ++q) {

@@ -174,6 +174,13 @@ __device__ __forceinline__ uint32_t pack_u8_tie(float x, int byte, uint32_t pack
     *tie = __builtin_fabsf(x - r) > 0.5f - kTieEps;
     return __builtin_amdgcn_cvt_pk_u8_f32(r, (unsigned)byte, packed);
 }
+// the same, handing back the distance from the rounded value: callers with many outputs keep a running maximum of
+// |dist| (one v_max per output) and look for the ties (|dist| > 0.5 - kTieEps) only when that maximum says there is one
+__device__ __forceinline__ uint32_t pack_u8_dist(float x, int byte, uint32_t packed, float* dist) {
+    const float r = __builtin_rintf(x);
+    *dist = x - r;
+    return __builtin_amdgcn_cvt_pk_u8_f32(r, (unsigned)byte, packed);
+}
 
 // to_u8 and the tie test sharing one v_rndne
 __device__ __forceinline__ uint32_t to_u8_tie(float x, bool* tie) {
