@@ -474,7 +474,7 @@ __device__ __forceinline__ int load_input_tile(uint8_t* Ct, const uint8_t* __res
         for (int k = 0; k < KD; ++k) {
             const int p = min(tid + k * NT, ND - 1);
             const int ry = p / RD;
-            v[k] = src[(int64_t)ry * rowdw + (p - ry * RD)];
+            v[k] = __builtin_nontemporal_load(&src[(int64_t)ry * rowdw + (p - ry * RD)]);   // read once: leave the L2 to the LUT pack
         }
         between();
 #pragma unroll
@@ -650,7 +650,7 @@ sr_fused_kernel(Params P) {
             for (int k = 0; k < KD; ++k) {
                 const int p = min(tid + k * NT, ND - 1);
                 const int ry = p / RD;
-                v[k] = src[(int64_t)ry * rowdw + (p - ry * RD)];
+                v[k] = __builtin_nontemporal_load(&src[(int64_t)ry * rowdw + (p - ry * RD)]);
             }
             if (D::GEO_EARLY && !EMIT) geo_search();
 #pragma unroll
@@ -1046,10 +1046,13 @@ sr_fused_kernel(Params P) {
         constexpr int GMAX = S == 2 ? 5 : 3;                      // rows per group (larger runs are split)
         int* g_grp = reinterpret_cast<int*>(g_dc + D::GEO_ROWS * S);
         const int ncolc = ncol * CH;
-        const int ndw = (ncolc + 6) >> 2;
         const int64_t rowpitch = (int64_t)P.oW * CH;
         uint8_t* seg0 = outp + ((int64_t)i0 * P.oW + j0) * CH;
         const bool rows_align = (rowpitch & 3) == 0;              // dword columns line up across the rows of a group
+        // dword columns per row: when every row of the block starts on a 4-byte boundary (a0 == 0 below) the block needs
+        // no slack column, and a 384-byte tile row is exactly 96 dwords = whole 128-byte lines per wave store
+        const bool seg_aligned = rows_align && (reinterpret_cast<uintptr_t>(seg0) & 3u) == 0;
+        const int ndw = seg_aligned ? (ncolc + 3) >> 2 : (ncolc + 6) >> 2;
         if (wave == 0) {
             int ng = 0;
             for (int base = 0; base < nrow; base += 64) {
@@ -1322,7 +1325,7 @@ s1_kernel(Params P) {
         const int rowdw = (W * CH) >> 2;
         for (int i = tid; i < rows * RD; i += NT) {
             const int r = i / RD;
-            dst[(int64_t)r * rowdw + (i - r * RD)] = reinterpret_cast<const uint32_t*>(Ft)[i];
+            __builtin_nontemporal_store(reinterpret_cast<const uint32_t*>(Ft)[i], &dst[(int64_t)r * rowdw + (i - r * RD)]);
         }
     } else {
         for (int i = tid; i < rows * cols3; i += NT) {
