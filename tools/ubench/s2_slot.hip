@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, unsigned long long* cyc
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     // random LDS contents: feat tile at 0 (16 KB), piece at 16 KB (96 KB)
-    for (int i = tid; i < (16384 + QPIECE_BYTES) / 4; i += NTH) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 3) * 40503u;
+    for (int i = tid; i < (16384 + PIECE_LDS) / 4; i += NTH) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 3) * 40503u;
     __syncthreads();
     const uint32_t bt_a0 = lds_addr(smem), qbase = lds_addr(smem + 16384);
     const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;
@@ -123,7 +123,7 @@ template <int NTH>
 __global__ void __launch_bounds__(1024) kp(uint32_t* out, unsigned long long* cyc, int iters, int rsq, int req, Off3 o0, Off3 o1) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < (16384 + QPIECE_BYTES) / 4; i += NTH) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 3) * 40503u;
+    for (int i = tid; i < (16384 + PIECE_LDS) / 4; i += NTH) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 3) * 40503u;
     __syncthreads();
     const uint32_t bt_a0 = lds_addr(smem), qbase = lds_addr(smem + 16384);
     const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;
@@ -179,7 +179,7 @@ template <int NTH>
 __global__ void __launch_bounds__(1024) kd(uint32_t* out, unsigned long long* cyc, int iters, int rsq, int req, Off3 o0, Off3 o1) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < (16384 + QPIECE_BYTES) / 4; i += NTH) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 3) * 40503u;
+    for (int i = tid; i < (16384 + PIECE_LDS) / 4; i += NTH) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 3) * 40503u;
     __syncthreads();
     const uint32_t bt_a0 = lds_addr(smem), qbase = lds_addr(smem + 16384);
     const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(1024) kd(uint32_t* out, unsigned long long* cy
 template <int V, int NTH>
 void run(const char* name, uint32_t* d, unsigned long long* c) {
     const int iters = 200, blocks = 256;
-    const int lds = 16384 + QPIECE_BYTES + 32768;      // one workgroup per CU
+    const int lds = 16384 + PIECE_LDS + 32768;      // one workgroup per CU
     Off3 o0 = tile_offsets<216>('s', 0), o1 = tile_offsets<216>('s', 2);
     void (*kern)(uint32_t*, unsigned long long*, int, int, int, Off3, Off3) = k<V >= 3 ? 0 : V, NTH>;
     if (V == 3) kern = kp<NTH>;
