@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(1024) kd(uint32_t* out, unsigned long long* cy
 template <int V, int NTH>
 void run(const char* name, uint32_t* d, unsigned long long* c) {
     const int iters = 200, blocks = 256;
-    const int lds = 16384 + PIECE_LDS + 32768;      // one workgroup per CU
+    const int lds = 16384 + PIECE_LDS + 4096;       // one workgroup per CU
     Off3 o0 = tile_offsets<216>('s', 0), o1 = tile_offsets<216>('s', 2);
     void (*kern)(uint32_t*, unsigned long long*, int, int, int, Off3, Off3) = k<V >= 3 ? 0 : V, NTH>;
     if (V == 3) kern = kp<NTH>;
