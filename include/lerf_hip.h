@@ -233,6 +233,11 @@ int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_war
  * input, the LUT pack and the output touches HBM.  Configurations outside the tile-fused kernel (C != 3, modes !=
  * "sct", S not in {2,4}, down-sampling) need the workspace and run the three direct kernels through it. */
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n);
+/* Test hook, no counterpart in the reference: the tile-fused kernel queues the outputs that sit within 1.5e-4 of a
+ * rounding tie (re-evaluated in float64, the reference's own arithmetic: resize_right2d_numpy.py:150-221) in a per-tile
+ * queue of 2048 entries and evaluates them on the spot once the queue is full.  Lowering the capacity (0..2048; < 0 =
+ * default) drives the parity tests through that fallback.  Process-wide, affects later launches; returns the old value. */
+int lerf_debug_set_tie_queue_cap(int cap);
 int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
                      const lerf_luts_t* luts, const lerf_sr_geo_t* geo,
                      int kind, double max_sigma,

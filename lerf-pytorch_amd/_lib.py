@@ -40,7 +40,7 @@ EXPORTS = [
     "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables", "lerf_sr_axis_tables_f32",
     "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
     "lerf_lut_stages_u8",
-    "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_u8",
+    "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_debug_set_tie_queue_cap", "lerf_sr_fused_u8",
     "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed",
     "lerf_metric_y_sse_u8", "lerf_metric_ssim_y_u8", "lerf_metric_masked_sse_u8",
     "lerf_swf2lut_interp_f32", "lerf_swf2lut_interp_bwd_f32", "lerf_resize_bwd_f32",
@@ -124,6 +124,7 @@ def lib():
     L.lerf_unpack_stages.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lerf_warp_packed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo), C.c_int, C.c_double,
                                    C.POINTER(Plane), C.c_void_p]
+    L.lerf_debug_set_tie_queue_cap.argtypes = [C.c_int]
     L.lerf_sr_fused_workspace_bytes.restype = C.c_size_t
     L.lerf_sr_fused_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.lerf_sr_fused_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts),

@@ -319,6 +319,8 @@ int lerf_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut,
     return rc != LERF_OK ? rc : check_launch();
 }
 
+int lerf_debug_set_tie_queue_cap(int cap) { return fused_set_tie_queue_cap(cap); }
+
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {
     // Two uses, the larger one sizes it: (a) the two-launch tile-fused path parks the stage-1 output of the batch there
     // (n frames, frame stride rounded up to 16 bytes) between s1_kernel and the stage-2/3 launch; (b) the general

@@ -105,10 +105,7 @@ struct Dims {
     static constexpr int END3 = OFF_GEO + SZ_GEO;
     // stage 3: queue of the outputs that sit on a rounding tie (re-evaluated in float64 after the task loop, all lanes
     // busy, instead of one lane at a time inside it); over the dead LUT piece, behind D (and behind the late geometry of S = 4)
-#ifndef LERF_TQ_CAP
-#define LERF_TQ_CAP 2048          // (a build with a capacity of 8 exercises the full-queue fallback in the parity tests)
-#endif
-    static constexpr int TQ_CAP = LERF_TQ_CAP;
+    static constexpr int TQ_CAP = 2048;                           // (lerf_debug_set_tie_queue_cap lowers the part in use: tests)
     static constexpr int OFF_TQ = GEO_EARLY ? OFF_D + up16(NH * 4) : END3;
     static_assert(OFF_TQ + TQ_CAP * 4 <= OFF_X + PIECE_LDS, "tie queue fits under the piece");
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -128,6 +125,7 @@ struct Params {
     uint32_t* emit; int64_t emit_sn;   // EMIT kernels: packed stage outputs, frame stride in dwords
     uint8_t* feat; int64_t feat_sn;    // two-launch path: stage-1 output [N][H][W][3] between s1_kernel and the FROM_FEAT kernel
     unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
+    int tq_cap;                      // stage-3 tie queue entries in use (<= Dims::TQ_CAP; lerf_debug_set_tie_queue_cap)
 };
 
 #ifdef LERF_STAMPS
@@ -1181,7 +1179,7 @@ sr_fused_kernel(Params P) {
                     const int xc = min(max(b0 + u, 0), ncolc - 1);
                     // queued for the pass behind the task loop; only a full queue is worked off on the spot
                     const int slot = atomicAdd(tq_count, 1);
-                    if (slot < D::TQ_CAP) {
+                    if (slot < P.tq_cap) {
                         tq[slot] = ((uint32_t)(il0 + r) << 16) | (uint32_t)xc;
                         continue;
                     }
@@ -1232,7 +1230,7 @@ sr_fused_kernel(Params P) {
         if (P.dis_r64 != nullptr) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const int nq = min(*tq_count, D::TQ_CAP);
+            const int nq = min(*tq_count, P.tq_cap);
             for (int i = tid; i < nq; i += NT) {
                 const uint32_t e = tq[i];
                 const int il = (int)(e >> 16), xc = (int)(e & 0xFFFFu);
@@ -1358,10 +1356,18 @@ bool fused_supported(const FusedArgs& a) {
     return true;
 }
 
+static int g_tie_queue_cap = fused::Dims<2>::TQ_CAP;
+int fused_set_tie_queue_cap(int cap) {
+    const int old = g_tie_queue_cap;
+    g_tie_queue_cap = cap < 0 ? fused::Dims<2>::TQ_CAP : (cap > fused::Dims<2>::TQ_CAP ? fused::Dims<2>::TQ_CAP : cap);
+    return old;
+}
+
 template <int S, int KIND, bool EMIT = false>
 static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     using D = fused::Dims<S>;
     fused::Params P;
+    P.tq_cap = g_tie_queue_cap;
     P.img = a.img; P.in_sn = a.in_sn; P.out = a.out; P.out_sn = a.out_sn;
     P.H = a.H; P.W = a.W; P.oH = a.oH; P.oW = a.oW;
     P.tiles_y = (a.H + fused::TH - 1) / fused::TH;

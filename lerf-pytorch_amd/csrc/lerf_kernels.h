@@ -68,6 +68,7 @@ bool fused_supported(const FusedArgs& a);
 size_t fused_lutpack_bytes(int oC);
 int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st);
 int launch_sr_fused(const FusedArgs& a, hipStream_t st);
+int fused_set_tie_queue_cap(int cap);       // returns the previous capacity; < 0 restores the default
 bool fused_stages_supported(const FusedArgs& a);
 int launch_stages_fused(const FusedArgs& a, hipStream_t st);
 // lerf_transfer.hip

@@ -112,6 +112,25 @@ def test_config2_support4_1080p_bytes_equal_port(torch, co, eng_g4, luts_g, kind
     _bytes_equal(out, ref, "LeRF-G S=4 1080p x2 %s" % kind)
 
 
+@pytest.mark.parametrize("cap", [0, 8])
+def test_tie_queue_full_falls_back_in_loop(torch, co, eng_g, eng_g4, eng_l, luts_g, luts_l, cap):
+    """Stage 3 queues the outputs that sit on a rounding tie (about 15 per 64x64 tile) and re-evaluates them in float64
+    behind the task loop; with the queue capacity lowered to 0 / 8 entries nearly all of them take the in-loop fallback
+    instead.  Both routes must give the reference's bytes (2x2 and 4x4 Gaussian, linear)."""
+    from lerf_pytorch_amd import _lib
+    lib = _lib.lib()
+    img = _frame("noise", 540, 960, 77)
+    old = lib.lerf_debug_set_tie_queue_cap(cap)
+    try:
+        assert old == 2048
+        _bytes_equal(eng_g.sr(img, 2), co.sr_u8(img, luts_g, 2, 2), "LeRF-G S=2, tie queue of %d" % cap)
+        _bytes_equal(eng_g4.sr(img, 2), co.sr_u8(img, luts_g, 2, 2, S=4), "LeRF-G S=4, tie queue of %d" % cap)
+        _bytes_equal(eng_l.sr(img, (1.5, 2.0)), co.sr_u8(img, luts_l, 1.5, 2.0, linear=True), "LeRF-L, tie queue of %d" % cap)
+    finally:
+        assert lib.lerf_debug_set_tie_queue_cap(-1) == cap
+    assert lib.lerf_debug_set_tie_queue_cap(-1) == 2048
+
+
 def test_config5_4k_to_8k_properties(torch, co, eng_g, luts_g):
     """2160x3840 -> 4320x7680: (a) the frame equals the float64 port byte for byte; (b) fused == unfused; (c) any
     interior crop with a 7-px halo reproduces the frame's bytes; (d) 8 strips with 7-row halos, ranks emulated one
