@@ -310,6 +310,19 @@ __host__ __device__ constexpr int min_tile_offset(char mode, int rot0, int nrot,
     }
     return m;
 }
+// the eight neighbours of the 3x3 block around a pixel (byte offsets in a tile of pitch SP) and the index of an offset among them
+template <int SP>
+__host__ __device__ constexpr int block3_offset(int i) {
+    const int dy = i < 3 ? -1 : (i < 5 ? 0 : 1);
+    const int dx = i < 3 ? i - 1 : (i < 5 ? (i == 3 ? -1 : 1) : i - 6);
+    return dy * SP + dx * CH;
+}
+template <int SP>
+__host__ __device__ constexpr int block3_index(int off) {
+    for (int i = 0; i < 8; ++i)
+        if (block3_offset<SP>(i) == off) return i;
+    return 0;
+}
 template <int SP, char MODE, int ROT, int MINO>
 __device__ __forceinline__ void load_rotation(uint32_t base, uint32_t& rb, uint32_t& rc, uint32_t& rd) {
     constexpr Off3 o = tile_offsets<SP>(MODE, ROT);
@@ -328,6 +341,24 @@ __device__ __forceinline__ int byte_lookups(uint32_t lut_a, uint32_t center) {
     const uint32_t base = center + (uint32_t)MINO;
     uint32_t ra = lds_pixel_hi_off<-MINO>(base);
     uint32_t rb[4], rc[4], rd[4];
+    if constexpr (MODE == 's' && NROT == 4 && ROT0 == 0 && RSTEP == 1) {
+        // the four rotations of the 2x2 pattern cover the 3x3 block around the centre: its four edge neighbours are used
+        // by two rotations each, so 8 reads serve the 12 operands
+        uint32_t nb[8];
+        nb[0] = lds_pixel_hi_off<block3_offset<SP>(0) - MINO>(base); nb[1] = lds_pixel_hi_off<block3_offset<SP>(1) - MINO>(base);
+        nb[2] = lds_pixel_hi_off<block3_offset<SP>(2) - MINO>(base); nb[3] = lds_pixel_hi_off<block3_offset<SP>(3) - MINO>(base);
+        nb[4] = lds_pixel_hi_off<block3_offset<SP>(4) - MINO>(base); nb[5] = lds_pixel_hi_off<block3_offset<SP>(5) - MINO>(base);
+        nb[6] = lds_pixel_hi_off<block3_offset<SP>(6) - MINO>(base); nb[7] = lds_pixel_hi_off<block3_offset<SP>(7) - MINO>(base);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra), "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3]), "+v"(nb[4]), "+v"(nb[5]), "+v"(nb[6]), "+v"(nb[7]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const Off3 o = tile_offsets<SP>('s', r);
+            rb[r] = nb[block3_index<SP>(o.o[0])];
+            rc[r] = nb[block3_index<SP>(o.o[1])];
+            rd[r] = nb[block3_index<SP>(o.o[2])];
+        }
+    } else {
     load_rotation<SP, MODE, ROT0, MINO>(base, rb[0], rc[0], rd[0]);
     load_rotation<SP, MODE, ROT0 + RSTEP, MINO>(base, rb[1], rc[1], rd[1]);
     if constexpr (NROT == 4) {
@@ -338,6 +369,7 @@ __device__ __forceinline__ int byte_lookups(uint32_t lut_a, uint32_t center) {
                        "+v"(rc[2]), "+v"(rd[2]), "+v"(rb[3]), "+v"(rc[3]), "+v"(rd[3]));
     } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra), "+v"(rb[0]), "+v"(rc[0]), "+v"(rd[0]), "+v"(rb[1]), "+v"(rc[1]), "+v"(rd[1]));
+    }
     }
     // stage B: walks
     const unsigned sa = kStrideA, sb = kStrideB, sc = kStrideC, sd = kStrideD;
