@@ -85,12 +85,11 @@ struct Dims {
     static constexpr int OFF_C = OFF_LUT + LUT_PAD;
     static constexpr int OFF_ACC = OFF_C + up16(NI);
     static constexpr int END1 = OFF_ACC + up16(NF * 2);
-    // stage 2, LeRF-G: one piece.  The position lists, the per-thread list cursors and the wave x bin table only live
-    // between the binning and the first piece store (the first piece waits in registers) and overlay the piece.
+    // stage 2, LeRF-G: one piece.  The position lists and the wave x bin count table only live between the binning and the
+    // first piece store (the first piece waits in registers) and overlay the piece.
     static constexpr int MAXR = (NH + NBIN * 63 + NT - 1) / NT;   // slot rounds: every bin padded to whole waves (14)
     static constexpr int OFF_LST = OFF_X;
-    static constexpr int OFF_CNT = OFF_LST + MAXR * NT * 2;
-    static constexpr int OFF_TAB = OFF_CNT + 4 * NT * 2;          // the scratch is laid out for four bins
+    static constexpr int OFF_TAB = OFF_LST + MAXR * NT * 2;       // [wave][4 bins] counts
     static_assert(OFF_TAB + NW * 4 * 4 <= OFF_X + PIECE_LDS, "binning scratch fits under the piece");
     static constexpr int END2 = OFF_X + PIECE_LDS;
     // stage 3
@@ -755,11 +754,10 @@ sr_fused_kernel(Params P) {
         // ---- stage 2, LeRF-G: packed 3-channel LUT pieces, pixels binned by the top-axis level of their centre
         constexpr int MAXR = D::MAXR;
         uint16_t* lst = reinterpret_cast<uint16_t*>(smem + D::OFF_LST);
-        uint16_t* cnt = reinterpret_cast<uint16_t*>(smem + D::OFF_CNT);      // [bin][thread] list cursors
-        int* tab = reinterpret_cast<int*>(smem + D::OFF_TAB);                // [wave][bin] counts, then list bases
+        int* tab = reinterpret_cast<int*>(smem + D::OFF_TAB);                // [wave][bin] counts
         // Counting sort of the hyper-region positions by bin, every bin padded to whole waves: list entry i belongs to
-        // slot round i / NT of thread i % NT, so a 64-entry chunk (one wave in one round) never mixes bins.
-        // ctl[32 + b] first chunk of bin b, ctl[40 + b] one past its last, ctl[48 + i] i-th non-empty bin, ctl[56] their number.
+        // slot round i / NT of thread i % NT, so a 64-entry chunk (one wave in one round) never mixes bins.  One barrier:
+        // per-thread histograms -> wave scans -> the 16 x 4 wave totals through LDS -> every wave derives its own bases.
         // Positions of the hyper region that lie outside the frame (tiles on the right / bottom edge, the halo ring of edge
         // tiles) are not looked up at all: stage 3 reads them as replicas of the clamped position (edge-padded hyper maps,
         // zero image), which fill_outside() below copies once the in-frame values exist.  A 28-row strip tile or the
@@ -802,10 +800,14 @@ sr_fused_kernel(Params P) {
             t[0] = (int)(ia & 0xFFFFu); t[1] = (int)(ia >> 16); t[2] = (int)(ib & 0xFFFFu); t[3] = (int)(ib >> 16);
         }
         __syncthreads();
-        if (wave == 0) {
-            // lane = w * 4 + b
+        // Every wave turns the 16 x 4 wave counts into what it needs itself (lane = w * 4 + b), in registers: the list base
+        // of each of its own bins, and -- the same in all waves -- each bin's first chunk and one past its last (a byte
+        // each) and the set of non-empty bins.  No second barrier, no table to read back.
+        uint32_t ne_bins, cs_pack, ce_pack;          // wave-uniform
+        uint32_t cur01, cur23;                       // this thread's list cursors, two 16-bit fields per register
+        {
             const int bb = lane & 3, w = lane >> 2;
-            const int c = tab[w * 4 + bb];
+            const int c = tab[lane];
             int incl = c;                                        // scan over the waves of a bin: lanes 4 apart
 #pragma unroll
             for (int d = 4; d < 64; d <<= 1) {
@@ -821,16 +823,20 @@ sr_fused_kernel(Params P) {
                 if (bb >= d) start += up;
             }
             start -= padded;
-            tab[w * 4 + bb] = start + incl - c;                  // list base of (wave, bin)
-            const unsigned long long ne = __ballot(w == 0 && total > 0);
-            if (w == 0) {
-                ctl[32 + bb] = start >> 6;
-                ctl[40 + bb] = (start + padded) >> 6;
-                if (total > 0) ctl[48 + __popcll(ne & ((1ull << bb) - 1ull))] = bb;
-                if (bb == 0) ctl[56] = __popcll(ne);
-            }
+            const int base = start + incl - c;                   // list base of (wave w, bin bb)
+            const int wl = __builtin_amdgcn_readfirstlane(wave) * 4;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(base, wl), b1 = (uint32_t)__builtin_amdgcn_readlane(base, wl + 1),
+                           b2 = (uint32_t)__builtin_amdgcn_readlane(base, wl + 2), b3 = (uint32_t)__builtin_amdgcn_readlane(base, wl + 3);
+            const uint32_t ea = ia - xa, eb = ib - xb;           // counts of the lanes below
+            cur01 = ((b0 + (ea & 0xFFFFu)) & 0xFFFFu) | ((b1 + (ea >> 16)) << 16);
+            cur23 = ((b2 + (eb & 0xFFFFu)) & 0xFFFFu) | ((b3 + (eb >> 16)) << 16);
+            const int sc = start >> 6, ec = (start + padded) >> 6;           // chunks: < 256
+            cs_pack = (uint32_t)__builtin_amdgcn_readlane(sc, 0) | ((uint32_t)__builtin_amdgcn_readlane(sc, 1) << 8) |
+                      ((uint32_t)__builtin_amdgcn_readlane(sc, 2) << 16) | ((uint32_t)__builtin_amdgcn_readlane(sc, 3) << 24);
+            ce_pack = (uint32_t)__builtin_amdgcn_readlane(ec, 0) | ((uint32_t)__builtin_amdgcn_readlane(ec, 1) << 8) |
+                      ((uint32_t)__builtin_amdgcn_readlane(ec, 2) << 16) | ((uint32_t)__builtin_amdgcn_readlane(ec, 3) << 24);
+            ne_bins = (uint32_t)(__ballot(total > 0) & 0xFull);
         }
-        __syncthreads();
         // The next piece rides in registers behind the lookups of the current one: NSLAB x 16 bytes per thread.
         uint4 pr[NSLAB];
 #pragma unroll
@@ -841,25 +847,20 @@ sr_fused_kernel(Params P) {
 #pragma unroll
             for (int i = 0; i < NSLAB; ++i) pr[i] = s_[i * NT];
         };
-        const int nbins = __builtin_amdgcn_readfirstlane(ctl[56]);
+        const int nbins = __builtin_popcount(ne_bins);
         const int nph = nbins * 6;
-        if (nph > 0) pre_load(0, __builtin_amdgcn_readfirstlane(ctl[48]));      // in flight during the scatter and the slot set-up
+        if (nph > 0) pre_load(0, __builtin_ctz(ne_bins));      // in flight during the scatter and the slot set-up
         {
-            // list cursors of this thread: base of (wave, bin) + the counts of the lanes below
-            const int* t = tab + wave * 4;
-            const uint32_t ea = ia - xa, eb = ib - xb;
-            cnt[0 * NT + tid] = (uint16_t)(t[0] + (ea & 0xFFFFu));
-            cnt[1 * NT + tid] = (uint16_t)(t[1] + (ea >> 16));
-            cnt[2 * NT + tid] = (uint16_t)(t[2] + (eb & 0xFFFFu));
-            cnt[3 * NT + tid] = (uint16_t)(t[3] + (eb >> 16));
+            // scatter: a position's list entry = the thread's cursor of its bin, which then moves on (registers only)
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
                 const uint32_t q = k < 8 ? (qlo >> (4 * k)) & 0xFu : (qhi >> (4 * (k - 8))) & 0xFu;
                 if (q < NBIN) {
-                    uint16_t* c = cnt + q * NT + tid;
-                    const uint16_t v = *c;
-                    *c = (uint16_t)(v + 1);
+                    const uint32_t pair = q < 2 ? cur01 : cur23;
+                    const uint32_t v = (q & 1u) ? pair >> 16 : pair & 0xFFFFu;
                     lst[v] = (uint16_t)(tid * KH + k);
+                    const uint32_t inc = (q & 1u) ? 0x10000u : 1u;
+                    if (q < 2) cur01 += inc; else cur23 += inc;
                 }
             }
         }
@@ -934,14 +935,16 @@ sr_fused_kernel(Params P) {
         // per-bin scalars, refreshed when a bin's first LUT comes up (kept loop-carried on purpose: loop-invariant code
         // motion out of an inner per-LUT loop would park every round's slot address in a register of its own)
         int bq = 0, bq_next = 0, l = 0, bi = 0;
+        uint32_t ne_left = ne_bins;               // non-empty bins not yet started
         uint32_t act = 0, qbase = 0;
         for (int ph = 0; ph < nph; ++ph) {
             if (l == 0) {
                 // its level range, and this wave's rounds: chunk 16 k + wave inside [cs, ce) -- one scalar bit test per
                 // unrolled round
-                bq = __builtin_amdgcn_readfirstlane(ctl[48 + bi]);
-                bq_next = bi + 1 < nbins ? __builtin_amdgcn_readfirstlane(ctl[48 + bi + 1]) : 0;
-                const int cs = __builtin_amdgcn_readfirstlane(ctl[32 + bq]), ce = __builtin_amdgcn_readfirstlane(ctl[40 + bq]);
+                bq = __builtin_ctz(ne_left);
+                ne_left &= ne_left - 1u;
+                bq_next = ne_left != 0u ? __builtin_ctz(ne_left) : 0;
+                const int cs = (int)((cs_pack >> (8 * bq)) & 0xFFu), ce = (int)((ce_pack >> (8 * bq)) & 0xFFu);
                 const int klo = cs > wv ? (cs - wv + 15) >> 4 : 0, khi = ce > wv ? (ce - wv + 15) >> 4 : 0;
                 act = wrounds & ((1u << khi) - 1u) & ~((1u << klo) - 1u);
                 // LDS address of the piece's logical entry 0 (the piece starts at top-axis level bin_lo(bq))
