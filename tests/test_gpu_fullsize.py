@@ -164,6 +164,19 @@ def test_config5_batch_of_frames(torch, eng_g):
         assert torch.equal(out[b], eng_g.sr(x[b], 2))
 
 
+@pytest.mark.parametrize("n,hw", [(3, (1080, 1920)), (7, (600, 1100)), (19, (300, 700)), (4, (300, 700))])
+def test_batches_through_the_xcd_tile_order(torch, co, eng_g, luts_g, n, hw):
+    """Launches of >= 1024 workgroups hand every XCD a contiguous eighth of the (frame, tile) sequence (xcd_order); the
+    grid sizes here (3 x 510 = 1530, 7 x 180 = 1260, 19 x 55 = 1045: remainders 2, 4, 5 modulo 8; 4 x 55 stays on the linear
+    order below the threshold) exercise its remainder handling: a batch equals its frames one by one, and the C port on one of them."""
+    rng = np.random.default_rng(63 + n)
+    x = torch.from_numpy(rng.integers(0, 256, (n,) + hw + (3,), dtype=np.uint8)).cuda()
+    out = eng_g.sr(x, 2)
+    for b in range(n):
+        assert torch.equal(out[b], eng_g.sr(x[b], 2)), "frame %d of %d" % (b, n)
+    _bytes_equal(out[n - 1].cpu().numpy(), co.sr_u8(x[n - 1].cpu().numpy(), luts_g, 2, 2), "last frame of a batch of %d" % n)
+
+
 # ------------------------------------------------------------------------------------------------ float32 outputs
 @pytest.mark.parametrize("model,scale", [("lerf-g", (2.0, 2.0)), ("lerf-g", (3.0, 3.0)), ("lerf-l", (1.5, 2.0))])
 def test_float32_outputs_abs_error_sr(torch, co, eng_g, eng_l, luts_g, luts_l, model, scale):
