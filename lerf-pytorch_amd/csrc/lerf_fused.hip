@@ -733,18 +733,42 @@ sr_fused_kernel(Params P) {
         uint8_t* hq8 = smem + D::OFF_C;                   // input tile is dead: reuse for the u8 hyper values
         const uint8_t* s2 = P.pack + 3 * LUT_PAD;
         const int div2 = kQ * 12;
-#define LERF_L2(IDX, MODE, PAR, PH)                                                                        \
-        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, s2 + (IDX) * LUT_PAD, tid);                          \
-        __syncthreads();                                                                                   \
+        // every LUT but the first rides in registers behind the lookups of the previous one (as in stage 1), so that only the
+        // LDS store of a LUT, not its L2 round trip, stands between two phases
+        constexpr int L2N = (LERF_LUT_ENTRIES + 15) / 16, L2TAIL = L2N - 5 * NT;
+        static_assert(L2TAIL > 0 && L2TAIL <= NT, "byte LUT = 5 full uint4 rounds + a tail");
+        uint4 m0, m1, m2, m3, m4, m5 = make_uint4(0, 0, 0, 0);
+#define LERF_L2_LOAD(IDX)                                                                          \
+        do {                                                                                       \
+            const uint4* s_ = reinterpret_cast<const uint4*>(s2 + (IDX) * LUT_PAD);                \
+            m0 = s_[tid]; m1 = s_[tid + NT]; m2 = s_[tid + 2 * NT]; m3 = s_[tid + 3 * NT]; m4 = s_[tid + 4 * NT]; \
+            if (tid < L2TAIL) m5 = s_[tid + 5 * NT];                                               \
+        } while (0)
+#define LERF_L2_STORE()                                                                            \
+        do {                                                                                       \
+            uint4* d_ = reinterpret_cast<uint4*>(smem + D::OFF_LUT);                               \
+            d_[tid] = m0; d_[tid + NT] = m1; d_[tid + 2 * NT] = m2; d_[tid + 3 * NT] = m3; d_[tid + 4 * NT] = m4; \
+            if (tid < L2TAIL) d_[tid + 5 * NT] = m5;                                               \
+        } while (0)
+#define LERF_L2(NEXT, MODE, PAR, PH)                                                                       \
+        if ((NEXT) < 6) LERF_L2_LOAD(NEXT);                                                                \
         byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, Hc, Wc, div2, 127, tid); \
+        __syncthreads();                                                                                   \
+        if ((NEXT) < 6) {                                                                                  \
+            LERF_L2_STORE();                                                                               \
+            __syncthreads();                                                                               \
+        }
+        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, s2 + 0 * LUT_PAD, tid);
         __syncthreads();
-        LERF_L2(0, 's', 0, 0)
-        LERF_L2(1, 's', 1, 1)
-        LERF_L2(2, 'c', 0, 1)
-        LERF_L2(3, 'c', 1, 1)
-        LERF_L2(4, 't', 0, 1)
-        LERF_L2(5, 't', 1, 2)
+        LERF_L2(1, 's', 0, 0)
+        LERF_L2(2, 's', 1, 1)
+        LERF_L2(3, 'c', 0, 1)
+        LERF_L2(4, 'c', 1, 1)
+        LERF_L2(5, 't', 0, 1)
+        LERF_L2(6, 't', 1, 2)
 #undef LERF_L2
+#undef LERF_L2_LOAD
+#undef LERF_L2_STORE
         // pack (alpha_q, 0, 0, feat-or-0) dwords for stage 3
         uint32_t tmp[(D::NH + NT - 1) / NT];
 #pragma unroll
