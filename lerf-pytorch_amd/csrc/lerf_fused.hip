@@ -1,8 +1,8 @@
 // Tile-fused uint8 SR path for MI355X (gfx950): stage-1 LUTs -> stage-2 LUTs -> spatially-varying resampling per
-// 64x64 LR tile.  With a caller workspace (the normal case) it is TWO launches: s1_kernel computes stage 1 once per
-// pixel and parks its uint8 output in the workspace, sr_fused_kernel<.., FROM_FEAT> runs stage 2, the finalisation and
-// stage 3 from it -- the hyper-parameters never leave the CU.  Without a workspace ONE launch does everything and
-// recomputes stage 1 on each tile's halo.
+// 64x64 LR tile (tiles handed to the XCDs in contiguous eighths: xcd_order).  With a caller workspace (the normal case)
+// it is TWO launches: s1_kernel computes stage 1 once per pixel and parks its uint8 output in the workspace,
+// sr_fused_kernel<.., FROM_FEAT> runs stage 2, the finalisation and stage 3 from it -- the hyper-parameters never leave
+// the CU.  Without a workspace ONE launch does everything and recomputes stage 1 on each tile's halo.
 //
 // Reference path being replaced: eltr._worker, resample/eval_lut_sr.py:541-665
 // (FourSimplexInterpFaster :24-470 x 24 passes, SteeringGaussianResize2dNumpy /
@@ -23,7 +23,9 @@
 //   C    input tile u8 (78x78x3)        stage 1 only
 //   ACC  int16 partial sums             stage 1 (and stage 2 of LeRF-L)
 //   LST  pixel lists sorted by bin      stage 2 (LeRF-G), transient (under the piece, which waits in registers)
-//   D    (hq0,hq1,hq2,feat) dwords      stage 3, overlays LUT
+//   D    (hq0,hq1,hq2,feat) dwords      stage 3, overlays LUT (52 KB / 55 KB)
+//   GEO  tile geometry tables           stage 3 (9 KB; staged at kernel start for S=2)
+//   TQ   rounding-tie queue             stage 3 (8 KB, behind D)
 //
 // Stage 2 of LeRF-G keeps the whole 3-channel LUT entry in one dword, so one
 // simplex walk (index sort + 5 LDS gathers) serves all three hyper channels.
