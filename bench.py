@@ -182,8 +182,8 @@ def spawn_ranks(n):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, choices=[1, 2, 3, 4, 5], default=2, help="BASELINE.json configs[] (1-based)")
     ap.add_argument("--frames", type=int, default=8, help="frames per step (per GPU in frames mode; total batch in config 5)")
     ap.add_argument("--input", choices=["noise", "natural"], default=None)
