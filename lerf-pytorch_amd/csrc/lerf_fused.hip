@@ -845,7 +845,7 @@ sr_fused_kernel(Params P) {
         uint32_t ne_bins, cs_pack, ce_pack;          // wave-uniform
         uint32_t cur01, cur23;                       // this thread's list cursors, two 16-bit fields per register
         {
-            const int bb = lane & 3, w = lane >> 2;
+            const int bb = lane & 3;                             // lane = w * 4 + bb
             const int c = tab[lane];
             int incl = c;                                        // scan over the waves of a bin: lanes 4 apart
 #pragma unroll

@@ -1,7 +1,7 @@
 #!/bin/bash
 # device assembly of the fused kernels + register summary: tools/asm.sh [out.s]
 out=${1:-/tmp/fused.s}
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I/root/repo/include -S --cuda-device-only -o $out /root/repo/lerf-pytorch_amd/csrc/lerf_fused.hip $EXTRA 2>&1 | grep -v "warning: argument"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -I/root/repo/include -S --cuda-device-only -o $out /root/repo/lerf-pytorch_amd/csrc/lerf_fused.hip $EXTRA 2>&1 | grep -v "warning: argument"
 python3 - $out <<'PY'
 import re,sys
 t=open(sys.argv[1]).read()
