@@ -890,17 +890,25 @@ sr_fused_kernel(Params P) {
         const int nph = nbins * 6;
         if (nph > 0) pre_load(0, __builtin_ctz(ne_bins));      // in flight during the scatter and the slot set-up
         {
-            // scatter: a position's list entry = the thread's cursor of its bin, which then moves on (registers only)
+            // scatter: a position's list entry = the thread's cursor of its bin, which then moves on (registers only).
+            // The entry is the position's feat-tile ADDRESS (listed positions lie inside the frame, so it is the unclamped
+            // one: one increment per position, a row step every HP positions), which the slot set-up then reads back
+            // as it is -- no second address computation per slot.
+            const int p0 = tid * KH, ry0 = p0 / D::HP;
+            uint32_t col = (uint32_t)(p0 - ry0 * D::HP);
+            uint32_t ap = (uint32_t)((ry0 + R2) * D::FP + R2 * CH) + col;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
                 const uint32_t q = k < 8 ? (qlo >> (4 * k)) & 0xFu : (qhi >> (4 * (k - 8))) & 0xFu;
                 if (q < NBIN) {
                     const uint32_t pair = q < 2 ? cur01 : cur23;
                     const uint32_t v = (q & 1u) ? pair >> 16 : pair & 0xFFFFu;
-                    lst[v] = (uint16_t)(tid * KH + k);
+                    lst[v] = (uint16_t)ap;
                     const uint32_t inc = (q & 1u) ? 0x10000u : 1u;
                     if (q < 2) cur01 += inc; else cur23 += inc;
                 }
+                ++ap;
+                if (++col == (uint32_t)D::HP) { col = 0; ap += (uint32_t)(D::FP - D::HP); }
             }
         }
         __syncthreads();
@@ -917,11 +925,8 @@ sr_fused_kernel(Params P) {
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
             const uint32_t p = lst[k * NT + tid];
-            uint32_t a = 0xFFFFu;
-            if (p != 0xFFFFu) {
-                a = (uint32_t)center_addr<D::HP, D::FP>((int)p, hy0, hx0, fy0, fx0, Hc, Wc, nullptr);
-                vmask |= 1u << k;
-            }
+            uint32_t a = p;
+            if (p != 0xFFFFu) vmask |= 1u << k;
             const unsigned long long real = __ballot(p != 0xFFFFu);
             if (real != 0ull) {
                 const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)a, (int)__builtin_ctzll(real));
@@ -1160,8 +1165,9 @@ sr_fused_kernel(Params P) {
         const int ntask = ngrp * ndw;
         uint32_t* tq = reinterpret_cast<uint32_t*>(smem + D::OFF_TQ);
         int* tq_count = ctl + 23;                               // zeroed with the group table below
-        auto run_tasks = [&](auto gs_const) {
+        auto run_tasks = [&](auto gs_const, auto ns_const) {
         constexpr int GS = decltype(gs_const)::value;          // rows per group, 0 = read it per group
+        constexpr bool NS = decltype(ns_const)::value;         // Gaussian sums without the minimum shift (lerf_stage3.h)
         constexpr int GN = GS > 0 ? GS : GMAX;
         for (int t = tid; t < ntask; t += NT) {
             const int g = (int)__umulhi((unsigned)t, magic);
@@ -1226,7 +1232,7 @@ sr_fused_kernel(Params P) {
                                 else
                                     e[a * S + b] = s3::lin_factor(p0[a * S + b], dx, s3::dist_class_f(dx)) * ty[a * S + b];
                             }
-                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, SS, true, true>(e, v);
+                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, SS, true, true, NS>(e, v);
                         if (DIST) {
                             packed[r] = s3::pack_u8_dist(xf, u, packed[r], &dist[DIST ? r * 4 + u : 0]);
                             dmax = __builtin_fmaxf(dmax, __builtin_fabsf(dist[DIST ? r * 4 + u : 0]));
@@ -1295,10 +1301,14 @@ sr_fused_kernel(Params P) {
         // the constant-size variants cover the integer scale factors (x2 -> 2 rows per group, ...); anything else reads
         // the group size per task
         constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
-        if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});
-        else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{});
-        else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{});
-        else run_tasks(std::integral_constant<int, 0>{});
+        // max_sigma beyond kNoShiftMaxSigma (never the case with the reference's option defaults): the unshifted Gaussian sums
+        // could underflow, the generic loop with minimum-shifted weights takes over
+        const bool noshift = KIND != LERF_KIND_GAUSS || P.max_sigma <= s3::kNoShiftMaxSigma;
+        if (!noshift) run_tasks(std::integral_constant<int, 0>{}, std::false_type{});
+        else if (gsame == 2) run_tasks(std::integral_constant<int, 2>{}, std::true_type{});
+        else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{}, std::true_type{});
+        else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{}, std::true_type{});
+        else run_tasks(std::integral_constant<int, 0>{}, std::true_type{});
         // ---- tie pass: the queued outputs in float64, one per lane; each patches its byte behind the task loop's
         //      dword stores (drained and fenced by the barrier)
         if (P.dis_r64 != nullptr) {

@@ -320,8 +320,11 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 }
             }
         }
-        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1,
-                                    sizeof(TH) == 1 && sizeof(TO) == 1>(e, v);
+        // the unshifted sums only where they cannot underflow (lerf_stage3.h: kNoShiftMaxSigma); same choice as the fused kernel
+        constexpr bool U8P = sizeof(TH) == 1 && sizeof(TO) == 1;
+        const float xf = (U8P && (float)max_sigma <= s3::kNoShiftMaxSigma)
+                             ? s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1, U8P, true>(e, v)
+                             : s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1, U8P, false>(e, v);
         if (sizeof(TH) == 1 && sizeof(TO) == 1 && dis_r64 != nullptr && s3::near_tie(xf)) {
             double dx64[MAXS], dy64[MAXS];
 #pragma unroll

@@ -104,16 +104,24 @@ __device__ __forceinline__ float lin_factor(float alpha, float x, int cls) {
     return f < 0.0f ? 0.0f : f;                                            // negative weights clipped (:240)
 }
 
+// The unshifted Gaussian branch of finish() is safe only while exp2(-e') of the NEAREST tap is a normal float32: on an SR
+// grid that tap lies within half a pixel on both axes, so e' <= 0.5 log2(e) (0.25 + 0.25 + 0.5) max_sigma^2 =
+// 0.7214 max_sigma^2, which stays below 126 for max_sigma <= 13.2.  max_sigma is a free parameter of the reference's
+// classes (resize_right2d_numpy.py:143) and of the C ABI: every caller picks NOSHIFT = (max_sigma <= kNoShiftMaxSigma)
+// on the host side of the launch or by a wave-uniform branch, and larger values take the minimum-shifted sums, whose
+// largest weight is exactly 1 (the reference's float64 arithmetic never underflows there either).
+constexpr float kNoShiftMaxSigma = 13.0f;
+
 // normalised weighted sum over N taps; e[] are quadratic forms (GAUSS) or weights
-template <bool GAUSS, int N, bool FAST = false, bool SCALED = false>
+template <bool GAUSS, int N, bool FAST = false, bool SCALED = false, bool NOSHIFT = false>
 __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]) {
 #pragma clang fp contract(off)
     // the sums start from the first tap (0 + x and fma(w, v, 0) are exact, but without fast-math the compiler keeps them)
     float num, den;
-    if (GAUSS && SCALED && (N == 4 || N == 16)) {
-        // 2x2 / 4x4 support on an SR grid (taps at left .. left+S-1 with left = ceil(g - S/2 - eps)): the nearest tap lies
-        // within half a pixel on both axes, so its pre-scaled form is at most 0.5 log2(e) (25 + 25 + 50) = 72 and
-        // exp2(-72) is a normal float32 -- the denominator cannot vanish and the weights need no shift by the support's
+    if (GAUSS && SCALED && NOSHIFT && (N == 4 || N == 16)) {
+        // 2x2 / 4x4 support on an SR grid (taps at left .. left+S-1 with left = ceil(g - S/2 - eps)), max_sigma <=
+        // kNoShiftMaxSigma: the nearest tap's pre-scaled form is at most 0.7214 * 169 = 122 (72 at the default max_sigma
+        // of 10) and exp2(-122) is a normal float32 -- the denominator cannot vanish and the weights need no shift by the support's
         // minimum (N-1 v_min + N v_sub per output saved; the relative accuracy of w = exp2(-e) is that of e either way)
         den = __builtin_amdgcn_exp2f(-e[0]);
         num = den * v[0];
