@@ -292,8 +292,7 @@ def main():
 
         def step(x=frames, o=outs):
             packed = ops.stages_packed(x, eng.luts, workspace=ws)                  # one launch pair for the batch
-            for b in range(x.shape[0]):
-                ops.warp_packed(packed[b], geo, kind, ms, out=o[b])
+            ops.warp_packed(packed, geo, kind, ms, out=o)                          # one launch for the batch (shared homography)
         return step, outs, out_hw, frames
 
     if cfg == 4:

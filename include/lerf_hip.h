@@ -12,8 +12,9 @@
  *   - plain pointers and sizes only; no torch / HIP types in the signatures
  *     (`stream` is a hipStream_t passed as void*; NULL = default stream);
  *   - every function returns 0 on success or a negative LERF_E* code -- no
- *     exceptions cross the ABI, nothing is allocated, there is no global
- *     state; the caller owns every buffer, LUT buffers are borrowed read-only;
+ *     exceptions cross the ABI, nothing is allocated, there is no mutable
+ *     global state (per-device "kernel attribute set" flags apart); the caller
+ *     owns every buffer, LUT buffers are borrowed read-only;
  *   - device entry points only enqueue work on `stream`; they never
  *     synchronise with the host;
  *   - re-entrant: concurrency = different streams.
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LERF_ABI_VERSION 3
+#define LERF_ABI_VERSION 4
 #define LERF_MAX_MODES 5          /* s, c, t, d, y  (resample/eval_lut_sr.py:12-18) */
 #define LERF_LUT_ENTRIES 83521    /* 17^4, interval = 4 (resample/eval_lut_sr.py:27-28) */
 #define LERF_MAX_SUPPORT 8
@@ -97,12 +98,22 @@ typedef struct {
     int S;                   /* support size (2 in every published result, 4 = class default) */
     int out_h, out_w;
     const int32_t* left_r;   /* device [out_h]    first source row of the support (unpadded coords) */
-    const float* dis_r;      /* device [out_h*S]  row distances  */
+    const float* dis_r;      /* device [out_h*S]  row distances: uint8 outputs (float32 production arithmetic) */
     const int32_t* left_c;   /* device [out_w] */
     const float* dis_c;      /* device [out_w*S] */
-    const double* dis_r64;   /* device, optional: float64 distances for LERF_F64 outputs */
-    const double* dis_c64;
-    int pad_mode;            /* LERF_PAD_*; non-constant modes: float outputs of lerf_resize only */
+    const double* dis_r64;   /* device [out_h*S]: REQUIRED for LERF_F32 and LERF_F64 outputs of lerf_resize (both are evaluated */
+    const double* dis_c64;   /* in float64, LERF_EINVAL without them); optional for uint8 outputs, where they arm the tie guard */
+    int pad_mode;            /* LERF_PAD_* of the image operand; non-constant modes: float outputs of lerf_resize only */
+    /* ---- ABI 4 (zero = the behaviour of ABI 3) */
+    int tie_queue_cap;       /* test hook of the tile-fused kernel: outputs within 1.5e-4 of a rounding tie are queued per tile and
+                              * re-evaluated in float64 behind the tile's task loop; 0 = the default capacity (2048 per tile), n > 0 =
+                              * n entries, < 0 = no queue (every tie is evaluated inside the loop).  Lets the parity tests drive the
+                              * overflow path; carried per call, the library keeps no state */
+    int roi_y, roi_x;        /* LR region the tiles of lerf_sr_fused_u8 are laid over (origin and extent in LR pixels); roi_h = 0 or */
+    int roi_h, roi_w;        /* roi_w = 0: the whole frame.  A rank of a 2-D block partition passes its OWNED block here and the block
+                              * plus halo as the frame: halo pixels then only ever serve as tile halos (255 instead of 288 tiles for a
+                              * 1080x960 block of a 2160x3840 frame).  The output tables must list only outputs whose support starts
+                              * inside the region (the caller's slicing rule; lerf-pytorch_amd/dist.py BlockPlan) */
 } lerf_sr_geo_t;
 
 /* Homography geometry (resize_right/resize_right2d_numpy.py:306-407): evaluated
@@ -166,12 +177,12 @@ int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C,
                         int h, int w, const int8_t dy[4], const int8_t dx[4],
                         const int8_t* lut, int oC, int interval, int16_t* out, void* stream);
 
-/* LUT pack for the tile-fused kernel (modes "sct"/"sct" only): the stage-1
+/* LUT pack for the tile-fused kernel (1..4 modes per stage, any of "sdyct"; oC = 1 or 3): the stage-1
  * LUTs padded to 16-byte multiples, and the stage-2 LUTs as one uint32 per
- * entry holding the oC biased bytes (layout in DESIGN.md).  The caller owns
- * `buf` (lerf_fused_lutpack_bytes(oC) bytes of device memory) and stores it in
+ * entry holding the oC biased bytes, cut into the pieces the kernel stages (layout in DESIGN.md).  The caller owns
+ * `buf` (lerf_fused_lutpack_bytes(luts) bytes of device memory; 0 = this LUT set has no fused kernel) and stores it in
  * lerf_luts_t.fused_pack. */
-size_t lerf_fused_lutpack_bytes(int oC);
+size_t lerf_fused_lutpack_bytes(const lerf_luts_t* luts);
 int lerf_fused_lutpack_build(const lerf_luts_t* luts, void* buf, void* stream);
 
 /* Stages 1+2 of eltr._worker (resample/eval_lut_sr.py:541-628,
@@ -208,40 +219,78 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3],
               int H, int W, int C, const lerf_warp_geo_t* geo,
               int kind, double max_sigma, const lerf_mplane_t* out, void* stream);
 
-/* Stages 1+2 by the tile-fused kernel (modes "sct"/"sct", C = 3, luts->fused_pack set), `n` frames:
- * packed[(y*W + x)*3 + c] = hq0 | hq1<<8 | hq2<<16 | feat<<24  (hq1, hq2 = 0 for LeRF-L).
+/* Stages 1+2 by the tile-fused kernel (luts->fused_pack set), `n` frames:
+ * packed[(y*W + x)*C + c] = hq0 | hq1<<8 | hq2<<16 | feat<<24  (hq1, hq2 = 0 for LeRF-L).
  * Same values as lerf_lut_stages_u8, ~4x faster; feeds lerf_warp_packed / lerf_unpack_stages.
- * workspace: optional device scratch of AT LEAST lerf_sr_fused_workspace_bytes(H, W, C, n) bytes (NULL = none): with it
- * stage 1 runs as its own launch without recomputing tile halos, like lerf_sr_fused_u8. */
+ * workspace: optional device scratch (NULL = none) of `workspace_bytes` bytes: with it stage 1 runs as its own launch
+ * without recomputing tile halos, like lerf_sr_fused_u8.  LERF_EINVAL when it is non-NULL and smaller than
+ * lerf_sr_fused_workspace_bytes(H, W, C, n). */
 int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
-                          const lerf_luts_t* luts, uint32_t* packed, int64_t packed_sn, void* workspace, void* stream);
+                          const lerf_luts_t* luts, uint32_t* packed, int64_t packed_sn,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* packed dwords -> feat uint8 [n_pxch] and hq uint8 [n_pxch][oC] (either may be NULL) */
 int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, void* stream);
 
-/* lerf_warp (gauss / linear) reading the packed stage outputs of one HWC frame; out: uint8 or float32 */
-int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_warp_geo_t* geo,
-                     int kind, double max_sigma, const lerf_mplane_t* out, void* stream);
+/* lerf_warp (gauss / linear) reading the packed stage outputs of `n` HWC frames that share one homography (frame
+ * strides packed_sn in dwords, out_sn in elements of `out`; n = 1: one frame) in ONE launch; out: uint8 or float32 */
+int lerf_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, int W, int C, const lerf_warp_geo_t* geo,
+                     int kind, double max_sigma, const lerf_mplane_t* out, int64_t out_sn, void* stream);
 
 /* Whole SR path of eltr._worker (resample/eval_lut_sr.py:541-665) for a batch of `n` frames (batch strides
  * in_sn / out_sn in elements): uint8 HWC in -> uint8 HWC out.
- * workspace != NULL (at least lerf_sr_fused_workspace_bytes(H, W, C, n) bytes of device memory -- a smaller buffer
- * is written out of bounds): TWO launches over the same grid of 64x64 LR tiles; stage 1 runs once per pixel and its
- * uint8 output (3 B per LR pixel) waits in the workspace, the second launch runs stage 2, the finalisation and stage
+ * workspace != NULL (`workspace_bytes` >= lerf_sr_fused_workspace_bytes(H, W, C, n) bytes of device memory, LERF_EINVAL
+ * when shorter): TWO launches over the same grid of 64x64 LR tiles; stage 1 runs once per pixel and its
+ * uint8 output (C bytes per LR pixel) waits in the workspace, the second launch runs stage 2, the finalisation and stage
  * 3 per tile; the hyper-parameters never leave the CU.
- * workspace == NULL: ONE launch; every tile recomputes stage 1 on its halo (about 4 % slower) and nothing but the
- * input, the LUT pack and the output touches HBM.  Configurations outside the tile-fused kernel (C != 3, modes !=
- * "sct", S not in {2,4}, down-sampling) need the workspace and run the three direct kernels through it. */
+ * workspace == NULL: ONE launch; every tile recomputes stage 1 on its halo (about 4 % slower on a batch, the better
+ * choice for a single frame or block that fills the chip once) and nothing but the input, the LUT pack and the output
+ * touches HBM.  Configurations outside the tile-fused kernel (see lerf_sr_fused_supported) need the workspace and run
+ * the three direct kernels through it. */
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n);
-/* Test hook, no counterpart in the reference: the tile-fused kernel queues the outputs that sit within 1.5e-4 of a
- * rounding tie (re-evaluated in float64, the reference's own arithmetic: resize_right2d_numpy.py:150-221) in a per-tile
- * queue of 2048 entries and evaluates them on the spot once the queue is full.  Lowering the capacity (0..2048; < 0 =
- * default) drives the parity tests through that fallback.  Process-wide, affects later launches; returns the old value. */
-int lerf_debug_set_tie_queue_cap(int cap);
 int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C,
                      const lerf_luts_t* luts, const lerf_sr_geo_t* geo,
                      int kind, double max_sigma,
-                     uint8_t* out, int64_t out_sn, void* workspace, void* stream);
+                     uint8_t* out, int64_t out_sn, void* workspace, size_t workspace_bytes, void* stream);
+/* 1 when lerf_sr_fused_u8 would take the tile-fused kernels for this configuration, 0 when it would fall back to the
+ * direct kernels (host-side query, no device work) */
+int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind);
+
+/* Frames of DIFFERENT sizes through ONE launch pair of the general tile-fused kernels (each workgroup finds its frame in a
+ * descriptor table that travels in the kernel arguments; chunks of 16 frames per launch): what eltr.run does image by
+ * image over a benchmark folder (resample/eval_lut_sr.py:489-512).  Every item carries its own geometry (same support S
+ * and pad_mode for all; tie_queue_cap / roi of the first item apply).  `items` is a HOST array.  workspace: device scratch of
+ * at least lerf_sr_ragged_workspace_bytes(items, n, C) bytes (required).  Configurations without a tile-fused kernel run
+ * item by item through lerf_sr_fused_u8. */
+typedef struct {
+    const uint8_t* img;      /* device, dense uint8 [H][W][C] */
+    uint8_t* out;            /* device, dense uint8 [geo.out_h][geo.out_w][C] */
+    int H, W;
+    lerf_sr_geo_t geo;
+} lerf_sr_item_t;
+size_t lerf_sr_ragged_workspace_bytes(const lerf_sr_item_t* items, int n, int C);
+int lerf_sr_fused_ragged_u8(const lerf_sr_item_t* items, int n, int C, const lerf_luts_t* luts, int kind, double max_sigma,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* the same for stages 1+2 alone (packed dwords out, see lerf_stages_packed_u8): the warp harness' stage passes over a
+ * folder of images (resample/eval_lut_warp.py:100-191) */
+typedef struct {
+    const uint8_t* img;      /* device, dense uint8 [H][W][C] */
+    uint32_t* packed;        /* device, dense uint32 [H][W][C] */
+    int H, W;
+} lerf_stage_item_t;
+size_t lerf_stages_ragged_workspace_bytes(const lerf_stage_item_t* items, int n, int C);
+int lerf_stages_packed_ragged_u8(const lerf_stage_item_t* items, int n, int C, const lerf_luts_t* luts,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Halo plumbing of the multi-GPU partitions (lerf-pytorch_amd/dist.py): copies up to LERF_MAX_RECTS rectangles between
+ * a batch of dense uint8 frames [n][fh][fw][C] and one contiguous staging buffer, in ONE launch.
+ * to_staging = 1: frame rectangles -> staging (pack before the sends); 0: staging -> frame rectangles (unpack after the
+ * receives).  Rectangle r covers rows [y, y+h) x columns [x, x+w) of every frame and lives at staging + off (bytes) as a
+ * dense [n][h][w][C] block. */
+#define LERF_MAX_RECTS 8
+typedef struct { int y, x, h, w; int64_t off; } lerf_rect_t;
+int lerf_rect_copy_u8(uint8_t* frames, int n, int fh, int fw, int C, uint8_t* staging,
+                      const lerf_rect_t* rects, int n_rects, int to_staging, void* stream);
 
 /* ---- evaluation metrics of the reference harness, on the device (uint8 HWC RGB, row pitch in elements).
  * Each call leaves two doubles in `result` (device memory): a sum and a count; no host sync.

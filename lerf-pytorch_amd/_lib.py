@@ -40,8 +40,9 @@ EXPORTS = [
     "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables", "lerf_sr_axis_tables_f32",
     "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
     "lerf_lut_stages_u8",
-    "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_debug_set_tie_queue_cap", "lerf_sr_fused_u8",
-    "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed",
+    "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_supported", "lerf_sr_fused_u8",
+    "lerf_sr_ragged_workspace_bytes", "lerf_sr_fused_ragged_u8", "lerf_stages_ragged_workspace_bytes", "lerf_stages_packed_ragged_u8",
+    "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed", "lerf_rect_copy_u8",
     "lerf_metric_y_sse_u8", "lerf_metric_ssim_y_u8", "lerf_metric_masked_sse_u8",
     "lerf_swf2lut_interp_f32", "lerf_swf2lut_interp_bwd_f32", "lerf_resize_bwd_f32",
     "lerf_srnet_weight_floats", "lerf_srnet_to_lut",
@@ -73,7 +74,24 @@ class SrGeo(C.Structure):
         ("left_r", C.c_void_p), ("dis_r", C.c_void_p), ("left_c", C.c_void_p), ("dis_c", C.c_void_p),
         ("dis_r64", C.c_void_p), ("dis_c64", C.c_void_p),
         ("pad_mode", C.c_int),
+        ("tie_queue_cap", C.c_int),                                   # 0 = default, n > 0 = n entries, < 0 = no queue
+        ("roi_y", C.c_int), ("roi_x", C.c_int), ("roi_h", C.c_int), ("roi_w", C.c_int),   # 0-sized = whole frame
     ]
+
+
+class SrItem(C.Structure):          # lerf_sr_item_t: one frame of a ragged launch
+    _fields_ = [("img", C.c_void_p), ("out", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("geo", SrGeo)]
+
+
+class StageItem(C.Structure):       # lerf_stage_item_t
+    _fields_ = [("img", C.c_void_p), ("packed", C.c_void_p), ("H", C.c_int), ("W", C.c_int)]
+
+
+class Rect(C.Structure):            # lerf_rect_t
+    _fields_ = [("y", C.c_int), ("x", C.c_int), ("h", C.c_int), ("w", C.c_int), ("off", C.c_int64)]
+
+
+LERF_MAX_RECTS = 8
 
 
 class WarpGeo(C.Structure):
@@ -111,7 +129,7 @@ def lib():
     L.lerf_lut_interp_i16.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lerf_fused_lutpack_bytes.restype = C.c_size_t
-    L.lerf_fused_lutpack_bytes.argtypes = [C.c_int]
+    L.lerf_fused_lutpack_bytes.argtypes = [C.POINTER(Luts)]
     L.lerf_fused_lutpack_build.argtypes = [C.POINTER(Luts), C.c_void_p, C.c_void_p]
     L.lerf_lut_stages_u8.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
                                      C.POINTER(Plane), C.POINTER(Plane), C.c_void_p]
@@ -120,15 +138,25 @@ def lib():
     L.lerf_warp.argtypes = [C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo),
                             C.c_int, C.c_double, C.POINTER(Plane), C.c_void_p]
     L.lerf_stages_packed_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
-                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     L.lerf_unpack_stages.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.lerf_warp_packed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo), C.c_int, C.c_double,
-                                   C.POINTER(Plane), C.c_void_p]
-    L.lerf_debug_set_tie_queue_cap.argtypes = [C.c_int]
+    L.lerf_warp_packed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WarpGeo), C.c_int, C.c_double,
+                                   C.POINTER(Plane), C.c_int64, C.c_void_p]
+    L.lerf_rect_copy_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Rect), C.c_int, C.c_int,
+                                    C.c_void_p]
+    L.lerf_sr_fused_supported.argtypes = [C.c_int, C.POINTER(Luts), C.POINTER(SrGeo), C.c_int, C.c_int, C.c_int]
+    L.lerf_sr_ragged_workspace_bytes.restype = C.c_size_t
+    L.lerf_sr_ragged_workspace_bytes.argtypes = [C.POINTER(SrItem), C.c_int, C.c_int]
+    L.lerf_sr_fused_ragged_u8.argtypes = [C.POINTER(SrItem), C.c_int, C.c_int, C.POINTER(Luts), C.c_int, C.c_double, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]
+    L.lerf_stages_ragged_workspace_bytes.restype = C.c_size_t
+    L.lerf_stages_ragged_workspace_bytes.argtypes = [C.POINTER(StageItem), C.c_int, C.c_int]
+    L.lerf_stages_packed_ragged_u8.argtypes = [C.POINTER(StageItem), C.c_int, C.c_int, C.POINTER(Luts), C.c_void_p, C.c_size_t,
+                                               C.c_void_p]
     L.lerf_sr_fused_workspace_bytes.restype = C.c_size_t
     L.lerf_sr_fused_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.lerf_sr_fused_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts),
-                                   C.POINTER(SrGeo), C.c_int, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+                                   C.POINTER(SrGeo), C.c_int, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     L.lerf_metric_y_sse_u8.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p]
     L.lerf_metric_ssim_y_u8.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -144,7 +172,7 @@ def lib():
     L.lerf_srnet_to_lut.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:          # AttributeError here = the .so does not match include/lerf_hip.h
         getattr(L, name)
-    if L.lerf_abi_version() != 3:
+    if L.lerf_abi_version() != 4:
         raise LerfError("liblerf_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -185,13 +185,11 @@ int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C, in
     return rc != LERF_OK ? rc : check_launch();
 }
 
-size_t lerf_fused_lutpack_bytes(int oC) { return (oC == 1 || oC == 3) ? fused_lutpack_bytes(oC) : 0; }
+size_t lerf_fused_lutpack_bytes(const lerf_luts_t* luts) { return luts ? fused_lutpack_bytes(luts) : 0; }
 
 int lerf_fused_lutpack_build(const lerf_luts_t* luts, void* buf, void* stream) {
     if (!luts || !buf) return LERF_EINVAL;
-    if (luts->n_modes1 != 3 || luts->n_modes2 != 3 || memcmp(luts->modes1, "sct", 3) != 0 ||
-        memcmp(luts->modes2, "sct", 3) != 0)
-        return LERF_EUNSUPPORTED;
+    if (fused_lutpack_bytes(luts) == 0) return LERF_EUNSUPPORTED;
     int rc = fused_lutpack_build(luts, buf, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
@@ -243,7 +241,6 @@ int lerf_resize(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, in
     a.out = out->ptr; a.out_dtype = out->dtype; a.oy = out->sy; a.ox = out->sx; a.oc = out->sc;
     a.pad_mode = geo->pad_mode;
     if (a.pad_mode < LERF_PAD_CONSTANT || a.pad_mode > LERF_PAD_WRAP) return LERF_EINVAL;
-    if (a.pad_mode != LERF_PAD_CONSTANT && out->dtype == LERF_U8) return LERF_EUNSUPPORTED;
     int rc = launch_resize(a, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
@@ -279,15 +276,45 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int 
 }
 
 int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts,
-                          uint32_t* packed, int64_t packed_sn, void* workspace, void* stream) {
+                          uint32_t* packed, int64_t packed_sn, void* workspace, size_t workspace_bytes, void* stream) {
     if (!img || !luts || !packed || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
     FusedArgs f{};
     f.img = img; f.in_sn = in_sn; f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts;
     f.S = 2; f.oH = H; f.oW = W; f.kind = luts->oC == 3 ? LERF_KIND_GAUSS : LERF_KIND_LINEAR;
-    f.emit = packed; f.emit_sn = packed_sn; f.workspace = workspace;
+    f.emit = packed; f.emit_sn = packed_sn; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
     if (!fused_stages_supported(f)) return LERF_EUNSUPPORTED;
+    if (workspace && workspace_bytes < fused_workspace_bytes(f)) return LERF_EINVAL;
     int rc = launch_stages_fused(f, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
+}
+
+size_t lerf_stages_ragged_workspace_bytes(const lerf_stage_item_t* items, int n, int C) {
+    if (!items || n < 1 || C < 1) return 0;
+    size_t t = 0;
+    for (int i = 0; i < n; ++i) t += ((size_t)items[i].H * items[i].W * C + 15) / 16 * 16;
+    return t;
+}
+
+int lerf_stages_packed_ragged_u8(const lerf_stage_item_t* items, int n, int C, const lerf_luts_t* luts, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (!items || !luts || n < 1 || n > 4096 || C < 1) return LERF_EINVAL;
+    FusedItem its[64];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int m = n - i0 < 64 ? n - i0 : 64;
+        for (int i = 0; i < m; ++i) {
+            const lerf_stage_item_t& s = items[i0 + i];
+            if (!s.img || !s.packed || s.H < 1 || s.W < 1) return LERF_EINVAL;
+            its[i] = FusedItem{s.img, nullptr, s.packed, s.H, s.W, s.H, s.W, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        }
+        FusedArgs f{};
+        f.C = C; f.luts = luts; f.S = 2; f.kind = luts->oC == 3 ? LERF_KIND_GAUSS : LERF_KIND_LINEAR;
+        f.items = its; f.n_items = m; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
+        if (!fused_stages_supported(f)) return LERF_EUNSUPPORTED;
+        if (workspace && workspace_bytes < fused_workspace_bytes(f)) return LERF_EINVAL;
+        int rc = launch_stages_fused(f, as_stream(stream));
+        if (rc != LERF_OK) return rc;
+    }
+    return check_launch();
 }
 
 int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, void* stream) {
@@ -296,9 +323,9 @@ int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* 
     return rc != LERF_OK ? rc : check_launch();
 }
 
-int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_warp_geo_t* geo, int kind, double max_sigma,
-                     const lerf_mplane_t* out, void* stream) {
-    if (!packed || !geo || !out || !out->ptr || H < 1 || W < 1 || C < 1 || geo->out_h < 1 || geo->out_w < 1)
+int lerf_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, int W, int C, const lerf_warp_geo_t* geo, int kind,
+                     double max_sigma, const lerf_mplane_t* out, int64_t out_sn, void* stream) {
+    if (!packed || !geo || !out || !out->ptr || n < 1 || H < 1 || W < 1 || C < 1 || geo->out_h < 1 || geo->out_w < 1)
         return LERF_EINVAL;
     WarpGeo g;
     g.S = geo->S; g.oH = geo->out_h; g.oW = geo->out_w;
@@ -306,8 +333,19 @@ int lerf_warp_packed(const uint32_t* packed, int H, int W, int C, const lerf_war
     g.pad_r_lo = geo->pad_r_lo; g.pad_r_hi = geo->pad_r_hi; g.pad_c_lo = geo->pad_c_lo; g.pad_c_hi = geo->pad_c_hi;
     g.pad_mode = LERF_PAD_CONSTANT;
     if (geo->pad_mode != LERF_PAD_CONSTANT) return LERF_EUNSUPPORTED;
-    int rc = launch_warp_packed(packed, H, W, C, g, kind, (float)max_sigma, out->ptr, out->dtype, out->sy, out->sx,
-                                out->sc, as_stream(stream));
+    int rc = launch_warp_packed(packed, packed_sn, n, H, W, C, g, kind, (float)max_sigma, out->ptr, out->dtype, out->sy, out->sx,
+                                out->sc, out_sn, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
+int lerf_rect_copy_u8(uint8_t* frames, int n, int fh, int fw, int C, uint8_t* staging, const lerf_rect_t* rects, int n_rects,
+                      int to_staging, void* stream) {
+    if (!frames || !staging || !rects || n < 1 || fh < 1 || fw < 1 || C < 1 || n_rects < 1 || n_rects > LERF_MAX_RECTS) return LERF_EINVAL;
+    for (int r = 0; r < n_rects; ++r)
+        if (rects[r].y < 0 || rects[r].x < 0 || rects[r].h < 1 || rects[r].w < 1 || rects[r].y + rects[r].h > fh ||
+            rects[r].x + rects[r].w > fw || rects[r].off < 0)
+            return LERF_EINVAL;
+    int rc = launch_rect_copy(frames, n, fh, fw, C, staging, rects, n_rects, to_staging, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
 
@@ -319,38 +357,62 @@ int lerf_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut,
     return rc != LERF_OK ? rc : check_launch();
 }
 
-int lerf_debug_set_tie_queue_cap(int cap) { return fused_set_tie_queue_cap(cap); }
+static size_t general_workspace_bytes(int H, int W, int C, int n) { return (size_t)n * H * W * C * 4; }
 
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {
     // Two uses, the larger one sizes it: (a) the two-launch tile-fused path parks the stage-1 output of the batch there
     // (n frames, frame stride rounded up to 16 bytes) between s1_kernel and the stage-2/3 launch; (b) the general
-    // fallback keeps feat + up to 3 hyper planes per frame.  A non-NULL workspace MUST have at least this size.
+    // fallback keeps feat + up to 3 hyper planes per frame.
     if (H < 1 || W < 1 || C < 1 || n < 1) return 0;
     const size_t hwc = (size_t)H * W * C;
-    const size_t a = (size_t)n * ((hwc + 15) / 16 * 16), b = (size_t)n * hwc * 4;
+    const size_t a = (size_t)n * ((hwc + 15) / 16 * 16), b = general_workspace_bytes(H, W, C, n);
     return a > b ? a : b;
 }
 
-int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts,
-                     const lerf_sr_geo_t* geo, int kind, double max_sigma, uint8_t* out, int64_t out_sn,
-                     void* workspace, void* stream) {
-    if (!img || !out || !luts || !geo || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
-    if (!geo->left_r || !geo->left_c || !geo->dis_r || !geo->dis_c) return LERF_EINVAL;
-    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return LERF_EUNSUPPORTED;
-    if ((kind == LERF_KIND_GAUSS) != (luts->oC == 3)) return LERF_EINVAL;
-    FusedArgs f{};
-    f.img = img; f.in_sn = in_sn; f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts;
+static void fused_args_of(FusedArgs& f, int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind) {
+    f.H = H; f.W = W; f.C = C; f.luts = luts;
     f.S = geo->S; f.oH = geo->out_h; f.oW = geo->out_w;
     f.left_r = geo->left_r; f.dis_r = geo->dis_r; f.left_c = geo->left_c; f.dis_c = geo->dis_c;
     f.dis_r64 = (geo->dis_r64 && geo->dis_c64) ? geo->dis_r64 : nullptr;      // both or neither: tie guard
     f.dis_c64 = (geo->dis_r64 && geo->dis_c64) ? geo->dis_c64 : nullptr;
-    f.kind = kind; f.max_sigma = (float)max_sigma; f.out = out; f.out_sn = out_sn; f.workspace = workspace;
+    f.kind = kind;
+    f.roi_y = geo->roi_y; f.roi_x = geo->roi_x; f.roi_h = geo->roi_h; f.roi_w = geo->roi_w;
+    f.tq_cap = geo->tie_queue_cap; f.pad_mode = geo->pad_mode;
+}
+
+int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind) {
+    if (!luts || !geo || H < 1 || W < 1 || C < 1) return 0;
+    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return 0;
+    if ((kind == LERF_KIND_GAUSS) != (luts->oC == 3)) return 0;
+    FusedArgs f{};
+    fused_args_of(f, C, luts, geo, H, W, kind);
+    f.n = 1;
+    f.workspace = (void*)1;          // "a workspace will be passed" (wrap padding needs the two-launch path)
+    return fused_supported(f) ? 1 : 0;
+}
+
+int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts,
+                     const lerf_sr_geo_t* geo, int kind, double max_sigma, uint8_t* out, int64_t out_sn,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!img || !out || !luts || !geo || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    if (!geo->left_r || !geo->left_c || !geo->dis_r || !geo->dis_c) return LERF_EINVAL;
+    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return LERF_EUNSUPPORTED;
+    if ((kind == LERF_KIND_GAUSS) != (luts->oC == 3)) return LERF_EINVAL;
+    if (geo->pad_mode < LERF_PAD_CONSTANT || geo->pad_mode > LERF_PAD_WRAP) return LERF_EINVAL;
+    const bool roi = geo->roi_h > 0 && geo->roi_w > 0;
+    if (roi && (geo->roi_y < 0 || geo->roi_x < 0 || geo->roi_y + geo->roi_h > H || geo->roi_x + geo->roi_w > W)) return LERF_EINVAL;
+    FusedArgs f{};
+    fused_args_of(f, C, luts, geo, H, W, kind);
+    f.img = img; f.in_sn = in_sn; f.n = n;
+    f.max_sigma = (float)max_sigma; f.out = out; f.out_sn = out_sn; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
     if (fused_supported(f)) {
+        if (workspace && !roi && workspace_bytes < fused_workspace_bytes(f)) return LERF_EINVAL;
         int rc = launch_sr_fused(f, as_stream(stream));
         return rc != LERF_OK ? rc : check_launch();
     }
     // general configuration: the three stages through the caller's workspace
-    if (!workspace) return LERF_EINVAL;
+    if (!workspace || roi) return roi ? LERF_EUNSUPPORTED : LERF_EINVAL;
+    if (workspace_bytes < general_workspace_bytes(H, W, C, n)) return LERF_EINVAL;
     const int oC = luts->oC;
     for (int b = 0; b < n; ++b) {
         uint8_t* ws = (uint8_t*)workspace + (size_t)b * H * W * C * 4;
@@ -369,6 +431,56 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
         if (rc != LERF_OK) return rc;
     }
     return LERF_OK;
+}
+
+size_t lerf_sr_ragged_workspace_bytes(const lerf_sr_item_t* items, int n, int C) {
+    if (!items || n < 1 || C < 1) return 0;
+    size_t sum = 0, mx = 0;
+    for (int i = 0; i < n; ++i) {
+        sum += ((size_t)items[i].H * items[i].W * C + 15) / 16 * 16;
+        const size_t g = lerf_sr_fused_workspace_bytes(items[i].H, items[i].W, C, 1);
+        mx = g > mx ? g : mx;
+    }
+    return sum > mx ? sum : mx;
+}
+
+int lerf_sr_fused_ragged_u8(const lerf_sr_item_t* items, int n, int C, const lerf_luts_t* luts, int kind, double max_sigma,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!items || !luts || n < 1 || n > 4096 || C < 1 || !workspace) return LERF_EINVAL;
+    if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return LERF_EUNSUPPORTED;
+    if ((kind == LERF_KIND_GAUSS) != (luts->oC == 3)) return LERF_EINVAL;
+    if (workspace_bytes < lerf_sr_ragged_workspace_bytes(items, n, C)) return LERF_EINVAL;
+    bool all = true;
+    for (int i = 0; i < n; ++i) {
+        const lerf_sr_item_t& s = items[i];
+        if (!s.img || !s.out || s.H < 1 || s.W < 1 || !s.geo.left_r || !s.geo.left_c || !s.geo.dis_r || !s.geo.dis_c) return LERF_EINVAL;
+        if (s.geo.S != items[0].geo.S || s.geo.pad_mode != items[0].geo.pad_mode) return LERF_EINVAL;
+        all = all && lerf_sr_fused_supported(C, luts, &s.geo, s.H, s.W, kind) && s.geo.roi_h == 0;
+    }
+    if (!all) {                       // some item has no tile-fused kernel: item by item (same results)
+        for (int i = 0; i < n; ++i) {
+            const lerf_sr_item_t& s = items[i];
+            int rc = lerf_sr_fused_u8(s.img, 0, 1, s.H, s.W, C, luts, &s.geo, kind, max_sigma, s.out, 0, workspace, workspace_bytes, stream);
+            if (rc != LERF_OK) return rc;
+        }
+        return LERF_OK;
+    }
+    FusedItem its[64];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int m = n - i0 < 64 ? n - i0 : 64;
+        for (int i = 0; i < m; ++i) {
+            const lerf_sr_item_t& s = items[i0 + i];
+            its[i] = FusedItem{s.img, s.out, nullptr, s.H, s.W, s.geo.out_h, s.geo.out_w, s.geo.left_r, s.geo.dis_r,
+                               s.geo.left_c, s.geo.dis_c, s.geo.dis_r64, s.geo.dis_c64};
+        }
+        FusedArgs f{};
+        fused_args_of(f, C, luts, &items[0].geo, items[i0].H, items[i0].W, kind);
+        f.roi_h = f.roi_w = 0;
+        f.items = its; f.n_items = m; f.max_sigma = (float)max_sigma; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
+        int rc = launch_sr_fused(f, as_stream(stream));
+        if (rc != LERF_OK) return rc;
+    }
+    return check_launch();
 }
 
 }  // extern "C"

@@ -1,1532 +1,97 @@
-// Tile-fused uint8 SR path for MI355X (gfx950): stage-1 LUTs -> stage-2 LUTs -> spatially-varying resampling per
-// 64x64 LR tile (tiles handed to the XCDs in contiguous eighths: xcd_order).  With a caller workspace (the normal case)
-// it is TWO launches: s1_kernel computes stage 1 once per pixel and parks its uint8 output in the workspace,
-// sr_fused_kernel<.., FROM_FEAT> runs stage 2, the finalisation and stage 3 from it -- the hyper-parameters never leave
-// the CU.  Without a workspace ONE launch does everything and recomputes stage 1 on each tile's halo.
+// Tile-fused uint8 SR path for MI355X (gfx950): host-side dispatch and the LUT pack.  The kernels live in
+// lerf_fused_impl.h, instantiated once per channel count: this file holds the RGB instance with the SPECIALISED kernels
+// of the published configuration (modes "sct" / "sct", scale factors below 4.9); lerf_fused_g3.hip / _c1.hip / _c4.hip
+// hold the general kernels (any 1..4 sampling patterns per stage, scale factors up to 8, frames of different sizes in
+// one launch) for 3, 1 and 4 channels.
 //
 // Reference path being replaced: eltr._worker, resample/eval_lut_sr.py:541-665
 // (FourSimplexInterpFaster :24-470 x 24 passes, SteeringGaussianResize2dNumpy /
 // AmplifiedLinearResize2dNumpy, resize_right/resize_right2d_numpy.py:142-282).
-//
-// Work decomposition
-//   one 1024-thread workgroup (16 waves, 1 per CU: LDS-bound) per 64x64 LR tile
-//   of one frame.  The tile owns the output pixels whose support starts inside
-//   it.  Halo: 3 (stage 1) + 3 (stage 2) + S/2 (stage 3) LR pixels per side,
-//   recomputed per tile; true image borders use the reference's rules (clamped
-//   sampling for the LUT stages, zero image / edge hyper for stage 3).
-//
-// LDS plan (dynamic, one array; sizes for S=2 / S=4)
-//   B    feat tile u8                   (72x72x3 = 15.5 KB / 74x74x3)     all stages
-//   LUT  stage 1: one int8 LUT          83.5 KB
-//        stage 2 (LeRF-G): a THIRD of one packed LUT = the 7 top-axis levels that pixels whose
-//        centre level lies in the bin can touch, 7*4913 dwords = 134 KB
-//   C    input tile u8 (78x78x3)        stage 1 only
-//   ACC  int16 partial sums             stage 1 (and stage 2 of LeRF-L)
-//   LST  pixel lists sorted by bin      stage 2 (LeRF-G), transient (under the piece, which waits in registers)
-//   D    (hq0,hq1,hq2,feat) dwords      stage 3, overlays LUT (52 KB / 55 KB)
-//   GEO  tile geometry tables           stage 3 (9 KB; staged at kernel start for S=2)
-//   TQ   rounding-tie queue             stage 3 (8 KB, behind D)
-//
-// Stage 2 of LeRF-G keeps the whole 3-channel LUT entry in one dword, so one
-// simplex walk (index sort + 5 LDS gathers) serves all three hyper channels.
-// The full packed LUT (326 KB) cannot live in LDS; pixels are therefore binned
-// by the level of their centre value (which selects the slowest LUT axis
-// for every mode and rotation), and each (LUT, bin) phase processes only the
-// pixels of that bin with all 64 lanes busy.  Per-pixel accumulators stay in
-// VGPRs across phases (two packed 16-bit fields + one).
-#include <string.h>
-#include <type_traits>
-
-#include "lerf_kernels.h"
-#include "lerf_stage3.h"
+#define LERF_FUSED_NS fused
+#define LERF_FUSED_CH 3
+#include "lerf_fused_impl.h"
 
 namespace lerf {
-namespace fused {
 
-constexpr int NT = 1024;           // threads per workgroup
-constexpr int NW = NT / 64;        // waves
-constexpr int TH = 64, TW = 64;    // LR tile
-constexpr int CH = 3;              // channels (RGB frames)
-constexpr int R1 = 3, R2 = 3;      // stage radii for modes s,c,t
-constexpr int LUT_PAD = 83584;     // padded entries per LUT in the pack (16-B multiple)
-// Stage-2 bins: a pixel-channel goes by the top-axis level (high nibble) of its centre value, which selects the slowest
-// LUT axis for every mode and rotation.  Bin b covers the levels [bin_lo(b), bin_lo(b + 1)); its piece of a packed LUT is
-// those levels plus the one above (the simplex walk steps up once).
-#ifndef LERF_NBIN
-#define LERF_NBIN 3
-#endif
-constexpr int NBIN = LERF_NBIN;
-#if LERF_NBIN == 4      // four bins of 4 levels, 5-level pieces of 96 KiB (24 phases per tile): the measured alternative
-__host__ __device__ constexpr int bin_lo(int b) { return 4 * b; }
-__device__ __forceinline__ uint32_t bin_of_level(uint32_t msb) { return msb >> 2; }
-constexpr int PIECE_LEVELS = 5;                               // levels per piece
-#else                   // three bins of 6, 5 and 5 levels, 7-level pieces of 134 KiB that fill the LDS: 18 longer phases
-__host__ __device__ constexpr int bin_lo(int b) { return b == 0 ? 0 : (b == 1 ? 6 : (b == 2 ? 11 : 16)); }
-__device__ __forceinline__ uint32_t bin_of_level(uint32_t msb) { return (msb >= 6u ? 1u : 0u) + (msb >= 11u ? 1u : 0u); }
-constexpr int PIECE_LEVELS = 7;
-#endif
-constexpr int PIECE_ENTRIES = PIECE_LEVELS * kStrideA;
-constexpr int NSLAB = (PIECE_ENTRIES * 4 + 16 * NT - 1) / (16 * NT);   // 16 bytes per thread and slab
-constexpr int PIECE_BYTES = NSLAB * 16 * NT;                  // one piece in the pack (144 KiB, 34391 dwords used)
-constexpr int PIECE_BLOCKS = (PIECE_ENTRIES * 4 + 1023) / 1024;      // 1-KiB blocks of a piece that hold data
-constexpr int PIECE_LDS = PIECE_BLOCKS * 1024;                // what a piece occupies in LDS
-
-template <int S>
-struct Dims {
-    static constexpr int R3 = S / 2;
-    static constexpr int HY = TH + 2 * R3, HX = TW + 2 * R3, HP = HX * CH, NH = HY * HP;   // hyper region
-    static constexpr int FY = HY + 2 * R2, FX = HX + 2 * R2, FP = FX * CH, NF = FY * FP;   // feat region
-    // input region; its LDS pitch is a dword multiple with room for a 0..3 byte phase, so that interior tiles can be
-    // fetched as aligned dwords (row r of the tile = global bytes from the 4-byte boundary below its first pixel)
-    static constexpr int IY = FY + 2 * R1, IX = FX + 2 * R1, IPB = IX * CH, IP = (IPB + 3 + 3) / 4 * 4, NI = IY * IP;
-    static constexpr int up16(int x) { return (x + 15) / 16 * 16; }
-    static constexpr int OFF_B = 0;
-    static constexpr int OFF_X = up16(NF);                       // stage-dependent area starts here
-    // stage 1 (and byte-LUT stage 2)
-    static constexpr int OFF_LUT = OFF_X;
-    static constexpr int OFF_C = OFF_LUT + LUT_PAD;
-    static constexpr int OFF_ACC = OFF_C + up16(NI);
-    static constexpr int END1 = OFF_ACC + up16(NF * 2);
-    // stage 2, LeRF-G: one piece.  The position lists and the wave x bin count table only live between the binning and the
-    // first piece store (the first piece waits in registers) and overlay the piece.
-    static constexpr int MAXR = (NH + NBIN * 63 + NT - 1) / NT;   // slot rounds: every bin padded to whole waves (14)
-    static constexpr int OFF_LST = OFF_X;
-    static constexpr int OFF_TAB = OFF_LST + MAXR * NT * 2;       // [wave][4 bins] counts
-    static_assert(OFF_TAB + NW * 4 * 4 <= OFF_X + PIECE_LDS, "binning scratch fits under the piece");
-    static constexpr int END2 = OFF_X + PIECE_LDS;
-    // stage 3
-    static constexpr int OFF_D = OFF_X;
-    // S = 2: the tile geometry is staged at kernel start (its table look-ups overlap the input load) into a
-    // region of its own; S = 4 has no room for that and stages it right before stage 3, over the dead LUT area
-    static constexpr bool GEO_EARLY = (S == 2);
-    static constexpr int cmax0(int a, int b) { return a > b ? a : b; }
-    static constexpr int OFF_GEO = GEO_EARLY ? cmax0(END1, END2) : OFF_D + up16(NH * 4);
-    static constexpr int GEO_ROWS = 320;                          // max owned output rows / cols per tile (scale <= 4.9)
-    static constexpr int SZ_GEO = 2 * GEO_ROWS * (4 + 4 * S) + (GEO_ROWS + 16) * 4;   // + row-group table
-    static constexpr int END3 = OFF_GEO + SZ_GEO;
-    // stage 3: queue of the outputs that sit on a rounding tie (re-evaluated in float64 after the task loop, all lanes
-    // busy, instead of one lane at a time inside it); over the dead LUT piece, behind D (and behind the late geometry of S = 4)
-    static constexpr int TQ_CAP = 2048;                           // (lerf_debug_set_tie_queue_cap lowers the part in use: tests)
-    static constexpr int OFF_TQ = GEO_EARLY ? OFF_D + up16(NH * 4) : END3;
-    static_assert(OFF_TQ + TQ_CAP * 4 <= OFF_X + PIECE_LDS, "tie queue fits under the piece");
-    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-    static constexpr int LDS_BYTES = cmax(END1, cmax(END2, END3)) + 512;  // + small control block
-    static constexpr int OFF_CTL = LDS_BYTES - 512;
-};
-
-struct Params {
-    const uint8_t* img; int64_t in_sn;
-    uint8_t* out; int64_t out_sn;
-    int H, W, oH, oW, tiles_y, tiles_x;
-    const uint8_t* pack;             // fused LUT pack (see lerf_fused_lutpack_*)
-    const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
-    const double* dis_r64; const double* dis_c64;      // tie guard (may be NULL: guard off)
-    float max_sigma;
-    int s2off[6][6];                 // stage-2 LUT l: feat-tile byte offsets of pixels b,c,d for rotations par, par+2
-    uint32_t* emit; int64_t emit_sn;   // EMIT kernels: packed stage outputs, frame stride in dwords
-    uint8_t* feat; int64_t feat_sn;    // two-launch path: stage-1 output [N][H][W][3] between s1_kernel and the FROM_FEAT kernel
-    unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
-    int tq_cap;                      // stage-3 tie queue entries in use (<= Dims::TQ_CAP; lerf_debug_set_tie_queue_cap)
-};
-
-#ifdef LERF_STAMPS
-#define LERF_STAMP(k) do { if (tid == 0) P.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define LERF_STAMP_ADD(k, t0) do { if (tid == 0) P.stamps[(size_t)blockIdx.x * 16 + (k)] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
-#define LERF_NOW() __builtin_amdgcn_s_memtime()
-#else
-#define LERF_STAMP(k) do {} while (0)
-#define LERF_STAMP_ADD(k, t0) do {} while (0)
-#define LERF_NOW() 0ull
-#endif
-
-// byte offsets of the 3 non-centre pixels of (mode, rot) in a u8 tile of pitch P
-struct Off3 { int o[3]; };
-template <int P>
-__host__ __device__ constexpr Off3 tile_offsets(char mode, int rot) {
-    int dy[4] = {0, 0, 0, 0}, dx[4] = {0, 0, 0, 0};
-    switch (mode) {
-        case 's': dy[1] = 0; dx[1] = 1; dy[2] = 1; dx[2] = 0; dy[3] = 1; dx[3] = 1; break;
-        case 'c': dy[1] = 0; dx[1] = 1; dy[2] = 0; dx[2] = 2; dy[3] = 0; dx[3] = 3; break;
-        default:  dy[1] = 1; dx[1] = 1; dy[2] = 2; dx[2] = 2; dy[3] = 3; dx[3] = 3; break;   // 't'
-    }
-    Off3 r{};
-    for (int k = 1; k < 4; ++k) {
-        int y = dy[k], x = dx[k];
-        for (int i = 0; i < (rot & 3); ++i) { int t = y; y = x; x = -t; }
-        r.o[k - 1] = y * P + x * CH;
-    }
-    return r;
-}
-
-// ---------------------------------------------------------------------------
-// simplex walk (index/weight computation only).  Keys are (LSB << 16) | axis stride so that one unsigned sort orders
-// the four axes by decreasing LSB (ties: zero weight, any order).  STRIDE_SCALE = bytes per LUT entry, folded into
-// the strides so the indices are byte offsets.
-//
-// Instruction budget (gfx950 issues v_and/or/add/sub/lshr in ~2.4 cycles per wave64, every 3-operand or min/max/
-// shift-left/24-bit-multiply op in ~4.3: profiles/r01_valu_instruction_rates.txt), per lookup:
-//   keys      3 x (v_and + v_lshl_or)                       the centre key is shared by the rotations of a position
-//   sort      7 three-input ops  m = max3(a,b,c)  e = med3(a,b,c)  n = min3(a,b,c)
-//                                s0 = max(m,d)  s1 = med3(m,e,d)  s2 = med3(e,n,d)  s3 = min(n,d)
-//             instead of the 10 of a 5-comparator network
-//   indices   the walk ends at base + (all four strides), a constant: vertex 4 is an immediate offset on vertex 0 and
-//             vertex 3 = vertex 4 - stride(s3), so only s0, s1, s3 contribute an AND + ADD/SUB (s2 is needed for its
-//             LSB alone)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-// (f << 16) | stride in one instruction (the compiler prefers shift-left + and + or)
-__device__ __forceinline__ unsigned make_key(unsigned f, unsigned stride) {
-    unsigned r;
-    asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(f), "s"(stride));
-    return r;
-}
-
-// LDS accesses by 32-bit LDS address.  `smem` is a link-time symbol: pointer arithmetic on it leaves one "+ smem" per
-// distinct address chain in the instruction stream (v_add 0); folding the table's LDS address into the walk's base
-// index once per position removes them, and constant parts still fold into the DS immediate offset.
-typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
-typedef __attribute__((address_space(3))) const int8_t lds_ci8_t;
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-// OFF is applied as a constant element index so that it lands in the DS immediate offset
-template <int OFF = 0>
-__device__ __forceinline__ uint32_t lds_ld32(uint32_t a) { return ((lds_cu32_t*)a)[OFF / 4]; }
-template <int OFF = 0>
-__device__ __forceinline__ int lds_ldi8(uint32_t a) { return (int)((lds_ci8_t*)a)[OFF]; }
-
-// A tile pixel is needed twice: its LSB in bits 16..19 of the sort key and its MSB as an index digit.  ds_read_u8_d16_hi
-// returns the byte in bits 16..23 (v << 16 for free; what it leaves in the low half is not relied upon), so that
-//   key = (r & 0x000F0000) | stride   one v_and_or_b32          msb = r >> 20   one v_lshrrev_b32
-// instead of v_and + v_lshl_or + v_lshrrev on a zero-extended byte.  The compiler does not track inline-asm LDS
-// loads: pixels_ready() waits for them (it names the registers so that every use is ordered behind it).
-__device__ __forceinline__ uint32_t lds_pixel_hi(uint32_t addr) {
-    uint32_t r;
-    asm volatile("ds_read_u8_d16_hi %0, %1" : "=v"(r) : "v"(addr));
-    return r;
-}
-template <int OFF>
-__device__ __forceinline__ uint32_t lds_pixel_hi_off(uint32_t addr) {
-    uint32_t r;
-    asm volatile("ds_read_u8_d16_hi %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
-}
-__device__ __forceinline__ unsigned key_of(uint32_t r, unsigned stride) {
-    unsigned k;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(k) : "v"(r), "s"(0x000F0000u), "v"(stride));
-    return k;
-}
-__device__ __forceinline__ unsigned msb_of(uint32_t r) { return r >> 20; }
-
-template <int STRIDE_SCALE>
-struct Walk {
-    static constexpr int ALL = (kStrideA + kStrideB + kStrideC + kStrideD) * STRIDE_SCALE;   // vertex 4 - vertex 0
-    int i0, i1, i2, i3m;        // byte offsets of vertices 0, 1, 2 and (vertex 3 - ALL); vertex 4 = i0 + ALL
-    unsigned f0, f1, f2, f3;    // sorted LSBs
-    // vertex n = address a(n) + constant c(n): the constant goes into the DS immediate offset
-    __device__ __forceinline__ uint32_t a(int n) const { return (uint32_t)(n == 0 ? i0 : n == 1 ? i1 : n == 2 ? i2 : n == 3 ? i3m : i0); }
-    static constexpr int c(int n) { return n >= 3 ? ALL : 0; }
-    __device__ __forceinline__ uint32_t ld32(int n) const { return n >= 3 ? lds_ld32<ALL>(a(n)) : lds_ld32<0>(a(n)); }
-    __device__ __forceinline__ int ldi8(int n) const { return n >= 3 ? lds_ldi8<ALL>(a(n)) : lds_ldi8<0>(a(n)); }
-};
-
-// ka = key of the centre pixel, basea = its MSB contribution to the index (both shared by the rotations of a position);
-// rb, rc, rd = the other three pixels as lds_pixel_hi() returned them; sb, sc, sd = the axis strides (bytes) in VGPRs
-template <int STRIDE_SCALE>
-__device__ __forceinline__ Walk<STRIDE_SCALE> simplex_walk(unsigned ka, int basea, uint32_t rb, uint32_t rc, uint32_t rd,
-                                                           unsigned sb, unsigned sc, unsigned sd) {
-    Walk<STRIDE_SCALE> W;
-    const unsigned kb = key_of(rb, sb), kc = key_of(rc, sc), kd = key_of(rd, sd);
-    // base index, Horner over the MSBs: ((b * 17 + c) * 17 + d) * scale + a-part
-    const unsigned t = __umul24(__umul24(msb_of(rb), (unsigned)kL) + msb_of(rc), (unsigned)kL) + msb_of(rd);
-    W.i0 = basea + (int)(t * STRIDE_SCALE);
-    const unsigned m = umax3(ka, kb, kc), e = umed3(ka, kb, kc), n = umin3(ka, kb, kc);
-    const unsigned s0 = m > kd ? m : kd;
-    const unsigned s1 = umed3(m, e, kd);
-    const unsigned s2 = umed3(e, n, kd);
-    const unsigned s3 = n < kd ? n : kd;
-    W.i1 = W.i0 + (int)(s0 & 0xFFFFu);
-    W.i2 = W.i1 + (int)(s1 & 0xFFFFu);
-    W.i3m = W.i0 - (int)(s3 & 0xFFFFu);
-    W.f0 = s0 >> 16; W.f1 = s1 >> 16; W.f2 = s2 >> 16; W.f3 = s3 >> 16;
-    return W;
-}
-
-// global -> LDS copy of `bytes` (rounded up to 16) by the whole workgroup; every load of a
-// thread is issued before its first LDS write so the L2 latency is paid once per copy
-template <int BYTES>
-struct Stage16 {
-    static constexpr int n = (BYTES + 15) >> 4;
-    static constexpr int FULL = n / NT;       // iterations every thread takes part in
-    static constexpr int TAIL = n - FULL * NT;
-    uint4 r[FULL];
-    uint4 rt;
-    __device__ __forceinline__ void load(const uint8_t* __restrict__ src, int tid) {
-        const uint4* s = reinterpret_cast<const uint4*>(src);
-#pragma unroll
-        for (int i = 0; i < FULL; ++i) r[i] = s[tid + i * NT];
-        rt = make_uint4(0, 0, 0, 0);
-        if (TAIL > 0 && tid < TAIL) rt = s[tid + FULL * NT];
-    }
-    __device__ __forceinline__ void store(uint8_t* dst, int tid) const {
-        uint4* d = reinterpret_cast<uint4*>(dst);
-#pragma unroll
-        for (int i = 0; i < FULL; ++i) d[tid + i * NT] = r[i];
-        if (TAIL > 0 && tid < TAIL) d[tid + FULL * NT] = rt;
-    }
-};
-
-template <int BYTES>
-__device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__ src, int tid) {
-    Stage16<BYTES> st;
-    st.load(src, tid);
-    st.store(dst, tid);
-}
-
-// One byte-LUT phase over a destination region of NDST px-ch positions (row pitch DP)
-// whose centres live in a source tile (pitch SP).  MODE/ROT0/NROT/RSTEP are static so
-// the neighbour offsets fold into DS immediates.  PHASE: 0 = first (store), 1 = add,
-// 2 = add and finalise with (div, bias) into `dst8`.
-// smallest (most negative) neighbour byte offset over the rotations of a phase: DS immediates are unsigned
-template <int SP>
-__host__ __device__ constexpr int min_tile_offset(char mode, int rot0, int nrot, int rstep) {
-    int m = 0;
-    for (int i = 0; i < nrot; ++i) {
-        const Off3 o = tile_offsets<SP>(mode, rot0 + i * rstep);
-        for (int k = 0; k < 3; ++k) m = o.o[k] < m ? o.o[k] : m;
-    }
-    return m;
-}
-// the eight neighbours of the 3x3 block around a pixel (byte offsets in a tile of pitch SP) and the index of an offset among them
-template <int SP>
-__host__ __device__ constexpr int block3_offset(int i) {
-    const int dy = i < 3 ? -1 : (i < 5 ? 0 : 1);
-    const int dx = i < 3 ? i - 1 : (i < 5 ? (i == 3 ? -1 : 1) : i - 6);
-    return dy * SP + dx * CH;
-}
-template <int SP>
-__host__ __device__ constexpr int block3_index(int off) {
-    for (int i = 0; i < 8; ++i)
-        if (block3_offset<SP>(i) == off) return i;
-    return 0;
-}
-template <int SP, char MODE, int ROT, int MINO>
-__device__ __forceinline__ void load_rotation(uint32_t base, uint32_t& rb, uint32_t& rc, uint32_t& rd) {
-    constexpr Off3 o = tile_offsets<SP>(MODE, ROT);
-    rb = lds_pixel_hi_off<o.o[0] - MINO>(base);
-    rc = lds_pixel_hi_off<o.o[1] - MINO>(base);
-    rd = lds_pixel_hi_off<o.o[2] - MINO>(base);
-}
-
-// NROT (2 or 4) lookups of one byte LUT around the pixel at LDS address `center`; lut_a = LDS address of the LUT.
-// Returns the numerator sum_rot sum_n w_n P_n (weights sum to 16 per lookup).
-template <int SP, char MODE, int ROT0, int NROT, int RSTEP>
-__device__ __forceinline__ int byte_lookups(uint32_t lut_a, uint32_t center) {
-    static_assert(NROT == 2 || NROT == 4, "rotation pairs or all four");
-    constexpr int MINO = min_tile_offset<SP>(MODE, ROT0, NROT, RSTEP);
-    // stage A: every pixel read of the NROT rotations (high-half loads, see lds_pixel_hi)
-    const uint32_t base = center + (uint32_t)MINO;
-    uint32_t ra = lds_pixel_hi_off<-MINO>(base);
-    uint32_t rb[4], rc[4], rd[4];
-    if constexpr (MODE == 's' && NROT == 4 && ROT0 == 0 && RSTEP == 1) {
-        // the four rotations of the 2x2 pattern cover the 3x3 block around the centre: its four edge neighbours are used
-        // by two rotations each, so 8 reads serve the 12 operands
-        uint32_t nb[8];
-        nb[0] = lds_pixel_hi_off<block3_offset<SP>(0) - MINO>(base); nb[1] = lds_pixel_hi_off<block3_offset<SP>(1) - MINO>(base);
-        nb[2] = lds_pixel_hi_off<block3_offset<SP>(2) - MINO>(base); nb[3] = lds_pixel_hi_off<block3_offset<SP>(3) - MINO>(base);
-        nb[4] = lds_pixel_hi_off<block3_offset<SP>(4) - MINO>(base); nb[5] = lds_pixel_hi_off<block3_offset<SP>(5) - MINO>(base);
-        nb[6] = lds_pixel_hi_off<block3_offset<SP>(6) - MINO>(base); nb[7] = lds_pixel_hi_off<block3_offset<SP>(7) - MINO>(base);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ra), "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3]), "+v"(nb[4]), "+v"(nb[5]), "+v"(nb[6]), "+v"(nb[7]));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const Off3 o = tile_offsets<SP>('s', r);
-            rb[r] = nb[block3_index<SP>(o.o[0])];
-            rc[r] = nb[block3_index<SP>(o.o[1])];
-            rd[r] = nb[block3_index<SP>(o.o[2])];
-        }
-    } else {
-    load_rotation<SP, MODE, ROT0, MINO>(base, rb[0], rc[0], rd[0]);
-    load_rotation<SP, MODE, ROT0 + RSTEP, MINO>(base, rb[1], rc[1], rd[1]);
-    if constexpr (NROT == 4) {
-        load_rotation<SP, MODE, ROT0 + 2 * RSTEP, MINO>(base, rb[2], rc[2], rd[2]);
-        load_rotation<SP, MODE, ROT0 + 3 * RSTEP, MINO>(base, rb[3], rc[3], rd[3]);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ra), "+v"(rb[0]), "+v"(rc[0]), "+v"(rd[0]), "+v"(rb[1]), "+v"(rc[1]), "+v"(rd[1]), "+v"(rb[2]),
-                       "+v"(rc[2]), "+v"(rd[2]), "+v"(rb[3]), "+v"(rc[3]), "+v"(rd[3]));
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra), "+v"(rb[0]), "+v"(rc[0]), "+v"(rd[0]), "+v"(rb[1]), "+v"(rc[1]), "+v"(rd[1]));
-    }
-    }
-    // stage B: walks
-    const unsigned sa = kStrideA, sb = kStrideB, sc = kStrideC, sd = kStrideD;
-    const unsigned ka = key_of(ra, sa);
-    const int basea = (int)(__umul24(msb_of(ra), kStrideA) + lut_a);      // LDS address of the base corner
-    Walk<1> W[NROT];
-#pragma unroll
-    for (int i = 0; i < NROT; ++i) W[i] = simplex_walk<1>(ka, basea, rb[i], rc[i], rd[i], sb, sc, sd);
-    // stage C: all LUT gathers in flight together
-    int e[NROT][5];
-#pragma unroll
-    for (int i = 0; i < NROT; ++i)
-#pragma unroll
-        for (int n = 0; n < 5; ++n) e[i][n] = W[i].ldi8(n);
-    __builtin_amdgcn_sched_barrier(0);
-    // stage D: sum_n w_n P_n = 16 P_0 + sum_n f_n (P_{n+1} - P_n)   (w_0 = 16 - f_0, w_n = f_{n-1} - f_n, w_4 = f_3):
-    //          four multiply-adds and four subtractions per lookup instead of five weights + five multiply-adds
-    int acc = 0, sum0 = 0;
-#pragma unroll
-    for (int i = 0; i < NROT; ++i) {
-        sum0 += e[i][0];
-        acc += __mul24((int)W[i].f0, e[i][1] - e[i][0]);
-        acc += __mul24((int)W[i].f1, e[i][2] - e[i][1]);
-        acc += __mul24((int)W[i].f2, e[i][3] - e[i][2]);
-        acc += __mul24((int)W[i].f3, e[i][4] - e[i][3]);
-    }
-    return acc + kQ * sum0;
-}
-
-// position p of a region (pitch DPc px-ch per row, origin (y0g,x0g) in the frame) ->
-// byte address of its clamped centre in the source tile (pitch SP, origin (sy0g,sx0g))
-template <int DPc, int SP>
-__device__ __forceinline__ int center_addr(int p, int y0g, int x0g, int sy0g, int sx0g, int H, int W, bool* inside) {
-    int ry = p / DPc;
-    int r3 = p - ry * DPc;
-    if (H < 0) {                      // interior tile (caller passes H = -1): nothing to clamp
-        if (inside) *inside = true;
-        return (ry + (y0g - sy0g)) * SP + r3 + (x0g - sx0g) * CH;
-    }
-    int rx = r3 / CH;
-    int c = r3 - rx * CH;
-    int gy = y0g + ry, gx = x0g + rx;
-    int cy = clampi(gy, 0, H - 1), cx = clampi(gx, 0, W - 1);
-    if (inside) *inside = (cy == gy) && (cx == gx);
-    return (cy - sy0g) * SP + (cx - sx0g) * CH + c;
-}
-
-// SKIP_OUTSIDE: positions outside the frame are not evaluated (callers that never read them: s1_kernel).
-// Interior tiles (H < 0, a workgroup-uniform fact) take a loop of their own: a scalar trip count and no clamping or
-// frame tests, instead of a per-position interior branch, a vector loop condition and an inside-the-frame mask.
-template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, int PHASE>
-__device__ __forceinline__ void byte_position(uint32_t lut_a, uint32_t center, int16_t* acc16, uint8_t* dst8, int p, int div, int bias) {
-    int v = byte_lookups<SP, MODE, ROT0, NROT, RSTEP>(lut_a, center);
-    if (PHASE != 0) v += (int)acc16[p];
-    if (PHASE == 2)
-        dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
-    else
-        acc16[p] = (int16_t)v;
-}
-template <int NDST, int DPc, int SP, char MODE, int ROT0, int NROT, int RSTEP, int PHASE, bool SKIP_OUTSIDE = false>
-__device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src, int16_t* acc16, uint8_t* dst8,
-                                           int y0g, int x0g, int sy0g, int sx0g, int H, int W, int div, int bias,
-                                           int tid) {
-    const uint32_t lut_a = lds_addr(lut), src_a = lds_addr(src);
-    if (H < 0) {
-        constexpr int FULL = NDST / NT, TAIL = NDST - FULL * NT;
-        const uint32_t org = src_a + (uint32_t)((y0g - sy0g) * SP + (x0g - sx0g) * CH);
-#pragma unroll 1
-        for (int k = 0; k < FULL; ++k) {
-            const int p = tid + k * NT;
-            const int ry = p / DPc;
-            byte_position<NDST, DPc, SP, MODE, ROT0, NROT, RSTEP, PHASE>(lut_a, org + (uint32_t)(ry * (SP - DPc) + p), acc16, dst8, p, div, bias);
-        }
-        if (TAIL > 0 && tid < TAIL) {
-            const int p = tid + FULL * NT;
-            const int ry = p / DPc;
-            byte_position<NDST, DPc, SP, MODE, ROT0, NROT, RSTEP, PHASE>(lut_a, org + (uint32_t)(ry * (SP - DPc) + p), acc16, dst8, p, div, bias);
-        }
-        return;
-    }
-    for (int p = tid; p < NDST; p += NT) {
-        bool in = true;
-        int a = center_addr<DPc, SP>(p, y0g, x0g, sy0g, sx0g, H, W, SKIP_OUTSIDE ? &in : nullptr);
-        if (SKIP_OUTSIDE && !in) continue;
-        byte_position<NDST, DPc, SP, MODE, ROT0, NROT, RSTEP, PHASE>(lut_a, src_a + (uint32_t)a, acc16, dst8, p, div, bias);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// stage 3 helpers
-// ---------------------------------------------------------------------------
-// first i in [0,n) with a[i] >= key (a is non-decreasing), all 64 lanes of a wave cooperating:
-// 64-way splits, so a table of 8k entries needs three dependent loads instead of thirteen
-__device__ __forceinline__ int wave_lower_bound(const int* __restrict__ a, int n, int key, int lane) {
-    int lo = 0, hi = n;
-    while (hi - lo > 64) {
-        const int step = (hi - lo + 63) >> 6;
-        const int idx = lo + lane * step;
-        const bool less = idx < hi && a[idx] < key;
-        const int cnt = __popcll(__ballot(less));          // monotone: the first cnt probes are < key
-        const int nlo = cnt > 0 ? lo + (cnt - 1) * step + 1 : lo;
-        const int nhi = cnt < 64 ? min(hi, lo + cnt * step) : hi;
-        lo = nlo;
-        hi = nhi;
-    }
-    const int idx = lo + lane;
-    const bool less = idx < hi && a[idx] < key;
-    return lo + __popcll(__ballot(less));
-}
-
-
-// ---- input tile -> LDS.  Interior tiles whose rows all start at the same offset from a 4-byte boundary (frame pitch
-//      and frame stride multiples of 4: every RGB frame whose width is a multiple of 4) are fetched as aligned dwords
-//      and land in LDS with that offset as a phase (returned); the other tiles go byte by byte with clamped
-//      coordinates (np.pad(..., 'edge') in every rotated frame).  Every load of a thread is issued before its first
-//      LDS store (one L2/HBM latency); `between()` runs while the loads are in flight.
-template <int IY, int IPB, int IP, typename F>
-__device__ __forceinline__ int load_input_tile(uint8_t* Ct, const uint8_t* __restrict__ img, const Params& P, int H, int W, int iy0,
-                                               int ix0, bool interior, int tid, F between) {
-    int cphase = 0;
-    const int64_t row0 = ((int64_t)iy0 * W + ix0) * CH;                     // first byte of the region in the frame
-    const uintptr_t a0 = reinterpret_cast<uintptr_t>(img) + (uintptr_t)row0;
-    const bool dwords = interior && ((W * CH) & 3) == 0 && (P.in_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.img) & 3) == 0 &&
-                        (iy0 + IY < P.H || (ix0 * CH - (int)(a0 & 3)) + IP <= W * CH);   // never read past the frame
-    if (dwords) {
-        cphase = (int)(a0 & 3);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a0 - (uintptr_t)cphase);
-        constexpr int RD = IP / 4, ND = IY * RD, KD = (ND + NT - 1) / NT;
-        const int rowdw = (W * CH) >> 2;
-        uint32_t v[KD];
-#pragma unroll
-        for (int k = 0; k < KD; ++k) {
-            const int p = min(tid + k * NT, ND - 1);
-            const int ry = p / RD;
-            v[k] = __builtin_nontemporal_load(&src[(int64_t)ry * rowdw + (p - ry * RD)]);   // read once: leave the L2 to the LUT pack
-        }
-        between();
-#pragma unroll
-        for (int k = 0; k < KD; ++k) {
-            const int p = tid + k * NT;
-            if (p < ND) reinterpret_cast<uint32_t*>(Ct)[p] = v[k];
-        }
-    } else {
-        constexpr int NB = IY * IPB, KI = (NB + NT - 1) / NT;
-        uint8_t v[KI];
-#pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int p = min(tid + k * NT, NB - 1);
-            int ry = p / IPB;
-            int r3 = p - ry * IPB;
-            int rx = r3 / CH;
-            int c = r3 - rx * CH;
-            int gy = clampi(iy0 + ry, 0, H - 1), gx = clampi(ix0 + rx, 0, W - 1);
-            v[k] = img[((int64_t)gy * W + gx) * CH + c];
-        }
-        between();
-#pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int p = tid + k * NT;
-            if (p < NB) {
-                const int ry = p / IPB;
-                Ct[ry * IP + (p - ry * IPB)] = v[k];
-            }
-        }
-    }
-    return cphase;
-}
-
-// Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8; an affinity, not a guarantee -- nothing
-// depends on it but speed).  Handing every XCD a CONTIGUOUS eighth of the (frame, tile) sequence instead of every eighth tile
-// keeps the tiles that run side by side on one XCD neighbours in the frame: their input / feat halos and the LUT pieces
-// they ask for at the same time meet in that XCD's own L2.  Measured: L2 hit rate 94.8 -> 97.5 %, HBM fetch of the two launches
-// 169 -> 73 MB per step, +1.3 % throughput.  A bijection of [0, total) for any total.
-// Small launches (under four rounds of workgroups) keep the linear order: their cheap partial tiles at the end of the
-// sequence would all land on the last XCD (a 300-tile strip launch took 0.35 instead of 0.27 ms).
-__device__ __forceinline__ int xcd_order(int b, int total) {
-    if (total < 1024) return b;
-    const int x = b & 7, j = b >> 3, q = total >> 3, r = total & 7;
-    return x * q + (x < r ? x : r) + j;
-}
-
-// ---------------------------------------------------------------------------
-// the kernel
-// ---------------------------------------------------------------------------
-// EMIT = false: the whole SR path.  EMIT = true: stages 1+2 only; the tile's own 64x64 block of
-// (hq0,hq1,hq2,feat) dwords goes to P.emit ([H][W][3] uint32) for the warp kernels / the stage API.
-// FROM_FEAT = true: stage 1 has been run by s1_kernel over the whole batch; the feat tile (with its halo) is read
-// from P.feat instead of being recomputed from the input tile -- stage 1 then costs 64x64 instead of 72x72 positions
-// per tile (-21 % of its work) for 6 bytes of extra HBM traffic per LR pixel.
-template <int S, int KIND, bool EMIT, bool FROM_FEAT = false>
-__global__ void __launch_bounds__(NT)
-sr_fused_kernel(Params P) {
-    using D = Dims<S>;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    int bid = xcd_order((int)blockIdx.x, (int)gridDim.x);
-    const int tiles = P.tiles_y * P.tiles_x;
-    const int frame = bid / tiles;
-    bid -= frame * tiles;
-    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
-    const int ty0 = tyi * TH, tx0 = txi * TW;
-    const int H = P.H, W = P.W;
-    const uint8_t* __restrict__ img = P.img + frame * P.in_sn;
-    uint8_t* __restrict__ outp = P.out + frame * P.out_sn;
-
-    // region origins in frame coordinates
-    const int hy0 = ty0 - D::R3, hx0 = tx0 - D::R3;
-    const int fy0 = hy0 - R2, fx0 = hx0 - R2;
-    const int iy0 = fy0 - R1, ix0 = fx0 - R1;
-
-    uint8_t* Bt = smem + D::OFF_B;
-    int* ctl = reinterpret_cast<int*>(smem + D::OFF_CTL);
-    // interior tile: the whole input region lies inside the frame, so no coordinate is ever clamped and the
-    // centre addresses reduce to a multiply-add (center_addr's H < 0 path); ~80 % of the tiles of a 1080p frame
-    const bool interior = FROM_FEAT ? (fy0 >= 0 && fx0 >= 0 && fy0 + D::FY <= P.H && fx0 + D::FX <= P.W)
-                                    : (iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= P.H && ix0 + D::IX <= P.W);
-    const int Hc = interior ? -1 : P.H, Wc = P.W;
-
-    int* g_lr = reinterpret_cast<int*>(smem + D::OFF_GEO);
-    float* g_dr = reinterpret_cast<float*>(g_lr + D::GEO_ROWS);
-    int* g_lc = reinterpret_cast<int*>(g_dr + D::GEO_ROWS * S);
-    float* g_dc = reinterpret_cast<float*>(g_lc + D::GEO_ROWS);
-    // owned output rows / columns: four wave-parallel searches in the global tables
-    auto geo_search = [&]() {
-        if (wave < 4) {
-            const bool rows = wave < 2;
-            const int* tab = rows ? P.left_r : P.left_c;
-            const int n = rows ? P.oH : P.oW;
-            const int ti = rows ? tyi : txi, tn = rows ? P.tiles_y : P.tiles_x, t0 = rows ? ty0 : tx0;
-            int r;
-            if (!(wave & 1)) r = ti == 0 ? 0 : wave_lower_bound(tab, n, t0 - D::R3, lane);
-            else r = ti == tn - 1 ? n : wave_lower_bound(tab, n, t0 + (rows ? TH : TW) - D::R3, lane);
-            if (lane == 0) ctl[16 + wave] = r;
-        }
-    };
-    // tables of the owned block into LDS; LeRF-G distances pre-multiplied by (max_sigma/255)*sqrt(0.5 log2 e)
-    auto geo_stage = [&]() {
-        const int gi0 = ctl[16], gi1 = ctl[17], gj0 = ctl[18], gj1 = ctl[19];
-        const float gscale = KIND == LERF_KIND_GAUSS ? s3::gauss_scale(P.max_sigma) : 1.0f;
-        for (int e = tid; e < gi1 - gi0; e += NT) {
-            g_lr[e] = P.left_r[gi0 + e] - hy0;
-#pragma unroll
-            for (int b = 0; b < S; ++b) g_dr[e * S + b] = P.dis_r[(gi0 + e) * S + b] * gscale;
-        }
-        for (int e = tid; e < gj1 - gj0; e += NT) {
-            g_lc[e] = P.left_c[gj0 + e] - hx0;
-#pragma unroll
-            for (int a = 0; a < S; ++a) g_dc[e * S + a] = P.dis_c[(gj0 + e) * S + a] * gscale;
-        }
-    };
-
-    LERF_STAMP(0);
-#ifdef LERF_STAMPS
-    if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
-#endif
-    if (!FROM_FEAT) {
-    // ---- input tile (load_input_tile), the geometry search riding behind its loads
-    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, P, H, W, iy0, ix0, interior, tid,
-                                                             [&]() { if (D::GEO_EARLY && !EMIT) geo_search(); });
-
-    // ---- stage 1: three byte LUTs, 4 rotations each (eval_lut_sr.py:541-577)
-    {
-        const uint8_t* Ct = smem + D::OFF_C + cphase;
-        int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
-        int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
-        const int div1 = kQ * 3;
-        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
-        __syncthreads();
-        if (D::GEO_EARLY && !EMIT) geo_stage();            // search results are in ctl; its loads hide behind phase s
-        LERF_STAMP(1);
-        // the next LUT rides in registers behind the lookups (explicit scalars: an array/struct that lives
-        // across the position loop ends up in scratch)
-        constexpr int L1N = (LERF_LUT_ENTRIES + 15) / 16, L1TAIL = L1N - 5 * NT;
-        static_assert(L1TAIL > 0 && L1TAIL <= NT, "stage-1 LUT = 5 full uint4 rounds + a tail");
-        uint4 n0, n1, n2, n3, n4, n5 = make_uint4(0, 0, 0, 0);
-#define LERF_S1_LOAD(SRC)                                                                          \
-        do {                                                                                       \
-            const uint4* s_ = reinterpret_cast<const uint4*>(SRC);                                 \
-            n0 = s_[tid]; n1 = s_[tid + NT]; n2 = s_[tid + 2 * NT]; n3 = s_[tid + 3 * NT]; n4 = s_[tid + 4 * NT]; \
-            if (tid < L1TAIL) n5 = s_[tid + 5 * NT];                                               \
-        } while (0)
-#define LERF_S1_STORE()                                                                            \
-        do {                                                                                       \
-            uint4* d_ = reinterpret_cast<uint4*>(smem + D::OFF_LUT);                               \
-            d_[tid] = n0; d_[tid + NT] = n1; d_[tid + 2 * NT] = n2; d_[tid + 3 * NT] = n3; d_[tid + 4 * NT] = n4; \
-            if (tid < L1TAIL) d_[tid + 5 * NT] = n5;                                               \
-        } while (0)
-        LERF_S1_LOAD(P.pack + 1 * LUT_PAD);
-        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
-        __syncthreads();
-        LERF_STAMP(2);
-        LERF_S1_STORE();
-        __syncthreads();
-        LERF_STAMP(3);
-        LERF_S1_LOAD(P.pack + 2 * LUT_PAD);
-        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
-        __syncthreads();
-        LERF_STAMP(4);
-        LERF_S1_STORE();
-        __syncthreads();
-        LERF_STAMP(5);
-        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2>(lut, Ct, acc, Bt, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
-        __syncthreads();
-        LERF_STAMP(6);
-    }
-    } else {
-        // ---- feat tile (with its halo) from the stage-1 launch; out-of-frame positions take the clamped pixel,
-        //      which is what stage 1 evaluates for them
-        const uint8_t* __restrict__ fsrc = P.feat + frame * P.feat_sn;
-        const bool dwords = interior && (D::FP & 3) == 0 && ((W * CH) & 3) == 0 && (P.feat_sn & 3) == 0 &&
-                            (reinterpret_cast<uintptr_t>(P.feat) & 3) == 0 && ((fx0 * CH) & 3) == 0;
-        if (dwords) {
-            constexpr int RD = D::FP / 4, ND = D::FY * RD, KD = (ND + NT - 1) / NT;
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(fsrc + ((int64_t)fy0 * W + fx0) * CH);
-            const int rowdw = (W * CH) >> 2;
-            uint32_t v[KD];
-#pragma unroll
-            for (int k = 0; k < KD; ++k) {
-                const int p = min(tid + k * NT, ND - 1);
-                const int ry = p / RD;
-                v[k] = __builtin_nontemporal_load(&src[(int64_t)ry * rowdw + (p - ry * RD)]);
-            }
-            if (D::GEO_EARLY && !EMIT) geo_search();
-#pragma unroll
-            for (int k = 0; k < KD; ++k) {
-                const int p = tid + k * NT;
-                if (p < ND) reinterpret_cast<uint32_t*>(Bt)[p] = v[k];
-            }
-        } else {
-            constexpr int KI = (D::NF + NT - 1) / NT;
-            uint8_t v[KI];
-#pragma unroll
-            for (int k = 0; k < KI; ++k) {
-                const int p = min(tid + k * NT, D::NF - 1);
-                const int ry = p / D::FP;
-                const int r3 = p - ry * D::FP;
-                const int rx = r3 / CH;
-                const int gy = clampi(fy0 + ry, 0, H - 1), gx = clampi(fx0 + rx, 0, W - 1);
-                v[k] = fsrc[((int64_t)gy * W + gx) * CH + (r3 - rx * CH)];
-            }
-            if (D::GEO_EARLY && !EMIT) geo_search();
-#pragma unroll
-            for (int k = 0; k < KI; ++k) {
-                const int p = tid + k * NT;
-                if (p < D::NF) Bt[p] = v[k];
-            }
-        }
-        __syncthreads();
-        if (D::GEO_EARLY && !EMIT) geo_stage();
-        LERF_STAMP(6);
-    }
-
-    uint32_t* Dt = reinterpret_cast<uint32_t*>(smem + D::OFF_D);
-
-    if (KIND == LERF_KIND_LINEAR) {
-        // ---- stage 2, LeRF-L: six byte LUTs (mode x rotation parity), 2 rotations each (eval_lut_sr.py:579-628)
-        int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
-        int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
-        uint8_t* hq8 = smem + D::OFF_C;                   // input tile is dead: reuse for the u8 hyper values
-        const uint8_t* s2 = P.pack + 3 * LUT_PAD;
-        const int div2 = kQ * 12;
-        // every LUT but the first rides in registers behind the lookups of the previous one (as in stage 1), so that only the
-        // LDS store of a LUT, not its L2 round trip, stands between two phases
-        constexpr int L2N = (LERF_LUT_ENTRIES + 15) / 16, L2TAIL = L2N - 5 * NT;
-        static_assert(L2TAIL > 0 && L2TAIL <= NT, "byte LUT = 5 full uint4 rounds + a tail");
-        uint4 m0, m1, m2, m3, m4, m5 = make_uint4(0, 0, 0, 0);
-#define LERF_L2_LOAD(IDX)                                                                          \
-        do {                                                                                       \
-            const uint4* s_ = reinterpret_cast<const uint4*>(s2 + (IDX) * LUT_PAD);                \
-            m0 = s_[tid]; m1 = s_[tid + NT]; m2 = s_[tid + 2 * NT]; m3 = s_[tid + 3 * NT]; m4 = s_[tid + 4 * NT]; \
-            if (tid < L2TAIL) m5 = s_[tid + 5 * NT];                                               \
-        } while (0)
-#define LERF_L2_STORE()                                                                            \
-        do {                                                                                       \
-            uint4* d_ = reinterpret_cast<uint4*>(smem + D::OFF_LUT);                               \
-            d_[tid] = m0; d_[tid + NT] = m1; d_[tid + 2 * NT] = m2; d_[tid + 3 * NT] = m3; d_[tid + 4 * NT] = m4; \
-            if (tid < L2TAIL) d_[tid + 5 * NT] = m5;                                               \
-        } while (0)
-#define LERF_L2(NEXT, MODE, PAR, PH)                                                                       \
-        if ((NEXT) < 6) LERF_L2_LOAD(NEXT);                                                                \
-        byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, Hc, Wc, div2, 127, tid); \
-        __syncthreads();                                                                                   \
-        if ((NEXT) < 6) {                                                                                  \
-            LERF_L2_STORE();                                                                               \
-            __syncthreads();                                                                               \
-        }
-        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, s2 + 0 * LUT_PAD, tid);
-        __syncthreads();
-        LERF_L2(1, 's', 0, 0)
-        LERF_L2(2, 's', 1, 1)
-        LERF_L2(3, 'c', 0, 1)
-        LERF_L2(4, 'c', 1, 1)
-        LERF_L2(5, 't', 0, 1)
-        LERF_L2(6, 't', 1, 2)
-#undef LERF_L2
-#undef LERF_L2_LOAD
-#undef LERF_L2_STORE
-        // pack (alpha_q, 0, 0, feat-or-0) dwords for stage 3
-        uint32_t tmp[(D::NH + NT - 1) / NT];
-#pragma unroll
-        for (int k = 0; k < (D::NH + NT - 1) / NT; ++k) {
-            int p = k * NT + tid;
-            tmp[k] = 0;
-            if (p < D::NH) {
-                bool inside;
-                int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, &inside);
-                tmp[k] = (uint32_t)hq8[p] | ((inside ? (uint32_t)Bt[a] : 0u) << 24);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < (D::NH + NT - 1) / NT; ++k) {
-            int p = k * NT + tid;
-            if (p < D::NH) Dt[p] = tmp[k];
-        }
-    } else {
-        // ---- stage 2, LeRF-G: packed 3-channel LUT pieces, pixels binned by the top-axis level of their centre
-        constexpr int MAXR = D::MAXR;
-        uint16_t* lst = reinterpret_cast<uint16_t*>(smem + D::OFF_LST);
-        int* tab = reinterpret_cast<int*>(smem + D::OFF_TAB);                // [wave][bin] counts
-        // Counting sort of the hyper-region positions by bin, every bin padded to whole waves: list entry i belongs to
-        // slot round i / NT of thread i % NT, so a 64-entry chunk (one wave in one round) never mixes bins.  One barrier:
-        // per-thread histograms -> wave scans -> the 16 x 4 wave totals through LDS -> every wave derives its own bases.
-        // Positions of the hyper region that lie outside the frame (tiles on the right / bottom edge, the halo ring of edge
-        // tiles) are not looked up at all: stage 3 reads them as replicas of the clamped position (edge-padded hyper maps,
-        // zero image), which fill_outside() below copies once the in-frame values exist.  A 28-row strip tile or the
-        // last tile row of a 1080-row frame then costs what its in-frame part costs.
-        for (int i = tid; i < MAXR * NT / 2; i += NT) reinterpret_cast<uint32_t*>(lst)[i] = 0xFFFFFFFFu;
-        constexpr int KH = (D::NH + NT - 1) / NT;
-        static_assert(KH <= 15 && NBIN <= 4 && NW == 16, "nibble counts, one byte field per bin, one lane per (wave, bin)");
-        uint32_t qlo = 0, qhi = 0;              // 4 bits per owned position p = tid * KH + k: its bin, 15 = not looked up (thread-major lists = position order)
-        uint32_t xa, xb;                        // per-thread counts of bins (0, 1) and (2, 3), two 16-bit fields per register
-        {
-            uint32_t hist = 0;                  // one byte per bin
-#pragma unroll
-            for (int k = 0; k < KH; ++k) {
-                const int p = tid * KH + k;
-                uint32_t q = 15;
-                if (p < D::NH) {
-                    bool in = true;
-                    const int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, &in);
-                    if (in) q = bin_of_level((uint32_t)Bt[a] >> 4);
-                }
-                if (k < 8) qlo |= q << (4 * k); else qhi |= q << (4 * (k - 8));
-                hist += q < NBIN ? 1u << (8 * q) : 0u;
-            }
-            xa = (hist & 0xFFu) | ((hist << 8) & 0xFF0000u);
-            xb = ((hist >> 16) & 0xFFu) | ((hist >> 8) & 0xFF0000u);
-        }
-        // wave-inclusive scans of the packed count pairs (row shifts + the two row broadcasts of the DPP unit)
-        auto wave_scan = [](uint32_t v) {
-            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1
-            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
-            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
-            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
-            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15
-            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31
-            return v;
-        };
-        const uint32_t ia = wave_scan(xa), ib = wave_scan(xb);
-        if (lane == 63) {
-            int* t = tab + wave * 4;
-            t[0] = (int)(ia & 0xFFFFu); t[1] = (int)(ia >> 16); t[2] = (int)(ib & 0xFFFFu); t[3] = (int)(ib >> 16);
-        }
-        __syncthreads();
-        // Every wave turns the 16 x 4 wave counts into what it needs itself (lane = w * 4 + b), in registers: the list base
-        // of each of its own bins, and -- the same in all waves -- each bin's first chunk and one past its last (a byte
-        // each) and the set of non-empty bins.  No second barrier, no table to read back.
-        uint32_t ne_bins, cs_pack, ce_pack;          // wave-uniform
-        uint32_t cur01, cur23;                       // this thread's list cursors, two 16-bit fields per register
-        {
-            const int bb = lane & 3;                             // lane = w * 4 + bb
-            const int c = tab[lane];
-            int incl = c;                                        // scan over the waves of a bin: lanes 4 apart
-#pragma unroll
-            for (int d = 4; d < 64; d <<= 1) {
-                const int up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
-            }
-            const int total = __shfl(incl, 60 + bb);
-            const int padded = (total + 63) & ~63;
-            int start = padded;                                  // scan over the bins: 4 neighbouring lanes
-#pragma unroll
-            for (int d = 1; d < 4; d <<= 1) {
-                const int up = __shfl_up(start, d, 4);
-                if (bb >= d) start += up;
-            }
-            start -= padded;
-            const int base = start + incl - c;                   // list base of (wave w, bin bb)
-            const int wl = __builtin_amdgcn_readfirstlane(wave) * 4;
-            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(base, wl), b1 = (uint32_t)__builtin_amdgcn_readlane(base, wl + 1),
-                           b2 = (uint32_t)__builtin_amdgcn_readlane(base, wl + 2), b3 = (uint32_t)__builtin_amdgcn_readlane(base, wl + 3);
-            const uint32_t ea = ia - xa, eb = ib - xb;           // counts of the lanes below
-            cur01 = ((b0 + (ea & 0xFFFFu)) & 0xFFFFu) | ((b1 + (ea >> 16)) << 16);
-            cur23 = ((b2 + (eb & 0xFFFFu)) & 0xFFFFu) | ((b3 + (eb >> 16)) << 16);
-            const int sc = start >> 6, ec = (start + padded) >> 6;           // chunks: < 256
-            cs_pack = (uint32_t)__builtin_amdgcn_readlane(sc, 0) | ((uint32_t)__builtin_amdgcn_readlane(sc, 1) << 8) |
-                      ((uint32_t)__builtin_amdgcn_readlane(sc, 2) << 16) | ((uint32_t)__builtin_amdgcn_readlane(sc, 3) << 24);
-            ce_pack = (uint32_t)__builtin_amdgcn_readlane(ec, 0) | ((uint32_t)__builtin_amdgcn_readlane(ec, 1) << 8) |
-                      ((uint32_t)__builtin_amdgcn_readlane(ec, 2) << 16) | ((uint32_t)__builtin_amdgcn_readlane(ec, 3) << 24);
-            ne_bins = (uint32_t)(__ballot(total > 0) & 0xFull);
-        }
-        // The next piece rides in registers behind the lookups of the current one: NSLAB x 16 bytes per thread.
-        uint4 pr[NSLAB];
-#pragma unroll
-        for (int i = 0; i < NSLAB; ++i) pr[i] = make_uint4(0, 0, 0, 0);
-        const uint8_t* s2p = P.pack + 3 * LUT_PAD;          // [LUT l][bin b][PIECE_BYTES], blocks pre-permuted
-        auto pre_load = [&](int l, int bq) {
-            const uint4* s_ = reinterpret_cast<const uint4*>(s2p + ((size_t)l * NBIN + bq) * PIECE_BYTES) + (wave * 64 + lane);
-#pragma unroll
-            for (int i = 0; i < NSLAB; ++i) pr[i] = s_[i * NT];
-        };
-        const int nbins = __builtin_popcount(ne_bins);
-        const int nph = nbins * 6;
-        if (nph > 0) pre_load(0, __builtin_ctz(ne_bins));      // in flight during the scatter and the slot set-up
-        {
-            // scatter: a position's list entry = the thread's cursor of its bin, which then moves on (registers only).
-            // The entry is the position's feat-tile ADDRESS (listed positions lie inside the frame, so it is the unclamped
-            // one: one increment per position, a row step every HP positions), which the slot set-up then reads back
-            // as it is -- no second address computation per slot.
-            const int p0 = tid * KH, ry0 = p0 / D::HP;
-            uint32_t col = (uint32_t)(p0 - ry0 * D::HP);
-            uint32_t ap = (uint32_t)((ry0 + R2) * D::FP + R2 * CH) + col;
-#pragma unroll
-            for (int k = 0; k < KH; ++k) {
-                const uint32_t q = k < 8 ? (qlo >> (4 * k)) & 0xFu : (qhi >> (4 * (k - 8))) & 0xFu;
-                if (q < NBIN) {
-                    const uint32_t pair = q < 2 ? cur01 : cur23;
-                    const uint32_t v = (q & 1u) ? pair >> 16 : pair & 0xFFFFu;
-                    lst[v] = (uint16_t)ap;
-                    const uint32_t inc = (q & 1u) ? 0x10000u : 1u;
-                    if (q < 2) cur01 += inc; else cur23 += inc;
-                }
-                ++ap;
-                if (++col == (uint32_t)D::HP) { col = 0; ap += (uint32_t)(D::FP - D::HP); }
-            }
-        }
-        __syncthreads();
-        // slots -> registers.  Per slot: the feat-tile address of its centre (16 bits, two slots per VGPR) and three
-        // 16-bit accumulators (accA: e0 | e2 << 16; accB: e1).  Padding lanes of a partly filled wave repeat the wave's
-        // first real position (same bin, same LDS words: broadcast reads) into accumulators nobody reads, so the lookup
-        // loop needs no per-lane test; `vmask` remembers which slots are real, and the position id comes back out of the
-        // address when the sums are finalised (listed positions are inside the frame: the address is not clamped).
-        constexpr int MAXP = (MAXR + 1) / 2;
-        uint32_t slot2[MAXP];
-        uint32_t accA[MAXR], accB[MAXR];
-        uint32_t wrounds = 0;                 // bit k: this wave has a real position in round k (wave-uniform)
-        uint32_t vmask = 0;                   // bit k: this lane's slot k is real
-#pragma unroll
-        for (int k = 0; k < MAXR; ++k) {
-            const uint32_t p = lst[k * NT + tid];
-            uint32_t a = p;
-            if (p != 0xFFFFu) vmask |= 1u << k;
-            const unsigned long long real = __ballot(p != 0xFFFFu);
-            if (real != 0ull) {
-                const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)a, (int)__builtin_ctzll(real));
-                if (p == 0xFFFFu) a = a1;
-                wrounds |= 1u << k;
-            }
-            if (k & 1) slot2[k >> 1] |= a << 16; else slot2[k >> 1] = a;
-            accA[k] = 0;
-            accB[k] = 0;
-        }
-        __syncthreads();                      // the lists are dead: the first piece may land on them
-
-        LERF_STAMP(7);
-        // The piece travels as NSLAB x 16 bytes per thread (wave w, slab i: 1-KiB block B = 16 i + w of the piece, lane L
-        // its bytes 16 L..16 L+15) and is stored with ds_write_addtid_b32 (address = M0 + offset + 4*lane, no address
-        // VGPR: 128 B/clk/CU against 79 for ds_write_b128).  addtid puts component c of all lanes at block + 256 c + 4 L,
-        // so the pack holds every block pre-permuted (global dword 4L+c = logical dword 64c+L) and LDS ends up in
-        // natural order.  M0 = the wave's block column; the 16-bit offset reaches 4 slabs.
-#define LERF_ADDTID(V, OFF) asm volatile("ds_write_addtid_b32 %0 offset:" #OFF :: "v"(V) : "memory")
-#define LERF_ADDTID4(R, OFF0, OFF1, OFF2, OFF3) \
-        LERF_ADDTID(R.x, OFF0); LERF_ADDTID(R.y, OFF1); LERF_ADDTID(R.z, OFF2); LERF_ADDTID(R.w, OFF3)
-#define LERF_SET_M0(V) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(V) : "memory")
-        auto pre_store = [&]() {
-            const uint32_t m0a = __builtin_amdgcn_readfirstlane((uint32_t)D::OFF_X + (uint32_t)wave * 1024u);
-            // slab i holds blocks 16 i + wave: the last slab is partial (blocks beyond PIECE_BLOCKS carry no data)
-#define LERF_SLAB_OK(I) ((I) < NSLAB && (16 * (I) + 15 < PIECE_BLOCKS || 16 * (I) + wave < PIECE_BLOCKS))
-            LERF_SET_M0(m0a);
-            if (LERF_SLAB_OK(0)) { LERF_ADDTID4(pr[0], 0, 256, 512, 768); }
-            if (LERF_SLAB_OK(1)) { LERF_ADDTID4(pr[1 < NSLAB ? 1 : 0], 16384, 16640, 16896, 17152); }
-            if (LERF_SLAB_OK(2)) { LERF_ADDTID4(pr[2 < NSLAB ? 2 : 0], 32768, 33024, 33280, 33536); }
-            if (LERF_SLAB_OK(3)) { LERF_ADDTID4(pr[3 < NSLAB ? 3 : 0], 49152, 49408, 49664, 49920); }
-            if (NSLAB > 4) {
-                LERF_SET_M0(m0a + 65536u);
-                if (LERF_SLAB_OK(4)) { LERF_ADDTID4(pr[4 < NSLAB ? 4 : 0], 0, 256, 512, 768); }
-                if (LERF_SLAB_OK(5)) { LERF_ADDTID4(pr[5 < NSLAB ? 5 : 0], 16384, 16640, 16896, 17152); }
-                if (LERF_SLAB_OK(6)) { LERF_ADDTID4(pr[6 < NSLAB ? 6 : 0], 32768, 33024, 33280, 33536); }
-                if (LERF_SLAB_OK(7)) { LERF_ADDTID4(pr[7 < NSLAB ? 7 : 0], 49152, 49408, 49664, 49920); }
-            }
-            if (NSLAB > 8) {
-                LERF_SET_M0(m0a + 81920u);       // slab 5's base: M0 stays below 128 KiB, the offset field supplies the rest
-                if (LERF_SLAB_OK(8)) { LERF_ADDTID4(pr[8 < NSLAB ? 8 : 0], 49152, 49408, 49664, 49920); }
-            }
-            static_assert(NSLAB <= 9, "three M0 windows");
-#undef LERF_SLAB_OK
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        // phases = (non-empty bin) x (6 LUTs).  The next piece is fetched into registers while the current one is being
-        // used, so the L2 latency of the piece copies hides behind the lookups.
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        // per-bin scalars, refreshed when a bin's first LUT comes up (kept loop-carried on purpose: loop-invariant code
-        // motion out of an inner per-LUT loop would park every round's slot address in a register of its own)
-        int bq = 0, bq_next = 0, l = 0, bi = 0;
-        uint32_t ne_left = ne_bins;               // non-empty bins not yet started
-        uint32_t act = 0, qbase = 0;
-        for (int ph = 0; ph < nph; ++ph) {
-            if (l == 0) {
-                // its level range, and this wave's rounds: chunk 16 k + wave inside [cs, ce) -- one scalar bit test per
-                // unrolled round
-                bq = __builtin_ctz(ne_left);
-                ne_left &= ne_left - 1u;
-                bq_next = ne_left != 0u ? __builtin_ctz(ne_left) : 0;
-                const int cs = (int)((cs_pack >> (8 * bq)) & 0xFFu), ce = (int)((ce_pack >> (8 * bq)) & 0xFFu);
-                const int klo = cs > wv ? (cs - wv + 15) >> 4 : 0, khi = ce > wv ? (ce - wv + 15) >> 4 : 0;
-                act = wrounds & ((1u << khi) - 1u) & ~((1u << klo) - 1u);
-                // LDS address of the piece's logical entry 0 (the piece starts at top-axis level bin_lo(bq))
-                qbase = lds_addr(smem + D::OFF_X) - (uint32_t)bin_lo(bq) * (kStrideA * 4u);
-            }
-            const unsigned long long t_copy = LERF_NOW();
-            (void)t_copy;
-            pre_store();
-            Off3 o0, o1;                                     // LUT l = mode (l>>1), rotation parity (l&1)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                o0.o[i] = P.s2off[l][i];
-                o1.o[i] = P.s2off[l][3 + i];
-            }
-            const uint32_t bt_a = lds_addr(Bt);
-            const unsigned st_a = kStrideA * 4, st_b = kStrideB * 4, st_c = kStrideC * 4, st_d = kStrideD * 4;   // axis strides, bytes
-            __syncthreads();
-            if (l < 5) pre_load(l + 1, bq);
-            else if (bi + 1 < nbins) pre_load(0, bq_next);
-            LERF_STAMP_ADD(8, t_copy);
-            const unsigned long long t_look = LERF_NOW();
-            (void)t_look;
-#pragma unroll
-            for (int k = 0; k < MAXR; ++k) {
-                if ((act >> k) & 1u) {
-                    const uint32_t sa = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
-                    // stage A: the 7 pixel reads of the two rotations (high-half loads, see lds_pixel_hi)
-                    const uint32_t cpa = bt_a + sa;
-                    uint32_t ra = lds_pixel_hi(cpa);
-                    uint32_t rb0 = lds_pixel_hi(cpa + (uint32_t)o0.o[0]), rc0 = lds_pixel_hi(cpa + (uint32_t)o0.o[1]),
-                             rd0 = lds_pixel_hi(cpa + (uint32_t)o0.o[2]);
-                    uint32_t rb1 = lds_pixel_hi(cpa + (uint32_t)o1.o[0]), rc1 = lds_pixel_hi(cpa + (uint32_t)o1.o[1]),
-                             rd1 = lds_pixel_hi(cpa + (uint32_t)o1.o[2]);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra), "+v"(rb0), "+v"(rc0), "+v"(rd0), "+v"(rb1), "+v"(rc1), "+v"(rd1));
-                    // stage B: both walks (LDS addresses into the piece)
-                    const int basea = (int)(__umul24(msb_of(ra), kStrideA * 4) + qbase);
-                    const unsigned ka = key_of(ra, st_a);
-                    const Walk<4> W0 = simplex_walk<4>(ka, basea, rb0, rc0, rd0, st_b, st_c, st_d);
-                    const Walk<4> W1 = simplex_walk<4>(ka, basea, rb1, rc1, rd1, st_b, st_c, st_d);
-                    // stage C: ten dword gathers in flight together
-                    uint32_t d0[5], d1[5];
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) d0[n] = W0.ld32(n);
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) d1[n] = W1.ld32(n);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // stage D: two 24-bit MADs per corner: the entry is e0 | 0 << 8 | e2 << 16 | e1 << 24, and a 24-bit
-                    // multiply reads bits 0..23 only, so the (e0, e2) pair needs no mask; e1 is shifted down
-                    const unsigned w0[5] = {(unsigned)kQ - W0.f0, W0.f0 - W0.f1, W0.f1 - W0.f2, W0.f2 - W0.f3, W0.f3};
-                    const unsigned w1[5] = {(unsigned)kQ - W1.f0, W1.f0 - W1.f1, W1.f1 - W1.f2, W1.f2 - W1.f3, W1.f3};
-                    uint32_t a = accA[k], bb = accB[k];
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) {
-                        a += __umul24(w0[n], d0[n]);
-                        bb += __umul24(w0[n], d0[n] >> 24);
-                    }
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) {
-                        a += __umul24(w1[n], d1[n]);
-                        bb += __umul24(w1[n], d1[n] >> 24);
-                    }
-                    accA[k] = a;
-                    accB[k] = bb;
-                }
-            }
-            __syncthreads();
-            LERF_STAMP_ADD(9, t_look);
-            if (++l == 6) { l = 0; ++bi; }
-        }
-        LERF_STAMP(10);
-        // finalise: hq = rne(clip(N/192 + 127)); entries are biased by +128 -> 12 lookups * 16 * 128 = 24576
-        //           N + 127*192 = field - 24576 + 24384 = field - 192
-#pragma unroll
-        for (int k = 0; k < MAXR; ++k) {
-            if ((vmask >> k) & 1u) {
-                const int div2 = kQ * 12;
-                int n0 = (int)(accA[k] & 0xFFFFu) - div2;
-                int n2 = (int)(accA[k] >> 16) - div2;
-                int n1 = (int)accB[k] - div2;
-                uint32_t h0 = (uint32_t)rne_div_clip255_fast(n0, div2);
-                uint32_t h1 = (uint32_t)rne_div_clip255_fast(n1, div2);
-                uint32_t h2 = (uint32_t)rne_div_clip255_fast(n2, div2);
-                // feat-tile address -> hyper-region position: row (ry + R2) of pitch FP -> row ry of pitch HP, R2 pixels left
-                const uint32_t a = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
-                const uint32_t row = a / (uint32_t)D::FP;
-                const uint32_t p = a - row * (uint32_t)(D::FP - D::HP) - (uint32_t)(R2 * D::HP + R2 * CH);
-                Dt[p] = h0 | (h1 << 8) | (h2 << 16) | ((uint32_t)Bt[a] << 24);
-            }
-        }
-    }
-
-    if (!EMIT && KIND == LERF_KIND_GAUSS && Hc >= 0) {
-        // fill_outside: out-of-frame positions of the hyper region = the clamped position's hyper bytes, image byte 0
-        __syncthreads();
-        for (int p = tid; p < D::NH; p += NT) {
-            const int ry = p / D::HP, r3 = p - ry * D::HP, rx = r3 / CH, c = r3 - rx * CH;
-            const int gy = hy0 + ry, gx = hx0 + rx;
-            const int cy = clampi(gy, 0, H - 1), cx = clampi(gx, 0, W - 1);
-            if (cy != gy || cx != gx) Dt[p] = Dt[(cy - hy0) * D::HP + (cx - hx0) * CH + c] & 0x00FFFFFFu;
-        }
-    }
-
-    if (EMIT) {
-        __syncthreads();
-        uint32_t* eo = P.emit + frame * P.emit_sn;
-        const int rows = min(TH, H - ty0), cols3 = min(TW, W - tx0) * CH;
-        for (int il = wave; il < rows; il += NW) {
-            const uint32_t* srow = Dt + (il + D::R3) * D::HP + D::R3 * CH;
-            uint32_t* drow = eo + ((int64_t)(ty0 + il) * W + tx0) * CH;
-            for (int x = lane; x < cols3; x += 64) drow[x] = srow[x];
-        }
-        return;
-    }
-
-    // ---- stage 3 geometry of the owned output block (staged here for S = 4; S = 2 did it at kernel start)
-    if (!D::GEO_EARLY) {
-        geo_search();
-        __syncthreads();
-        geo_stage();
-    }
-    __syncthreads();
-    const int i0 = ctl[16], i1 = ctl[17], j0 = ctl[18], j1 = ctl[19];
-    const int nrow = i1 - i0, ncol = j1 - j0;
-
-    LERF_STAMP(11);
-    // ---- stage 3.  Consecutive output rows that start at the same source row (2 rows at x2, 3 at x3 ...) form a row
-    //      group and share their taps: one task = (row group, one 4-byte-aligned output dword column); the tap loads, the
-    //      u8 -> f32 conversions and the column-only terms are done once per group, the rows pay one multiply and two
-    //      FMAs per tap.  Same code for the 2x2 and the 4x4 support.
-    {
-        constexpr int SS = S * S;
-        constexpr int GMAX = S == 2 ? 5 : 3;                      // rows per group (larger runs are split)
-        int* g_grp = reinterpret_cast<int*>(g_dc + D::GEO_ROWS * S);
-        const int ncolc = ncol * CH;
-        const int64_t rowpitch = (int64_t)P.oW * CH;
-        uint8_t* seg0 = outp + ((int64_t)i0 * P.oW + j0) * CH;
-        const bool rows_align = (rowpitch & 3) == 0;              // dword columns line up across the rows of a group
-        // dword columns per row: when every row of the block starts on a 4-byte boundary (a0 == 0 below) the block needs
-        // no slack column, and a 384-byte tile row is exactly 96 dwords = whole 128-byte lines per wave store
-        const bool seg_aligned = rows_align && (reinterpret_cast<uintptr_t>(seg0) & 3u) == 0;
-        const int ndw = seg_aligned ? (ncolc + 3) >> 2 : (ncolc + 6) >> 2;
-        if (wave == 0) {
-            int ng = 0;
-            for (int base = 0; base < nrow; base += 64) {
-                const int il = base + lane;
-                bool start = false;
-                if (il < nrow)
-                    start = il == 0 || !rows_align || g_lr[il] != g_lr[il - 1] || (il >= GMAX && g_lr[il - GMAX] == g_lr[il]);
-                const unsigned long long m = __ballot(start);
-                if (start) g_grp[ng + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = il;
-                ng += __popcll(m);
-            }
-            if (lane == 0) g_grp[ng] = nrow;
-            // every group of the tile the same size (integer scale factors, away from the frame's top and bottom): the
-            // task loop then runs with that size as a compile-time constant, without a row test per tap set
-            const int g0 = ng > 0 ? g_grp[1] - g_grp[0] : 0;
-            bool same = true;
-            for (int base = 0; base < ng; base += 64) {
-                const int idx = base + lane;
-                if (idx < ng && g_grp[idx + 1] - g_grp[idx] != g0) same = false;
-            }
-            const bool uniform = __ballot(!same) == 0ull;
-            if (lane == 0) {
-                ctl[21] = ng;
-                ctl[22] = uniform ? g0 : 0;
-                ctl[23] = 0;
-            }
-        }
-        __syncthreads();
-        const int ngrp = ctl[21];
-        const int gsame = __builtin_amdgcn_readfirstlane(ctl[22]);
-        const unsigned magic = (unsigned)((0x100000000ull + (unsigned)ndw - 1) / (unsigned)(ndw > 0 ? ndw : 1));
-        const float ms255 = P.max_sigma * (1.0f / 255.0f);
-        const int ntask = ngrp * ndw;
-        uint32_t* tq = reinterpret_cast<uint32_t*>(smem + D::OFF_TQ);
-        int* tq_count = ctl + 23;                               // zeroed with the group table below
-        auto run_tasks = [&](auto gs_const, auto ns_const) {
-        constexpr int GS = decltype(gs_const)::value;          // rows per group, 0 = read it per group
-        constexpr bool NS = decltype(ns_const)::value;         // Gaussian sums without the minimum shift (lerf_stage3.h)
-        constexpr int GN = GS > 0 ? GS : GMAX;
-        for (int t = tid; t < ntask; t += NT) {
-            const int g = (int)__umulhi((unsigned)t, magic);
-            const int dw = t - g * ndw;
-            const int il0 = g_grp[g];
-            const int gs = GS > 0 ? GS : g_grp[g + 1] - il0;
-            uint8_t* seg = seg0 + il0 * rowpitch;
-            const int a0 = (int)(reinterpret_cast<uintptr_t>(seg) & 3u);
-            const int b0 = dw * 4 - a0;
-            const int lr = g_lr[il0];
-            uint32_t packed[GN];
-            // tie detection: the 2x2 kernels keep every output's distance from its rounded value and a running maximum
-            // (one v_max per output, the ties are looked for only when the maximum says there is one); the 4x4 kernel has
-            // no registers for that and sets a bit per output
-            constexpr bool DIST = S == 2;
-            float dist[DIST ? GN * 4 : 1];                        // [r*4+u]
-            float dmax = 0.0f;
-            unsigned tiebits = 0;                                 // bit r*4+u
-#pragma unroll
-            for (int r = 0; r < GN; ++r) packed[r] = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int xc = min(max(b0 + u, 0), ncolc - 1);    // clamped; invalid bytes are not stored
-                const int jl = xc / CH;
-                const int c = xc - jl * CH;
-                const int lc = g_lc[jl];
-                // shared by the rows of the group: per tap (a = column offset major, numpy meshgrid 'xy' :95-98; b = row offset)
-                float p0[SS], k1[SS], ty[SS], v[SS];
-#pragma unroll
-                for (int a = 0; a < S; ++a) {
-                    const float dy = g_dc[jl * S + a];
-#pragma unroll
-                    for (int b = 0; b < S; ++b) {
-                        const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                        v[a * S + b] = (float)(d >> 24);
-                        const float k0 = (float)(d & 0xFFu);
-                        if (KIND == LERF_KIND_GAUSS) {
-                            // column-only terms of the quadratic form: p0 <- (-2 rho) ty, ty <- ty^2 (gauss_form_cols)
-                            const float tyv = s3::gauss_t_u8((float)((d >> 16) & 0xFFu), dy);
-                            p0[a * S + b] = s3::gauss_m2rho_u8(k0) * tyv;
-                            k1[a * S + b] = (float)((d >> 8) & 0xFFu);
-                            ty[a * S + b] = tyv * tyv;
-                        } else {
-                            const float alpha = s3::lin_alpha_u8(k0, ms255);
-                            p0[a * S + b] = alpha;
-                            ty[a * S + b] = s3::lin_factor(alpha, dy, s3::dist_class_f(dy));
-                            k1[a * S + b] = 0.0f;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < GN; ++r) {
-                    if (r < gs) {
-                        float e[SS];
-#pragma unroll
-                        for (int a = 0; a < S; ++a)
-#pragma unroll
-                            for (int b = 0; b < S; ++b) {
-                                const float dx = g_dr[(il0 + r) * S + b];
-                                if (KIND == LERF_KIND_GAUSS)
-                                    e[a * S + b] = s3::gauss_form_cols(s3::gauss_t_u8(k1[a * S + b], dx), ty[a * S + b], p0[a * S + b]);
-                                else
-                                    e[a * S + b] = s3::lin_factor(p0[a * S + b], dx, s3::dist_class_f(dx)) * ty[a * S + b];
-                            }
-                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, SS, true, true, NS>(e, v);
-                        if (DIST) {
-                            packed[r] = s3::pack_u8_dist(xf, u, packed[r], &dist[DIST ? r * 4 + u : 0]);
-                            dmax = __builtin_fmaxf(dmax, __builtin_fabsf(dist[DIST ? r * 4 + u : 0]));
-                        } else {
-                            bool tie;
-                            packed[r] = s3::pack_u8_tie(xf, u, packed[r], &tie);
-                            if (tie) tiebits |= 1u << (r * 4 + u);
-                        }
-                    }
-                }
-            }
-            if ((DIST ? dmax > 0.5f - s3::kTieEps : tiebits != 0) && P.dis_r64 != nullptr) {
-                unsigned tiemask = tiebits;
-                if (DIST) {
-#pragma unroll
-                    for (int q = 0; q < GN * 4; ++q)
-                        if ((GS > 0 || (q >> 2) < gs) && __builtin_fabsf(dist[DIST ? q : 0]) > 0.5f - s3::kTieEps) tiemask |= 1u << q;
-                }
-                // rare: the output is re-evaluated in float64 exactly as the reference does (lerf_stage3.h, tie guard)
-#pragma unroll 1
-                for (int q = 0; q < GN * 4; ++q) {
-                    if (!((tiemask >> q) & 1u)) continue;
-                    const int r = q >> 2, u = q & 3;
-                    const int xc = min(max(b0 + u, 0), ncolc - 1);
-                    // queued for the pass behind the task loop; only a full queue is worked off on the spot
-                    const int slot = atomicAdd(tq_count, 1);
-                    if (slot < P.tq_cap) {
-                        tq[slot] = ((uint32_t)(il0 + r) << 16) | (uint32_t)xc;
-                        continue;
-                    }
-                    const int jl = xc / CH;
-                    const int c = xc - jl * CH;
-                    const int lc = g_lc[jl];
-                    uint32_t dd[SS];
-                    double dx64[S], dy64[S];
-#pragma unroll
-                    for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il0 + r) * S + b];
-#pragma unroll
-                    for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
-#pragma unroll
-                    for (int a = 0; a < S; ++a)
-#pragma unroll
-                        for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                    const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
-#pragma unroll
-                    for (int rr = 0; rr < GN; ++rr)
-                        if (rr == r) packed[rr] = (packed[rr] & ~(0xFFu << (8 * u))) | (r8 << (8 * u));
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < GN; ++r) {
-                if (r < gs) {
-                    uint8_t* sr = seg + r * rowpitch;
-                    if (b0 >= 0 && b0 + 3 < ncolc) {
-                        // streaming store: the output is never re-read here, keep the LUT pack resident in L2 instead
-                        __builtin_nontemporal_store(packed[r], reinterpret_cast<uint32_t*>(sr + b0));
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (b0 + u >= 0 && b0 + u < ncolc) sr[b0 + u] = (uint8_t)(packed[r] >> (8 * u));
-                    }
-                }
-            }
-        }
-        };
-        // the constant-size variants cover the integer scale factors (x2 -> 2 rows per group, ...); anything else reads
-        // the group size per task
-        constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
-        // max_sigma beyond kNoShiftMaxSigma (never the case with the reference's option defaults): the unshifted Gaussian sums
-        // could underflow, the generic loop with minimum-shifted weights takes over
-        const bool noshift = KIND != LERF_KIND_GAUSS || P.max_sigma <= s3::kNoShiftMaxSigma;
-        if (!noshift) run_tasks(std::integral_constant<int, 0>{}, std::false_type{});
-        else if (gsame == 2) run_tasks(std::integral_constant<int, 2>{}, std::true_type{});
-        else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{}, std::true_type{});
-        else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{}, std::true_type{});
-        else run_tasks(std::integral_constant<int, 0>{}, std::true_type{});
-        // ---- tie pass: the queued outputs in float64, one per lane; each patches its byte behind the task loop's
-        //      dword stores (drained and fenced by the barrier)
-        if (P.dis_r64 != nullptr) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int nq = min(*tq_count, P.tq_cap);
-            for (int i = tid; i < nq; i += NT) {
-                const uint32_t e = tq[i];
-                const int il = (int)(e >> 16), xc = (int)(e & 0xFFFFu);
-                const int jl = xc / CH;
-                const int c = xc - jl * CH;
-                const int lr = g_lr[il], lc = g_lc[jl];
-                uint32_t dd[SS];
-                double dx64[S], dy64[S];
-#pragma unroll
-                for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il) * S + b];
-#pragma unroll
-                for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
-#pragma unroll
-                for (int a = 0; a < S; ++a)
-#pragma unroll
-                    for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                seg0[il * rowpitch + xc] = (uint8_t)s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
-            }
-        }
-    }
-#ifdef LERF_STAMPS
-    __syncthreads();
-    LERF_STAMP(12);
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// stage 1 alone, one 64x64 block per workgroup with no halo (two-launch path): input tile (block + 3 px) -> the
-// three byte LUTs, 4 rotations each -> feat bytes to P.feat.  Same phases as in sr_fused_kernel.
-// ---------------------------------------------------------------------------
-constexpr int up16c(int x) { return (x + 15) / 16 * 16; }
-struct DimsA {
-    static constexpr int FY = TH, FX = TW, FP = FX * CH, NF = FY * FP;
-    static constexpr int IY = FY + 2 * R1, IX = FX + 2 * R1, IPB = IX * CH, IP = (IPB + 3 + 3) / 4 * 4, NI = IY * IP;
-    static constexpr int OFF_LUT = 0;
-    static constexpr int OFF_C = LUT_PAD;
-    static constexpr int OFF_ACC = OFF_C + up16c(NI);
-    static constexpr int OFF_F = OFF_ACC + up16c(NF * 2);
-    static constexpr int LDS_BYTES = OFF_F + up16c(NF);
-};
-
-__global__ void __launch_bounds__(NT)
-s1_kernel(Params P) {
-    using D = DimsA;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x;
-    int bid = xcd_order((int)blockIdx.x, (int)gridDim.x);
-    const int tiles = P.tiles_y * P.tiles_x;
-    const int frame = bid / tiles;
-    bid -= frame * tiles;
-    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
-    const int fy0 = tyi * TH, fx0 = txi * TW;
-    const int iy0 = fy0 - R1, ix0 = fx0 - R1;
-    const int H = P.H, W = P.W;
-    const uint8_t* __restrict__ img = P.img + frame * P.in_sn;
-    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= H && ix0 + D::IX <= W;
-    const int Hc = interior ? -1 : H, Wc = W;
-    uint8_t* Ft = smem + D::OFF_F;
-
-    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, P, H, W, iy0, ix0, interior, tid, []() {});
-    {
-        const uint8_t* Ct = smem + D::OFF_C + cphase;
-        int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
-        int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
-        const int div1 = kQ * 3;
-        constexpr int L1N = (LERF_LUT_ENTRIES + 15) / 16, L1TAIL = L1N - 5 * NT;
-        uint4 n0, n1, n2, n3, n4, n5 = make_uint4(0, 0, 0, 0);
-        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
-        __syncthreads();
-        LERF_S1_LOAD(P.pack + 1 * LUT_PAD);
-        byte_phase<D::NF, D::FP, D::IP, 's', 0, 4, 1, 0, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
-        __syncthreads();
-        LERF_S1_STORE();
-        __syncthreads();
-        LERF_S1_LOAD(P.pack + 2 * LUT_PAD);
-        byte_phase<D::NF, D::FP, D::IP, 'c', 0, 4, 1, 1, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
-        __syncthreads();
-        LERF_S1_STORE();
-        __syncthreads();
-        byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
-        __syncthreads();
-    }
-    // the block's rows to P.feat
-    uint8_t* __restrict__ fdst = P.feat + frame * P.feat_sn;
-    const int rows = min(TH, H - fy0), cols3 = min(TW, W - fx0) * CH;
-    const bool dwords = cols3 == D::FP && ((W * CH) & 3) == 0 && (P.feat_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.feat) & 3) == 0;
-    if (dwords) {
-        constexpr int RD = D::FP / 4;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(fdst + ((int64_t)fy0 * W + fx0) * CH);
-        const int rowdw = (W * CH) >> 2;
-        for (int i = tid; i < rows * RD; i += NT) {
-            const int r = i / RD;
-            __builtin_nontemporal_store(reinterpret_cast<const uint32_t*>(Ft)[i], &dst[(int64_t)r * rowdw + (i - r * RD)]);
-        }
-    } else {
-        for (int i = tid; i < rows * cols3; i += NT) {
-            const int r = i / cols3, c3 = i - r * cols3;
-            fdst[((int64_t)(fy0 + r) * W + fx0) * CH + c3] = Ft[r * D::FP + c3];
-        }
-    }
-}
-
-#undef LERF_S1_LOAD
-#undef LERF_S1_STORE
-#undef LERF_ADDTID
-#undef LERF_ADDTID4
-#undef LERF_SET_M0
-
-}  // namespace fused
-
-// ---------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------
-bool fused_supported(const FusedArgs& a) {
-    const lerf_luts_t* L = a.luts;
-    if (!L || !L->fused_pack) return false;
-    if (a.C != 3 || (a.S != 2 && a.S != 4)) return false;
-    if (L->n_modes1 != 3 || L->n_modes2 != 3) return false;
-    if (memcmp(L->modes1, "sct", 3) != 0 || memcmp(L->modes2, "sct", 3) != 0) return false;
-    if (a.oH < a.H || a.oW < a.W) return false;                     // up-sampling only
-    if ((int64_t)a.oH > 4 * (int64_t)a.H + 8 || (int64_t)a.oW > 4 * (int64_t)a.W + 8) return false;   // geometry staging
-    if (a.kind == LERF_KIND_LINEAR && a.S != 2) return false;
+static bool modes_ok(const char* m, int n) {
+    if (n < 1 || n > fused::MAXM) return false;
+    for (int i = 0; i < n; ++i)
+        if (m[i] != 's' && m[i] != 'd' && m[i] != 'y' && m[i] != 'c' && m[i] != 't') return false;
     return true;
 }
-
-static int g_tie_queue_cap = fused::Dims<2>::TQ_CAP;
-int fused_set_tie_queue_cap(int cap) {
-    const int old = g_tie_queue_cap;
-    g_tie_queue_cap = cap < 0 ? fused::Dims<2>::TQ_CAP : (cap > fused::Dims<2>::TQ_CAP ? fused::Dims<2>::TQ_CAP : cap);
-    return old;
+static bool luts_packable(const lerf_luts_t* L) {
+    return L && (L->oC == 1 || L->oC == 3) && modes_ok(L->modes1, L->n_modes1) && modes_ok(L->modes2, L->n_modes2);
 }
 
-template <int S, int KIND, bool EMIT = false>
-static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
-    using D = fused::Dims<S>;
-    fused::Params P;
-    P.tq_cap = g_tie_queue_cap;
-    P.img = a.img; P.in_sn = a.in_sn; P.out = a.out; P.out_sn = a.out_sn;
-    P.H = a.H; P.W = a.W; P.oH = a.oH; P.oW = a.oW;
-    P.tiles_y = (a.H + fused::TH - 1) / fused::TH;
-    P.tiles_x = (a.W + fused::TW - 1) / fused::TW;
-    P.pack = (const uint8_t*)a.luts->fused_pack;
-    P.left_r = a.left_r; P.dis_r = a.dis_r; P.left_c = a.left_c; P.dis_c = a.dis_c;
-    P.dis_r64 = a.dis_r64; P.dis_c64 = a.dis_c64;
-    P.max_sigma = a.max_sigma;
-    P.stamps = EMIT ? nullptr : (unsigned long long*)a.workspace;
-    for (int l = 0; l < 6; ++l) {
-        const char mc = "sct"[l >> 1];
-        fused::Off3 o0 = fused::tile_offsets<D::FP>(mc, l & 1), o1 = fused::tile_offsets<D::FP>(mc, (l & 1) + 2);
-        for (int i = 0; i < 3; ++i) {
-            P.s2off[l][i] = o0.o[i];
-            P.s2off[l][3 + i] = o1.o[i];
-        }
+// the specialised kernels of this file: RGB, modes "sct" / "sct", one frame size, scale < 4.9
+static bool fused_fast(const FusedArgs& a) {
+    const lerf_luts_t* L = a.luts;
+    if (a.C != 3 || a.items != nullptr) return false;
+    if (L->n_modes1 != 3 || L->n_modes2 != 3 || memcmp(L->modes1, "sct", 3) != 0 || memcmp(L->modes2, "sct", 3) != 0) return false;
+    return (int64_t)a.oH <= 4 * (int64_t)a.H + 8 && (int64_t)a.oW <= 4 * (int64_t)a.W + 8;      // geometry staging
+}
+
+static bool shape_ok(int H, int W, int oH, int oW) {
+    if (oH < H || oW < W) return false;                                                   // up-sampling only
+    return (int64_t)oH <= 8 * (int64_t)H + 8 && (int64_t)oW <= 8 * (int64_t)W + 8;         // large-geometry staging
+}
+
+bool fused_supported(const FusedArgs& a) {
+    const lerf_luts_t* L = a.luts;
+    if (!luts_packable(L) || !L->fused_pack) return false;
+    if ((a.C != 1 && a.C != 3 && a.C != 4) || (a.S != 2 && a.S != 4)) return false;
+    if (a.kind == LERF_KIND_LINEAR && a.S != 2) return false;
+    if (a.pad_mode < LERF_PAD_CONSTANT || a.pad_mode > LERF_PAD_WRAP) return false;
+    const bool roi = a.roi_h > 0 && a.roi_w > 0;
+    if (a.pad_mode == LERF_PAD_WRAP && (a.workspace == nullptr || roi)) return false;      // far-side pixels come from the stage-1 output
+    if (a.items != nullptr) {
+        if (a.n_items < 1 || roi) return false;
+        for (int i = 0; i < a.n_items; ++i)
+            if (a.items[i].H < 1 || a.items[i].W < 1 || !shape_ok(a.items[i].H, a.items[i].W, a.items[i].oH, a.items[i].oW)) return false;
+        return true;
     }
-    P.emit = (uint32_t*)a.emit; P.emit_sn = a.emit_sn;
-    P.feat = nullptr; P.feat_sn = 0;
-    const int64_t blocks = (int64_t)a.n * P.tiles_y * P.tiles_x;
-    if (blocks > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
-#ifndef LERF_STAMPS
-    // two launches when the caller's workspace can hold the stage-1 output of the batch: stage 1 without halo
-    // recomputation, then stages 2+3 from it (the diagnostic build keeps the single launch: its stamps live in the workspace)
-    if (a.workspace != nullptr) {
-        P.feat = (uint8_t*)a.workspace;
-        P.feat_sn = ((int64_t)a.H * a.W * a.C + 15) / 16 * 16;
-        auto ka = fused::s1_kernel;
-        auto kb = fused::sr_fused_kernel<S, KIND, EMIT, true>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                fused::DimsA::LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, D::LDS_BYTES) != hipSuccess)
-            return LERF_ELAUNCH;
-        hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(fused::NT), fused::DimsA::LDS_BYTES, st, P);
-        hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(fused::NT), D::LDS_BYTES, st, P);
-        return LERF_OK;
+    if (roi && (a.roi_y < 0 || a.roi_x < 0 || a.roi_y + a.roi_h > a.H || a.roi_x + a.roi_w > a.W)) return false;
+    return shape_ok(a.H, a.W, a.oH, a.oW);
+}
+
+size_t fused_workspace_bytes(const FusedArgs& a) {
+    if (a.items != nullptr) {
+        size_t t = 0;
+        for (int i = 0; i < a.n_items; ++i) t += ((size_t)a.items[i].H * a.items[i].W * a.C + 15) / 16 * 16;
+        return t;
     }
-#endif
-    auto kern = fused::sr_fused_kernel<S, KIND, EMIT>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            D::LDS_BYTES) != hipSuccess)
-        return LERF_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(fused::NT), D::LDS_BYTES, st, P);
-    return LERF_OK;
+    return (size_t)a.n * (((size_t)a.H * a.W * a.C + 15) / 16 * 16);
+}
+
+int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
+    if (a.C == 1) return launch_sr_fused_c1(a, st);
+    if (a.C == 4) return launch_sr_fused_c4(a, st);
+    if (a.C != 3) return LERF_EUNSUPPORTED;
+    return fused_fast(a) ? fused::launch_sr<false>(a, st) : launch_sr_fused_g3(a, st);
 }
 
 // stages 1+2 only: packed (hq0,hq1,hq2,feat) dwords per pixel-channel
 bool fused_stages_supported(const FusedArgs& a) {
     const lerf_luts_t* L = a.luts;
-    if (!L || !L->fused_pack || a.C != 3) return false;
-    if (L->n_modes1 != 3 || L->n_modes2 != 3) return false;
-    return memcmp(L->modes1, "sct", 3) == 0 && memcmp(L->modes2, "sct", 3) == 0;
+    if (!luts_packable(L) || !L->fused_pack) return false;
+    return a.C == 1 || a.C == 3 || a.C == 4;
 }
 
 int launch_stages_fused(const FusedArgs& a, hipStream_t st) {
-    if (a.luts->oC == 3) return launch_fused_t<2, LERF_KIND_GAUSS, true>(a, st);
-    if (a.luts->oC == 1) return launch_fused_t<2, LERF_KIND_LINEAR, true>(a, st);
-    return LERF_EUNSUPPORTED;
+    if (a.C == 1) return launch_stages_fused_c1(a, st);
+    if (a.C == 4) return launch_stages_fused_c4(a, st);
+    if (a.C != 3) return LERF_EUNSUPPORTED;
+    return fused_fast(a) ? fused::launch_stages<false>(a, st) : launch_stages_fused_g3(a, st);
 }
 
-int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
-    if (a.kind == LERF_KIND_GAUSS) {
-        if (a.S == 2) return launch_fused_t<2, LERF_KIND_GAUSS>(a, st);
-        if (a.S == 4) return launch_fused_t<4, LERF_KIND_GAUSS>(a, st);
-    } else if (a.kind == LERF_KIND_LINEAR) {
-        if (a.S == 2) return launch_fused_t<2, LERF_KIND_LINEAR>(a, st);
-    }
-    return LERF_EUNSUPPORTED;
-}
-
-// fused LUT pack: [n1 x LUT_PAD int8 stage-1 LUTs][stage-2 LUTs], stage 2 as
-//   oC == 3: 6 x NBIN pieces of PIECE_BYTES (dwords of biased bytes e0+128 | e2+128 << 16 | e1+128 << 24), order s_r0, s_r1, c_r0, ...
-//   oC == 1: 6 x LUT_PAD int8
-size_t fused_lutpack_bytes(int oC) {
-    return (size_t)3 * fused::LUT_PAD + (oC == 3 ? (size_t)6 * fused::NBIN * fused::PIECE_BYTES : (size_t)6 * fused::LUT_PAD);
+// fused LUT pack: [n1 x LUT_PAD int8 stage-1 LUTs][2 n2 stage-2 LUTs], n1 = len(modes1), n2 = len(modes2); stage 2 as
+//   oC == 3: 2 n2 x NBIN pieces of PIECE_BYTES (dwords of biased bytes e0+128 | e2+128 << 16 | e1+128 << 24),
+//            order modes2[0] r0, modes2[0] r1, modes2[1] r0, ...
+//   oC == 1: 2 n2 x LUT_PAD int8
+size_t fused_lutpack_bytes(const lerf_luts_t* L) {
+    if (!luts_packable(L)) return 0;
+    return (size_t)L->n_modes1 * fused::LUT_PAD +
+           (size_t)2 * L->n_modes2 * (L->oC == 3 ? (size_t)fused::NBIN * fused::PIECE_BYTES : (size_t)fused::LUT_PAD);
 }
 
 // stage-2 LUT (3 channels) -> NBIN pieces of biased-byte dwords (e0+128 | e2+128 << 16 | e1+128 << 24); piece b = LUT
@@ -1552,16 +117,15 @@ __global__ void pack_bytes_kernel(const int8_t* __restrict__ src, int8_t* __rest
     if (i < fused::LUT_PAD) dst[i] = i < LERF_LUT_ENTRIES ? src[i] : (int8_t)0;
 }
 int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st) {
-    if (L->n_modes1 != 3 || L->n_modes2 != 3) return LERF_EUNSUPPORTED;
-    if (L->oC != 1 && L->oC != 3) return LERF_EUNSUPPORTED;
+    if (!luts_packable(L)) return LERF_EUNSUPPORTED;
     uint8_t* base = (uint8_t*)buf;
     dim3 block(256), grid((fused::LUT_PAD + 255) / 256);
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < L->n_modes1; ++m) {
         if (!L->s1[m]) return LERF_EINVAL;
         hipLaunchKernelGGL(pack_bytes_kernel, grid, block, 0, st, L->s1[m], (int8_t*)(base + (size_t)m * fused::LUT_PAD));
     }
-    uint8_t* s2 = base + (size_t)3 * fused::LUT_PAD;
-    for (int m = 0; m < 3; ++m)
+    uint8_t* s2 = base + (size_t)L->n_modes1 * fused::LUT_PAD;
+    for (int m = 0; m < L->n_modes2; ++m)
         for (int r = 0; r < 2; ++r) {
             if (!L->s2[m][r]) return LERF_EINVAL;
             int l = m * 2 + r;

@@ -52,7 +52,13 @@ int launch_lut_stage(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int
 int launch_resize(const ResizeArgs& a, hipStream_t st);
 int launch_warp(const WarpArgs& a, hipStream_t st);
 
-// lerf_fused.hip
+// lerf_fused*.hip (lerf_fused_impl.h)
+struct FusedItem {                        // one frame of a ragged launch: its own size and geometry tables
+    const uint8_t* img; uint8_t* out; void* emit;
+    int H, W, oH, oW;
+    const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
+    const double* dis_r64; const double* dis_c64;
+};
 struct FusedArgs {
     const uint8_t* img; int64_t in_sn; int n, H, W, C;
     const lerf_luts_t* luts;
@@ -61,22 +67,35 @@ struct FusedArgs {
     const double* dis_r64; const double* dis_c64;
     int kind; float max_sigma;
     uint8_t* out; int64_t out_sn;
-    void* workspace;
+    void* workspace; size_t workspace_bytes;
     void* emit; int64_t emit_sn;          // launch_stages_fused: packed dwords out
+    int roi_y, roi_x, roi_h, roi_w;       // lerf_sr_geo_t region of interest (roi_h = 0: whole frame)
+    int tq_cap;                           // lerf_sr_geo_t.tie_queue_cap
+    int pad_mode;                         // LERF_PAD_* of the image operand
+    const FusedItem* items; int n_items;  // ragged launch (general kernels): frames of different sizes; img/out/H/W/... above unused
 };
-bool fused_supported(const FusedArgs& a);
-size_t fused_lutpack_bytes(int oC);
+bool fused_supported(const FusedArgs& a);          // some tile-fused kernel covers the configuration
+size_t fused_workspace_bytes(const FusedArgs& a);  // what the two-launch path parks in the workspace
+size_t fused_lutpack_bytes(const lerf_luts_t* L);
 int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st);
 int launch_sr_fused(const FusedArgs& a, hipStream_t st);
-int fused_set_tie_queue_cap(int cap);       // returns the previous capacity; < 0 restores the default
 bool fused_stages_supported(const FusedArgs& a);
 int launch_stages_fused(const FusedArgs& a, hipStream_t st);
+// the general kernels (any patterns, scale <= 8, ragged frames) per channel count, one translation unit each
+int launch_sr_fused_g3(const FusedArgs& a, hipStream_t st);
+int launch_stages_fused_g3(const FusedArgs& a, hipStream_t st);
+int launch_sr_fused_c1(const FusedArgs& a, hipStream_t st);
+int launch_stages_fused_c1(const FusedArgs& a, hipStream_t st);
+int launch_sr_fused_c4(const FusedArgs& a, hipStream_t st);
+int launch_stages_fused_c4(const FusedArgs& a, hipStream_t st);
 // lerf_transfer.hip
 size_t srnet_weight_floats(int outC);
 int launch_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut, float* y, hipStream_t st);
 
 int launch_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, hipStream_t st);
-int launch_warp_packed(const uint32_t* packed, int H, int W, int C, const WarpGeo& geo, int kind, float max_sigma,
-                       void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, hipStream_t st);
+int launch_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, int W, int C, const WarpGeo& geo, int kind,
+                       float max_sigma, void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn, hipStream_t st);
+int launch_rect_copy(uint8_t* frames, int n, int fh, int fw, int C, uint8_t* staging, const lerf_rect_t* rects, int n_rects,
+                     int to_staging, hipStream_t st);
 
 }  // namespace lerf

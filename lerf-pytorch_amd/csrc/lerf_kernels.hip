@@ -291,8 +291,9 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
             for (int b = 0; b < MAXS; ++b) {
                 int rr = lr + b, cc = lc + a;
                 int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);
-                bool inside = (rr == rcl) && (cc == ccl);
-                v[a * MAXS + b] = inside ? Loader<TI>::pixel(feat + rcl * fy + ccl * fx + c * fc) : 0.0f;   // zero pad (:208)
+                bool zr, zc;                                                                           // image pad rule (:208)
+                const int rs = pad_index(rr, H, pad_mode, &zr), cs = pad_index(cc, W, pad_mode, &zc);
+                v[a * MAXS + b] = (zr || zc) ? 0.0f : Loader<TI>::pixel(feat + rs * fy + cs * fx + c * fc);
                 if (sizeof(TH) == 1 && sizeof(TO) == 1) {
                     const int64_t hh = rcl * hy + ccl * hx + c * hc;
                     dd[a * MAXS + b] = (uint32_t)h0[hh] | ((KIND == LERF_KIND_GAUSS ? (uint32_t)h1[hh] : 0u) << 8) |
@@ -695,8 +696,10 @@ int launch_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t
 // resample/eval_lut_warp.py:100-222 with stages 1+2 from the fused kernel)
 template <typename TO, int KIND>
 __global__ void __launch_bounds__(256)
-warp_packed_kernel(const uint32_t* __restrict__ packed, int H, int W, int C, WarpGeo g, float max_sigma,
-                   TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+warp_packed_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, int H, int W, int C, WarpGeo g, float max_sigma,
+                   TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn) {
+    packed += (int64_t)blockIdx.z * packed_sn;             // frame of the batch (one homography for all)
+    out += (int64_t)blockIdx.z * out_sn;
     int xc = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (xc >= g.oW * C) return;
@@ -754,9 +757,11 @@ warp_packed_kernel(const uint32_t* __restrict__ packed, int H, int W, int C, War
 // spends most of its time repeating the two float64 divisions of the projection).
 template <typename TO, int KIND>
 __global__ void __launch_bounds__(256)
-warp_packed_px_kernel(const uint32_t* __restrict__ packed, int H, int W, WarpGeo g, float max_sigma,
-                      TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc) {
+warp_packed_px_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, int H, int W, WarpGeo g, float max_sigma,
+                      TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn) {
     constexpr int S = 2, C = 3;
+    packed += (int64_t)blockIdx.z * packed_sn;             // frame of the batch (one homography for all)
+    out += (int64_t)blockIdx.z * out_sn;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= g.oW) return;
@@ -835,14 +840,16 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed, int H, int W, WarpGeo
     }
 }
 
-int launch_warp_packed(const uint32_t* packed, int H, int W, int C, const WarpGeo& geo, int kind, float max_sigma,
-                       void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, hipStream_t st) {
+int launch_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, int W, int C, const WarpGeo& geo, int kind,
+                       float max_sigma, void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn, hipStream_t st) {
     if (geo.S < 1 || geo.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
+    if (n < 1 || n > 65535 || geo.oH > 65535) return LERF_EUNSUPPORTED;
     if (C == 3 && geo.S == 2 && (kind == LERF_KIND_GAUSS || kind == LERF_KIND_LINEAR) &&
         (out_dtype == LERF_U8 || out_dtype == LERF_F32)) {
-        dim3 blockp(256), gridp((geo.oW + 255) / 256, geo.oH);
+        dim3 blockp(256), gridp((geo.oW + 255) / 256, geo.oH, n);
 #define LERF_WPX(TO, KIND)                                                                                            \
-    hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND>), gridp, blockp, 0, st, packed, H, W, geo, max_sigma, (TO*)out, oy, ox, oc)
+    hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND>), gridp, blockp, 0, st, packed, packed_sn, H, W, geo, max_sigma, (TO*)out, \
+                       oy, ox, oc, out_sn)
         if (kind == LERF_KIND_GAUSS) {
             if (out_dtype == LERF_U8) LERF_WPX(uint8_t, LERF_KIND_GAUSS); else LERF_WPX(float, LERF_KIND_GAUSS);
         } else {
@@ -851,10 +858,10 @@ int launch_warp_packed(const uint32_t* packed, int H, int W, int C, const WarpGe
 #undef LERF_WPX
         return LERF_OK;
     }
-    dim3 block(256), grid((geo.oW * C + 255) / 256, geo.oH);
+    dim3 block(256), grid((geo.oW * C + 255) / 256, geo.oH, n);
 #define LERF_WPK(TO, KIND)                                                                                         \
-    hipLaunchKernelGGL((warp_packed_kernel<TO, KIND>), grid, block, 0, st, packed, H, W, C, geo, max_sigma, (TO*)out, \
-                       oy, ox, oc)
+    hipLaunchKernelGGL((warp_packed_kernel<TO, KIND>), grid, block, 0, st, packed, packed_sn, H, W, C, geo, max_sigma, (TO*)out, \
+                       oy, ox, oc, out_sn)
     if (kind == LERF_KIND_GAUSS) {
         if (out_dtype == LERF_U8) LERF_WPK(uint8_t, LERF_KIND_GAUSS);
         else if (out_dtype == LERF_F32) LERF_WPK(float, LERF_KIND_GAUSS);
@@ -867,6 +874,54 @@ int launch_warp_packed(const uint32_t* packed, int H, int W, int C, const WarpGe
         return LERF_EUNSUPPORTED;
     }
 #undef LERF_WPK
+    return LERF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// halo plumbing of the multi-GPU partitions: up to LERF_MAX_RECTS rectangles of a batch of dense uint8 frames <-> one
+// contiguous staging buffer, ONE launch (lerf_rect_copy_u8).  Bandwidth-trivial (a few hundred KB); what matters is the
+// launch count on a step of a few hundred microseconds.
+// ---------------------------------------------------------------------------
+struct RectSet {
+    int n;
+    int y[LERF_MAX_RECTS], x[LERF_MAX_RECTS], h[LERF_MAX_RECTS], wb[LERF_MAX_RECTS];   // wb = row bytes (w * C)
+    int64_t off[LERF_MAX_RECTS];
+    int64_t first[LERF_MAX_RECTS + 1];          // prefix sums of the rectangles' bytes over the batch
+};
+__global__ void __launch_bounds__(256)
+rect_copy_kernel(uint8_t* __restrict__ frames, int n_frames, int fh, int fw, int C, uint8_t* __restrict__ staging, RectSet R,
+                 int to_staging) {
+    const int64_t total = R.first[R.n];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = 0;
+#pragma unroll
+        for (int k = 1; k < LERF_MAX_RECTS; ++k)
+            if (k < R.n && i >= R.first[k]) r = k;
+        const int64_t e = i - R.first[r];                     // byte inside rectangle r's [n][h][w*C] block
+        const int64_t per = (int64_t)R.h[r] * R.wb[r];
+        const int f = (int)(e / per);
+        const int64_t q = e - (int64_t)f * per;
+        const int row = (int)(q / R.wb[r]), cb = (int)(q - (int64_t)row * R.wb[r]);
+        uint8_t* fp = frames + ((int64_t)f * fh + R.y[r] + row) * ((int64_t)fw * C) + (int64_t)R.x[r] * C + cb;
+        uint8_t* sp = staging + R.off[r] + e;
+        if (to_staging) *sp = *fp; else *fp = *sp;
+    }
+}
+
+int launch_rect_copy(uint8_t* frames, int n, int fh, int fw, int C, uint8_t* staging, const lerf_rect_t* rects, int n_rects,
+                     int to_staging, hipStream_t st) {
+    RectSet R{};
+    R.n = n_rects;
+    int64_t acc = 0;
+    for (int r = 0; r < n_rects; ++r) {
+        R.y[r] = rects[r].y; R.x[r] = rects[r].x; R.h[r] = rects[r].h; R.wb[r] = rects[r].w * C; R.off[r] = rects[r].off;
+        R.first[r] = acc;
+        acc += (int64_t)n * rects[r].h * rects[r].w * C;
+    }
+    for (int r = n_rects; r <= LERF_MAX_RECTS; ++r) R.first[r] = acc;
+    const int64_t blocks = (acc + 255) / 256;
+    hipLaunchKernelGGL(rect_copy_kernel, dim3((unsigned)(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096)), dim3(256), 0, st, frames, n,
+                       fh, fw, C, staging, R, to_staging);
     return LERF_OK;
 }
 

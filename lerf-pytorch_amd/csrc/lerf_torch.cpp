@@ -17,6 +17,7 @@
 // LUT sets travel as tensor lists: luts_s1 = [s, c, t] int8 [17^4, 1]; luts_s2 = [s_r0, s_r1, c_r0, c_r1, t_r0, t_r1]
 // int8 [17^4, outC]; pack = the fused LUT pack (lerf_fused_lutpack_build) or None.
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -31,6 +32,9 @@
 namespace {
 
 void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+
+// every op runs on the device of its first tensor: the current stream and at::empty's allocations are that device's
+using DeviceGuard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
 
 void check_rc(int rc, const char* what) { TORCH_CHECK(rc == LERF_OK, what, ": ", lerf_strerror(rc)); }
 
@@ -64,7 +68,7 @@ LutView make_luts(at::TensorList s1, at::TensorList s2, const c10::optional<at::
     }
     v.st.fused_pack = nullptr;
     if (pack.has_value() && pack->defined()) {
-        TORCH_CHECK(pack->scalar_type() == at::kByte && (size_t)pack->numel() >= lerf_fused_lutpack_bytes((int)oC) && pack->device() == dev &&
+        TORCH_CHECK(pack->scalar_type() == at::kByte && (size_t)pack->numel() >= lerf_fused_lutpack_bytes(&v.st) && pack->device() == dev &&
                         pack->is_contiguous(),
                     "pack must be the uint8 buffer lerf_fused_lutpack_build filled");
         v.st.fused_pack = pack->data_ptr();
@@ -126,6 +130,7 @@ void check_u8_frames(const at::Tensor& img) {
 // ------------------------------------------------------------------------------------------------ ops
 std::tuple<at::Tensor, at::Tensor> lut_stages(const at::Tensor& img, at::TensorList s1, at::TensorList s2) {
     TORCH_CHECK(img.scalar_type() == at::kByte && img.dim() == 3, "img must be uint8 [H,W,C]");
+    DeviceGuard guard(img.device());
     at::Tensor x = img.contiguous();
     LutView L = make_luts(s1, s2, c10::nullopt, x.device());
     const int H = (int)x.size(0), W = (int)x.size(1), C = (int)x.size(2);
@@ -140,6 +145,7 @@ std::tuple<at::Tensor, at::Tensor> lut_stages(const at::Tensor& img, at::TensorL
 at::Tensor sr_fused(const at::Tensor& img, at::TensorList s1, at::TensorList s2, const c10::optional<at::Tensor>& pack, double scale_h,
                     double scale_w, int64_t support, double max_sigma) {
     check_u8_frames(img);
+    DeviceGuard guard(img.device());
     const bool squeeze = img.dim() == 3;
     at::Tensor x = (squeeze ? img.unsqueeze(0) : img).contiguous();
     LutView L = make_luts(s1, s2, pack, x.device());
@@ -151,7 +157,7 @@ at::Tensor sr_fused(const at::Tensor& img, at::TensorList s1, at::TensorList s2,
     at::Tensor out = at::empty({N, g.oH, g.oW, C}, x.options());
     at::Tensor ws = at::empty({(int64_t)std::max<size_t>(lerf_sr_fused_workspace_bytes(H, W, C, N), 1)}, x.options());
     check_rc(lerf_sr_fused_u8((const uint8_t*)x.data_ptr(), x.stride(0), N, H, W, C, &L.st, &g.st, linear ? LERF_KIND_LINEAR : LERF_KIND_GAUSS,
-                              ms, (uint8_t*)out.data_ptr(), out.stride(0), ws.data_ptr(), cur_stream()),
+                              ms, (uint8_t*)out.data_ptr(), out.stride(0), ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
              "lerf_sr_fused_u8");
     return squeeze ? out.squeeze(0) : out;
 }
@@ -160,6 +166,7 @@ at::Tensor warp_fused(const at::Tensor& img, at::TensorList s1, at::TensorList s
                       const at::Tensor& matrix, int64_t out_h, int64_t out_w, int64_t support, double max_sigma) {
     TORCH_CHECK(img.scalar_type() == at::kByte && img.dim() == 3, "img must be uint8 [H,W,C]");
     TORCH_CHECK(matrix.numel() == 9, "matrix must be 3x3 (input -> output coordinates)");
+    DeviceGuard guard(img.device());
     at::Tensor x = img.contiguous();
     LutView L = make_luts(s1, s2, pack, x.device());
     const bool linear = L.st.oC == 1;
@@ -182,9 +189,9 @@ at::Tensor warp_fused(const at::Tensor& img, at::TensorList s1, at::TensorList s
         at::Tensor packed = at::empty({H, W, C}, x.options().dtype(at::kInt));
         at::Tensor ws = at::empty({(int64_t)std::max<size_t>(lerf_sr_fused_workspace_bytes(H, W, C, 1), 1)}, x.options());
         check_rc(lerf_stages_packed_u8((const uint8_t*)x.data_ptr(), 0, 1, H, W, C, &L.st, (uint32_t*)packed.data_ptr(), 0, ws.data_ptr(),
-                                       cur_stream()),
+                                       (size_t)ws.numel(), cur_stream()),
                  "lerf_stages_packed_u8");
-        check_rc(lerf_warp_packed((const uint32_t*)packed.data_ptr(), H, W, C, &g, kind, ms, &po, cur_stream()), "lerf_warp_packed");
+        check_rc(lerf_warp_packed((const uint32_t*)packed.data_ptr(), 0, 1, H, W, C, &g, kind, ms, &po, 0, cur_stream()), "lerf_warp_packed");
         return out;
     }
     auto fh = lut_stages(x, s1, s2);
@@ -201,6 +208,7 @@ at::Tensor warp_fused(const at::Tensor& img, at::TensorList s1, at::TensorList s
 // planar float32 maps [B,C,H,W] -> [B,C,oH,oW]; float32 geometry of the torch classes (resize_right2d_torch.py:48-103)
 at::Tensor resize_planar(int kind, const at::Tensor& feat, const std::vector<at::Tensor>& hs, double sh, double sw, int64_t S, double ms) {
     TORCH_CHECK(feat.dim() == 4 && feat.scalar_type() == at::kFloat, "feat must be float32 [B,C,H,W]");
+    DeviceGuard guard(feat.device());
     const int B = (int)feat.size(0), C = (int)feat.size(1), H = (int)feat.size(2), W = (int)feat.size(3);
     at::Tensor x = feat.contiguous();
     std::vector<at::Tensor> h;
@@ -235,9 +243,16 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> resize_backward(int64
                                                                            double scale_h, double scale_w, int64_t support, double max_sigma) {
     TORCH_CHECK(kind == LERF_KIND_GAUSS || kind == LERF_KIND_LINEAR, "kind: 0 = gauss, 1 = linear");
     TORCH_CHECK(feat.dim() == 4 && feat.scalar_type() == at::kFloat && grad_out.scalar_type() == at::kFloat, "float32 [B,C,H,W] tensors");
+    DeviceGuard guard(feat.device());
     const int B = (int)feat.size(0), C = (int)feat.size(1), H = (int)feat.size(2), W = (int)feat.size(3);
     const SrGeo& g = sr_geometry(H, W, scale_h, scale_w, (int)support, true, feat.device());
-    TORCH_CHECK(grad_out.size(2) == g.oH && grad_out.size(3) == g.oW, "grad_out does not match the output geometry");
+    TORCH_CHECK(grad_out.dim() == 4 && grad_out.size(0) == B && grad_out.size(1) == C && grad_out.size(2) == g.oH && grad_out.size(3) == g.oW &&
+                    grad_out.device() == feat.device(),
+                "grad_out must be [B,C,oH,oW] of the output geometry, on feat's device");
+    for (const at::Tensor* t : {&h0, &h1, &h2})         // all three are read by the Gaussian kernel, h0 by the linear one
+        TORCH_CHECK((t != &h0 && kind == LERF_KIND_LINEAR) ||
+                        (t->sizes() == feat.sizes() && t->scalar_type() == at::kFloat && t->device() == feat.device()),
+                    "hyper-parameter maps must match feat (float32, same shape and device)");
     at::Tensor x = feat.contiguous(), go = grad_out.contiguous(), a = h0.contiguous(), b = h1.contiguous(), c = h2.contiguous();
     at::Tensor gx = at::zeros_like(x), g0 = at::zeros_like(x), g1 = at::zeros_like(x), g2 = at::zeros_like(x);
     const bool gauss = kind == LERF_KIND_GAUSS;

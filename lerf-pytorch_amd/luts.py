@@ -64,8 +64,8 @@ class LutSet:
                 st.s2[i][r] = t.data_ptr()
         self.struct = st
         st.fused_pack = None
-        if modes == "sct" and modes2 == "sct":
-            nb = int(_lib.lib().lerf_fused_lutpack_bytes(self.oC))
+        nb = int(_lib.lib().lerf_fused_lutpack_bytes(C.byref(st)))       # 0: no tile-fused kernel for this set (5 modes in a stage)
+        if nb > 0:
             pack = torch.empty(nb, dtype=torch.uint8, device=self.device)
             _lib.check(_lib.lib().lerf_fused_lutpack_build(C.byref(st), pack.data_ptr(), _lib.current_stream()),
                        "lerf_fused_lutpack_build")

@@ -64,9 +64,20 @@ class SrGeometry:
         g = _lib.SrGeo()
         g.S, g.out_h, g.out_w = self.S, self.out_hw[0], self.out_hw[1]
         g.pad_mode = getattr(self, "pad_mode", 0)
+        g.tie_queue_cap = int(getattr(self, "tie_queue_cap", 0))
+        g.roi_y, g.roi_x, g.roi_h, g.roi_w = getattr(self, "roi", (0, 0, 0, 0))
         for k in ("left_r", "dis_r", "left_c", "dis_c", "dis_r64", "dis_c64"):
             setattr(g, k, self.t[k].data_ptr())
         self.struct = g
+
+    def with_tie_queue_cap(self, cap):
+        """Test hook (lerf_sr_geo_t.tie_queue_cap): a copy of this geometry whose launches queue at most `cap` rounding
+        ties per tile (0 entries: cap < 0 in the ABI; None restores the default) -- drives the in-loop fallback."""
+        g = object.__new__(SrGeometry)
+        g.__dict__.update(self.__dict__)
+        g.tie_queue_cap = 0 if cap is None else (-1 if int(cap) == 0 else int(cap))
+        g._upload()
+        return g
 
     def row_slice(self, lr_row0, lr_rows, out_row0, out_row1):
         """Geometry of a horizontal strip: the LR rows [lr_row0, lr_row0 + lr_rows) held locally
@@ -82,6 +93,22 @@ class SrGeometry:
         g.host = dict(left_r=(h["left_r"][out_row0:out_row1] - lr_row0).astype(np.int32),
                       dis_r=h["dis_r"][out_row0:out_row1], dis_r32=h["dis_r32"][out_row0:out_row1],
                       left_c=h["left_c"], dis_c=h["dis_c"], dis_c32=h["dis_c32"])
+        g._upload()
+        return g
+
+    def block_slice(self, lr_row0, lr_rows, out_row0, out_row1, lr_col0, lr_cols, out_col0, out_col1, roi=None):
+        """Geometry of a 2-D block: the LR rows [lr_row0, +lr_rows) x columns [lr_col0, +lr_cols) held locally (owned block
+        plus halo) produce the global output rows [out_row0, out_row1) x columns [out_col0, out_col1).  Both axes' tables
+        are the global ones rebased to the block.  roi = (y, x, h, w) of the OWNED block inside the local frame: the
+        tile-fused kernel lays its tiles over it, so halo pixels only ever serve as tile halos."""
+        g = self.row_slice(lr_row0, lr_rows, out_row0, out_row1)
+        h = self.host
+        g.in_hw = (int(lr_rows), int(lr_cols))
+        g.out_hw = (int(out_row1 - out_row0), int(out_col1 - out_col0))
+        g.host.update(left_c=(h["left_c"][out_col0:out_col1] - lr_col0).astype(np.int32),
+                      dis_c=h["dis_c"][out_col0:out_col1], dis_c32=h["dis_c32"][out_col0:out_col1])
+        if roi is not None:
+            g.roi = tuple(int(v) for v in roi)
         g._upload()
         return g
 
@@ -186,9 +213,34 @@ def stages_packed(img_u8, luts, workspace=None):
     elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
         raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
     _lib.check(_lib.lib().lerf_stages_packed_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(),
-                                                packed.data_ptr(), packed.stride(0), workspace.data_ptr(),
+                                                packed.data_ptr(), packed.stride(0), workspace.data_ptr(), workspace.numel(),
                                                 _lib.current_stream()), "lerf_stages_packed_u8")
     return packed[0] if squeeze else packed
+
+
+def stages_packed_ragged(imgs_u8, luts, workspace=None):
+    """Frames of DIFFERENT sizes, one launch pair (lerf_stages_packed_ragged_u8): list of uint8 [H_i,W_i,C] device tensors
+    -> list of int32 [H_i,W_i,C] packed stage outputs."""
+    torch = _torch()
+    if not imgs_u8:
+        return []
+    xs = [x.contiguous() for x in imgs_u8]
+    Cn = xs[0].shape[-1]
+    for x in xs:
+        if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[-1] != Cn or not x.is_cuda:
+            raise ValueError("ragged stages take uint8 [H,W,C] device tensors with one channel count")
+    outs = [torch.empty(tuple(x.shape), dtype=torch.int32, device=x.device) for x in xs]
+    items = (_lib.StageItem * len(xs))()
+    for it, x, o in zip(items, xs, outs):
+        it.img, it.packed, it.H, it.W = x.data_ptr(), o.data_ptr(), x.shape[0], x.shape[1]
+    need = int(_lib.lib().lerf_stages_ragged_workspace_bytes(items, len(xs), Cn))
+    if workspace is None:
+        workspace = _cached_workspace(need, xs[0].device)
+    elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
+        raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
+    _lib.check(_lib.lib().lerf_stages_packed_ragged_u8(items, len(xs), Cn, luts.ref(), workspace.data_ptr(), workspace.numel(),
+                                                       _lib.current_stream()), "lerf_stages_packed_ragged_u8")
+    return outs
 
 
 def unpack_stages(packed, oC):
@@ -201,22 +253,27 @@ def unpack_stages(packed, oC):
     return feat, hq
 
 
-def warp_packed(packed_hwc, geo: "WarpGeometry", kind="gauss", max_sigma=10.0, out="u8"):
-    """out: "u8" / "f32" (a fresh tensor) or a caller-owned uint8 / float32 tensor [oH,oW,C] to write into."""
+def warp_packed(packed, geo: "WarpGeometry", kind="gauss", max_sigma=10.0, out="u8"):
+    """packed: int32 [H,W,C] or a batch [N,H,W,C] sharing the homography (ONE launch for the batch).
+    out: "u8" / "f32" (a fresh tensor) or a caller-owned uint8 / float32 tensor of the output shape to write into."""
     torch = _torch()
-    p = packed_hwc.contiguous()
-    H, W, Cn = p.shape
+    squeeze = packed.dim() == 3
+    p = packed.unsqueeze(0) if squeeze else packed
+    if not p[0].is_contiguous():
+        p = p.contiguous()
+    N, H, W, Cn = p.shape
+    oshape = (N, geo.out_hw[0], geo.out_hw[1], Cn)
     if isinstance(out, str):
-        o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=p.device)
+        o = torch.empty(oshape, dtype=_out_dtype(out), device=p.device)
     else:
-        o = out
-        if tuple(o.shape) != (geo.out_hw[0], geo.out_hw[1], Cn) or o.dtype not in (torch.uint8, torch.float32) \
-                or o.device != p.device or o.stride(2) != 1:
-            raise ValueError("out must be a uint8/float32 [oH,oW,C] tensor on the input's device")
-    po = _planes_hwc(o)
-    _lib.check(_lib.lib().lerf_warp_packed(p.data_ptr(), H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
-                                           C.byref(po), _lib.current_stream()), "lerf_warp_packed")
-    return o
+        o = out.unsqueeze(0) if (squeeze and out.dim() == 3) else out
+        if tuple(o.shape) != oshape or o.dtype not in (torch.uint8, torch.float32) or o.device != p.device \
+                or o.stride(3) != 1:
+            raise ValueError("out must be a uint8/float32 tensor of shape %s on the input's device" % (oshape[1:] if squeeze else oshape,))
+    po = _lib.plane(o, o.stride(1), o.stride(2), o.stride(3))
+    _lib.check(_lib.lib().lerf_warp_packed(p.data_ptr(), p.stride(0), N, H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
+                                           C.byref(po), o.stride(0), _lib.current_stream()), "lerf_warp_packed")
+    return o[0] if squeeze else o
 
 
 # --------------------------------------------------------------------------- A5/A6/A8
@@ -319,19 +376,24 @@ def warp_planar(feat, hypers, geo: WarpGeometry, kind="gauss", max_sigma=10.0, o
 _WS = {}
 
 
-def fused_workspace(H, W, Cn, N, device):
-    """Device scratch of lerf_sr_fused_workspace_bytes() bytes for the two-launch fused path (stage-1 output of the
-    batch between s1_kernel and the stage-2/3 launch), cached per device and grown on demand: repeated calls on one
-    stream reuse it (launches on a stream are ordered, so the previous call has consumed it).  Callers that run
-    several streams concurrently pass their own `workspace=`."""
+def _cached_workspace(need, device):
+    """Scratch of at least `need` bytes, cached per (device, stream): launches on ONE stream are ordered, so the previous call
+    on that stream has consumed the buffer; another stream (or thread with its own stream) gets a buffer of its own instead
+    of racing for this one."""
     torch = _torch()
-    need = max(int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N)), 1)
-    key = (device.type, device.index)
+    need = max(int(need), 1)
+    key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
     ws = _WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
+
+
+def fused_workspace(H, W, Cn, N, device):
+    """Device scratch of lerf_sr_fused_workspace_bytes() bytes for the two-launch fused path (stage-1 output of the
+    batch between s1_kernel and the stage-2/3 launch), cached per device AND stream and grown on demand."""
+    return _cached_workspace(int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N)), device)
 
 
 def _gpu_visible(t):
@@ -354,7 +416,9 @@ def _check_out_u8(out, shape, device, what):
 
 def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out=None, workspace=None):
     """uint8 [H,W,C] or [N,H,W,C] -> uint8 [oH,oW,C] / [N,oH,oW,C].  Two launches per call (stage 1 over the batch into
-    the workspace, then stages 2+3 per tile); `out` (same rank as the input) and `workspace` may be caller-owned."""
+    the workspace, then stages 2+3 per tile); `out` (same rank as the input) and `workspace` may be caller-owned.
+    workspace=False: ONE launch, every tile recomputes stage 1 on its halo -- the better choice for a single frame or
+    block that fills the chip once (no workspace, no second launch)."""
     torch = _torch()
     if img_u8.dtype != torch.uint8:
         raise ValueError("img must be uint8")
@@ -370,17 +434,74 @@ def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out
     oshape = (N, geo.out_hw[0], geo.out_hw[1], Cn)
     if not _gpu_visible(img):
         raise ValueError("img must live in device memory or pinned host memory")
+    dev = img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device())
     if out is None:
-        o4 = torch.empty(oshape, dtype=torch.uint8, device=img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+        o4 = torch.empty(oshape, dtype=torch.uint8, device=dev)
     else:
         o4 = out.unsqueeze(0) if (squeeze and out.dim() == 3) else out
         _check_out_u8(o4, oshape, img.device, "out")
     need = int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N))
-    if workspace is None:
-        workspace = fused_workspace(H, W, Cn, N, img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device()))
-    elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
-        raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
+    if workspace is False:
+        ws_ptr, ws_n = None, 0
+    else:
+        if workspace is None:
+            workspace = fused_workspace(H, W, Cn, N, dev)
+        elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
+            raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
+        ws_ptr, ws_n = workspace.data_ptr(), workspace.numel()
     _lib.check(_lib.lib().lerf_sr_fused_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(), geo.ref(),
                                            KINDS[kind], float(max_sigma), o4.data_ptr(), o4.stride(0),
-                                           workspace.data_ptr(), _lib.current_stream()), "lerf_sr_fused_u8")
+                                           ws_ptr, ws_n, _lib.current_stream()), "lerf_sr_fused_u8")
     return o4[0] if squeeze else o4
+
+
+def sr_fused_supported(Cn, luts, geo: SrGeometry, kind="gauss"):
+    """True when lerf_sr_fused_u8 takes the tile-fused kernels for this configuration (else: the three direct kernels)."""
+    return bool(_lib.lib().lerf_sr_fused_supported(int(Cn), luts.ref(), geo.ref(), geo.in_hw[0], geo.in_hw[1], KINDS[kind]))
+
+
+def sr_fused_ragged_u8(imgs_u8, luts, geos, kind="gauss", max_sigma=10.0, workspace=None):
+    """Frames of DIFFERENT sizes through one launch pair (lerf_sr_fused_ragged_u8): lists of uint8 [H_i,W_i,C] device
+    tensors and their SrGeometry -> list of uint8 [oH_i,oW_i,C].  What the reference's harness does image by image over a
+    benchmark folder (eval_lut_sr.py:489-512)."""
+    torch = _torch()
+    if len(imgs_u8) != len(geos) or not imgs_u8:
+        raise ValueError("one geometry per image")
+    xs = [x.contiguous() for x in imgs_u8]
+    Cn = xs[0].shape[-1]
+    for x, g in zip(xs, geos):
+        if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[-1] != Cn or not x.is_cuda:
+            raise ValueError("ragged SR takes uint8 [H,W,C] device tensors with one channel count")
+        if tuple(x.shape[:2]) != g.in_hw:
+            raise ValueError("geometry was built for another input size")
+    outs = [torch.empty((g.out_hw[0], g.out_hw[1], Cn), dtype=torch.uint8, device=x.device) for x, g in zip(xs, geos)]
+    items = (_lib.SrItem * len(xs))()
+    for it, x, o, g in zip(items, xs, outs, geos):
+        it.img, it.out, it.H, it.W, it.geo = x.data_ptr(), o.data_ptr(), x.shape[0], x.shape[1], g.struct
+    need = int(_lib.lib().lerf_sr_ragged_workspace_bytes(items, len(xs), Cn))
+    if workspace is None:
+        workspace = _cached_workspace(need, xs[0].device)
+    elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
+        raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
+    _lib.check(_lib.lib().lerf_sr_fused_ragged_u8(items, len(xs), Cn, luts.ref(), KINDS[kind], float(max_sigma),
+                                                  workspace.data_ptr(), workspace.numel(), _lib.current_stream()),
+               "lerf_sr_fused_ragged_u8")
+    return outs
+
+
+def rect_copy(frames_u8, staging_u8, rects, to_staging):
+    """lerf_rect_copy_u8: rectangles (y, x, h, w, byte offset in staging) of a dense uint8 batch [N,fh,fw,C] <-> one
+    contiguous staging tensor, ONE launch (halo pack / unpack of dist.BlockBuffer)."""
+    torch = _torch()
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or not frames_u8.is_contiguous() or not staging_u8.is_contiguous():
+        raise ValueError("frames must be a dense uint8 [N,fh,fw,C] tensor, staging contiguous")
+    if not 1 <= len(rects) <= _lib.LERF_MAX_RECTS:
+        raise ValueError("1..%d rectangles" % _lib.LERF_MAX_RECTS)
+    N, fh, fw, Cn = frames_u8.shape
+    arr = (_lib.Rect * len(rects))()
+    for a, (y, x, h, w, off) in zip(arr, rects):
+        a.y, a.x, a.h, a.w, a.off = int(y), int(x), int(h), int(w), int(off)
+        if off + N * h * w * Cn > staging_u8.numel():
+            raise ValueError("staging buffer too small")
+    _lib.check(_lib.lib().lerf_rect_copy_u8(frames_u8.data_ptr(), N, fh, fw, Cn, staging_u8.data_ptr(), arr, len(rects),
+                                            1 if to_staging else 0, _lib.current_stream()), "lerf_rect_copy_u8")

@@ -52,7 +52,7 @@ class LerfEngine:
 
     # -- stages 1+2
     def _fused_stages_ok(self, x):
-        return x.shape[-1] == 3 and self.luts.struct.fused_pack is not None
+        return x.shape[-1] in (1, 3, 4) and self.luts.struct.fused_pack is not None
 
     def stages(self, img):
         x, as_np = self._dev(img)

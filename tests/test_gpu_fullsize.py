@@ -117,18 +117,19 @@ def test_tie_queue_full_falls_back_in_loop(torch, co, eng_g, eng_g4, eng_l, luts
     """Stage 3 queues the outputs that sit on a rounding tie (about 15 per 64x64 tile) and re-evaluates them in float64
     behind the task loop; with the queue capacity lowered to 0 / 8 entries nearly all of them take the in-loop fallback
     instead.  Both routes must give the reference's bytes (2x2 and 4x4 Gaussian, linear)."""
-    from lerf_pytorch_amd import _lib
-    lib = _lib.lib()
+    from lerf_pytorch_amd import ops
     img = _frame("noise", 540, 960, 77)
-    old = lib.lerf_debug_set_tie_queue_cap(cap)
-    try:
-        assert old == 2048
-        _bytes_equal(eng_g.sr(img, 2), co.sr_u8(img, luts_g, 2, 2), "LeRF-G S=2, tie queue of %d" % cap)
-        _bytes_equal(eng_g4.sr(img, 2), co.sr_u8(img, luts_g, 2, 2, S=4), "LeRF-G S=4, tie queue of %d" % cap)
-        _bytes_equal(eng_l.sr(img, (1.5, 2.0)), co.sr_u8(img, luts_l, 1.5, 2.0, linear=True), "LeRF-L, tie queue of %d" % cap)
-    finally:
-        assert lib.lerf_debug_set_tie_queue_cap(-1) == cap
-    assert lib.lerf_debug_set_tie_queue_cap(-1) == 2048
+    x = torch.from_numpy(img).cuda()
+
+    def run(eng, scale):
+        geo = eng.sr_geometry((540, 960), scale).with_tie_queue_cap(cap)      # lerf_sr_geo_t.tie_queue_cap: carried per call
+        assert geo.struct.tie_queue_cap == (-1 if cap == 0 else cap)
+        return ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma).cpu().numpy()
+
+    _bytes_equal(run(eng_g, 2), co.sr_u8(img, luts_g, 2, 2), "LeRF-G S=2, tie queue of %d" % cap)
+    _bytes_equal(run(eng_g4, 2), co.sr_u8(img, luts_g, 2, 2, S=4), "LeRF-G S=4, tie queue of %d" % cap)
+    _bytes_equal(run(eng_l, (1.5, 2.0)), co.sr_u8(img, luts_l, 1.5, 2.0, linear=True), "LeRF-L, tie queue of %d" % cap)
+    assert eng_g.sr_geometry((540, 960), 2).struct.tie_queue_cap == 0          # the engine's cached geometry is untouched
 
 
 def test_config5_4k_to_8k_properties(torch, co, eng_g, luts_g):
