@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the LeRF LUT resampling hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4,5}] [--mode frames|strips]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4,5}] [--mode frames|strips|blocks]
+                    [--scale S] [--channels {1,3,4}] [--sustained SECONDS]
 
 Default = BASELINE.json configs[1], the configuration the headline metric is quoted on: LeRF-G LUT x2 SR,
 1920x1080 -> 3840x2160 RGB.  One "step" = one pass of the hot path (stage-1 LUTs -> stage-2 LUTs -> spatially
@@ -13,7 +14,9 @@ one rank per GPU, RCCL); a failing rank makes the whole command fail.  Under tor
   --mode frames (default): every rank processes its own batch -- frames are independent, no data-path collective
                            (weak scaling; the barrier only brackets the timed region);
   --mode strips:           every frame is split into LR strips over the ranks with an RCCL halo exchange of raw
-                           uint8 rows (strong scaling on the same batch).
+                           uint8 rows (strong scaling on the same batch; SURVEY.md 8e);
+  --mode blocks:           every frame is split into a 2-D grid of blocks (8 ranks: 2 x 4; edges + corners exchanged in
+                           one RCCL group): a 2160x3840 frame is 255 tiles per rank, one round of workgroups.
 
 --config: 1 = 256x256 tile through the CPU oracle port (plumbing; 1 thread and all cores) beside the GPU,
           2 = headline, 3 = LeRF-L x1.5/x2.0 (and x2/x2), 4 = LeRF-G homographic warp 1080p -> 4K (isc / osc
@@ -36,7 +39,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-C = 3
+C = 3                                                   # channels per pixel (--channels overrides it for config 2)
 LUT_BYTES = {"lerf-g": 1753941, "lerf-l": 751689}      # 3 x 83521 + 6 x 83521 x oC
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 M_ISC = [[2.05, 0.12, 15.0], [-0.08, 1.95, 40.0], [1.5e-5, -1.0e-5, 1.0]]
@@ -95,11 +98,13 @@ def cpu_baseline_sr(frames_u8, model, sh, sw, budget_s=12.0, threads=None, max_n
     if threads is not None:
         c_oracle.set_threads(threads)
     thr = c_oracle.threads()
+    # one untimed call: the work area and the output frame are allocated and first-touched here (caller-owned scratch of
+    # lerf_oracle_sr_u8_ws, cached by the wrapper), not inside the timed loop
+    out = c_oracle.sr_u8(frames_u8[0], luts, sh, sw, S=S, linear=model == "lerf-l")
     t0 = time.perf_counter()
     n = 0
-    out = None
     while True:
-        out = c_oracle.sr_u8(frames_u8[n % len(frames_u8)], luts, sh, sw, S=S, linear=model == "lerf-l")
+        out = c_oracle.sr_u8(frames_u8[n % len(frames_u8)], luts, sh, sw, S=S, linear=model == "lerf-l", out=out)
         n += 1
         if time.perf_counter() - t0 >= budget_s or n >= max_n:
             break
@@ -192,10 +197,14 @@ def parse():
     ap.add_argument("--no-other-input", action="store_true",
                     help="skip the short secondary runs (profiling: keeps the kernel trace to one workload)")
     ap.add_argument("--unfused", action="store_true", help="config 2: time the 3-launch direct path instead")
-    ap.add_argument("--mode", choices=["frames", "strips"], default=None,
+    ap.add_argument("--scale", type=float, default=None, help="config 2: scale factor (default 2; > 4.9 takes the general kernels)")
+    ap.add_argument("--channels", type=int, choices=[1, 3, 4], default=3, help="config 2: channels per pixel (1 / 4: general kernels)")
+    ap.add_argument("--sustained", type=float, default=5.0,
+                    help="seconds of back-to-back steps for the `sustained` leg (0 = skip; reported beside `value`, never replacing it)")
+    ap.add_argument("--mode", choices=["frames", "strips", "blocks"], default=None,
                     help="frames: independent frames per GPU (default; config 5: the batch is divided over the GPUs); "
                          "strips: every frame is split into LR strips over the GPUs with an RCCL halo exchange "
-                         "(default for --config 5 with N > 1)")
+                         "(default for --config 5 with N > 1); blocks: a 2-D grid of blocks instead (8 GPUs: 2 x 4)")
     return ap.parse_args()
 
 
@@ -230,17 +239,25 @@ def main():
     if args.gpus != n_gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    global C
     cfg = args.config
     model = "lerf-l" if cfg == 3 else "lerf-g"
     H, W = (2160, 3840) if cfg == 5 else (1080, 1920)
     scale = (1.5, 2.0) if cfg == 3 else (2.0, 2.0)
+    if cfg == 2 and args.scale:
+        scale = (float(args.scale), float(args.scale))
+    if cfg == 2:
+        C = args.channels
+    elif args.channels != 3 or args.scale:
+        raise SystemExit("--channels / --scale vary config 2 only")
     S = args.support if cfg == 2 else 2
     kind = "linear" if model == "lerf-l" else "gauss"
     input_kind = args.input or ("natural" if cfg == 4 else "noise")
     mode = args.mode or ("strips" if (cfg == 5 and world > 1) else "frames")
-    strips = mode == "strips" and world > 1
+    strips = mode in ("strips", "blocks") and world > 1          # any partition of the FRAME over the ranks
+    blocks = mode == "blocks" and world > 1
     if strips and cfg == 4:
-        raise SystemExit("strips mode is an SR partition; the warp path scales by frames")
+        raise SystemExit("strips / blocks are SR partitions; the warp path scales by frames")
 
     eng = L.LerfEngine.shipped(model, support=S, max_sigma=10.0)
     B = args.frames
@@ -255,11 +272,29 @@ def main():
     if cfg == 5 and not strips:
         host = host[rank * B_local:(rank + 1) * B_local]
     ms = eng.max_sigma
+    buf_px = H * W
 
     def make_sr(scale_hw):
+        nonlocal buf_px
         geo = eng.sr_geometry((H, W), list(scale_hw))
         oH, oW = geo.out_hw
         ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, B_local)), dtype=torch.uint8, device="cuda")
+        if blocks:
+            from lerf_pytorch_amd import dist as ldist
+            lr_, lc_ = geo.host["left_r"], geo.host["left_c"]
+            plan = ldist.BlockPlan(H, W, ldist.block_grid(world), rank, eng.support, lr_, lc_)
+            lgeo = ldist.block_geometry(geo, plan)
+            buf = ldist.BlockBuffer(plan, B_local, C, torch.uint8, torch.device("cuda"), lr_, lc_)
+            buf.own.copy_(torch.from_numpy(np.ascontiguousarray(host[:, plan.y0:plan.y1, plan.x0:plan.x1])).cuda())
+            out = torch.empty((B_local, plan.i1 - plan.i0, plan.j1 - plan.j0, C), dtype=torch.uint8, device="cuda")
+
+            buf_px = buf.ext.shape[1] * buf.ext.shape[2]
+
+            def step(o=out):
+                ext = buf.exchange()
+                # one frame per launch: ONE launch without the stage-1 pass (255 tiles fill the chip once); a batch: two launches
+                ops.sr_fused_u8(ext, eng.luts, lgeo, kind, ms, out=o, workspace=False)
+            return step, out, (oH, oW), None
         if strips:
             from lerf_pytorch_amd import dist as ldist
             plan = ldist.StripPlan(H, world, rank, eng.support, geo.host["left_r"])
@@ -267,6 +302,7 @@ def main():
             buf = ldist.StripBuffer(plan, B_local, W, C, torch.uint8, torch.device("cuda"))
             buf.own.copy_(torch.from_numpy(host[:, plan.y0:plan.y1]).cuda())      # this rank's rows of every frame
             out = torch.empty((B_local, plan.i1 - plan.i0, oW, C), dtype=torch.uint8, device="cuda")
+            buf_px = buf.ext.shape[1] * buf.ext.shape[2]
 
             def step(o=out):
                 ext = buf.exchange()
@@ -329,8 +365,30 @@ def main():
     weak = cfg != 5 and not strips
     pix_per_step = (n_gpus if weak else 1) * (B_local if weak else B) * oH * oW
     value = pix_per_step * args.steps / dt / 1e6
-    alg_bytes = B_local * (H * W * C + (out.shape[1] if strips else oH) * oW * C) + LUT_BYTES[model]   # this rank's launch
+    in_px_local = (buf_px if strips else H * W)                                    # LR pixels this rank reads per frame
+    out_px_local = out.shape[1] * out.shape[2]                                     # output pixels this rank writes per frame
+    alg_bytes = B_local * (in_px_local * C + out_px_local * C) + LUT_BYTES[model]  # this rank's launch
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+
+    # sustained leg: seconds of back-to-back steps (clocks and temperatures settle; reported beside `value`, never instead)
+    sustained = None
+    if args.sustained > 0:
+        barrier()
+        t0 = time.perf_counter()
+        n_sus = 0
+        while True:
+            for _ in range(20):
+                step()
+            n_sus += 20
+            torch.cuda.synchronize()
+            stop = torch.tensor([1.0 if time.perf_counter() - t0 >= args.sustained else 0.0], device="cuda")
+            if world > 1:
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+            if stop.item() > 0:
+                break
+        barrier()
+        ds = time.perf_counter() - t0
+        sustained = (n_sus, ds)
 
     extra = {}
     single = rank == 0 and world == 1 and not args.no_other_input
@@ -393,11 +451,18 @@ def main():
         except Exception:
             traffic, tsrc, binding = None, None, None
 
-    names = {2: ("Mpix/s LeRF-G x2 SR (2K->4K)", "LeRF-G LUT x2 SR, 1920x1080->3840x2160 RGB uint8, S=%d, max_sigma=10 (BASELINE configs[1])" % S),
+    chn = {1: "grey", 3: "RGB", 4: "RGBA"}[C]
+    names = {2: ("Mpix/s LeRF-G x%g SR (2K->%s)" % (scale[0], "4K" if scale[0] == 2.0 else "%dx%d" % (oW, oH)),
+                 "LeRF-G LUT x%g SR, 1920x1080->%dx%d %s uint8, S=%d, max_sigma=10 (BASELINE configs[1]%s)"
+                 % (scale[0], oW, oH, chn, S, "" if (scale[0] == 2.0 and C == 3 and S == 2) else ", varied")),
              3: ("Mpix/s LeRF-L x1.5/x2.0 SR (2K input)", "LeRF-L LUT anisotropic SR x1.5/x2.0, 1920x1080->3840x1620 RGB uint8, S=2 (BASELINE configs[2])"),
              4: ("Mpix/s LeRF-G homographic warp (2K->4K)", "LeRF-G LUT homographic warp, 1920x1080->3840x2160 RGB uint8, isc-like matrix, S=2 (BASELINE configs[3])"),
              5: ("Mpix/s LeRF-G x2 SR (4K->8K, batch 8)", "LeRF-G LUT x2 SR, batch of %d frames 3840x2160->7680x4320 RGB uint8, S=2 (BASELINE configs[4])" % B)}
-    if strips:
+    if blocks:
+        from lerf_pytorch_amd import dist as ldist
+        par = "2-D blocks of every frame over %d GPUs (%d x %d grid), RCCL halo exchange of %d raw uint8 rows / columns with up to 8 neighbours (one batch_isend_irecv), one pack and one unpack launch" % (
+            (n_gpus,) + ldist.block_grid(n_gpus) + (3 + 3 + S // 2,))
+    elif strips:
         par = "LR strips of every frame over %d GPUs, RCCL halo exchange of %d raw uint8 rows per side (batch_isend_irecv)" % (n_gpus, 3 + 3 + S // 2)
     elif cfg == 5:
         par = "the batch divided over %d GPU(s), whole frames, no data-path collective" % n_gpus
@@ -410,14 +475,29 @@ def main():
         "vs_baseline": None, "dtype": "i32+f32 (u8 io)", "data": "synthetic",
         "config": {"workload": names[cfg][1], "baseline_config": cfg, "frames_per_step_per_gpu": B_local, "input": input_kind,
                    "path": "unfused-3-launch" if args.unfused else ("stages_packed + warp_packed" if cfg == 4 else "sr_fused_u8"),
-                   "mode": "strips" if strips else "frames", "parallelism": par, "ranks_reported_by_rccl": rccl_ranks},
+                   "mode": mode if strips else "frames", "parallelism": par, "ranks_reported_by_rccl": rccl_ranks,
+                   "channels": C, "scale": list(scale)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                      "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                      "binding_resource": "valu_issue (gather/VALU-bound path, HBM is the nominal roofline only: %.2f B per output pixel; DESIGN.md section 5)"
-                                         % ((alg_bytes - LUT_BYTES[model]) / (B_local * (out.shape[1] if strips else oH) * oW)),
+                                         % ((alg_bytes - LUT_BYTES[model]) / (B_local * out_px_local)),
                      "binding_resources_from_pmc": binding},
+        # LR (input) pixels per second: what the LUT stages see -- the fair comparison between scale factors
+        "lr_mpix_s": round(value * (H * W) / (oH * oW), 2),
     }
+    if binding and "valu_instr_per_cu_cycle" in binding:
+        # the resource that binds (recorded PMC of these kernel sources): VALU wave-instructions issued per CU-cycle against the
+        # 2.0 a CU can issue (4 SIMDs x one full-rate wave64 instruction per 2 cycles; three quarters of this kernel's mix is
+        # the half-rate class, so its own ceiling is ~1.15: DESIGN.md section 5)
+        res["roofline_valu"] = {"bound": "valu", "achieved": binding["valu_instr_per_cu_cycle"], "peak": 2.0,
+                                "unit": "wave-instr/CU-cycle", "frac": round(binding["valu_instr_per_cu_cycle"] / 2.0, 4),
+                                "source": tsrc}
+        res["roofline"]["bound_note"] = "nominal (contract): the binding resource is VALU issue, see roofline_valu"
+    if sustained:
+        res["sustained"] = {"seconds": round(sustained[1], 2), "steps": sustained[0],
+                            "value": round(pix_per_step * sustained[0] / sustained[1] / 1e6, 2), "unit": "Mpix/s",
+                            "ms_per_step": round(sustained[1] / sustained[0] * 1e3, 4)}
     res.update(extra)
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not strips:
@@ -434,13 +514,23 @@ def main():
                                          "mask_mismatches": int((mk != cpu_mask).sum())}
         else:
             budget = 12.0 if cfg != 5 else 20.0
+            if cfg == 2 and S == 2:
+                # scaling points of the port: one core on the 256x256 tile of BASELINE config 1 (a 1080p frame takes about a
+                # minute on one core), 32 threads on the frame, then every hardware thread (the figure in `cpu_baseline`)
+                tile = np.random.default_rng(0).integers(0, 256, (1, 256, 256, C), dtype=np.uint8)
+                cb1, _, _ = cpu_baseline_sr(tile, model, scale[0], scale[1], budget_s=5.0, threads=1, max_n=8)
+                res["cpu_baseline_single_thread"] = cb1
+                cb32, _, _ = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=5.0, threads=32, S=S)
+                res["cpu_baseline_32_threads"] = cb32
+                from oracle import c_oracle
+                c_oracle.set_threads(0)
             cb, cpu_out, n_cpu = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=budget, S=S)
             res["cpu_baseline"] = cb
             if cfg == 2 and S == 2:
-                # one core, on the 256x256 tile of BASELINE config 1 (a 1080p frame takes about a minute on one core)
-                tile = np.random.default_rng(0).integers(0, 256, (1, 256, 256, C), dtype=np.uint8)
-                cb1, _, _ = cpu_baseline_sr(tile, model, 2.0, 2.0, budget_s=6.0, threads=1, max_n=8)
-                res["cpu_baseline_single_thread"] = cb1
+                cb["scaling"] = {"threads_1_mpix_s": res["cpu_baseline_single_thread"]["value"],
+                                 "threads_32_mpix_s": res["cpu_baseline_32_threads"]["value"],
+                                 "threads_all_mpix_s": cb["value"],
+                                 "all_vs_single": round(cb["value"] / max(res["cpu_baseline_single_thread"]["value"], 1e-9), 1)}
             # the timed product output must equal the checker's (<= 1 LSB)
             ref_idx = (n_cpu - 1) % len(host)
             step()

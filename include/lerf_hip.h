@@ -254,7 +254,7 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
                      uint8_t* out, int64_t out_sn, void* workspace, size_t workspace_bytes, void* stream);
 /* 1 when lerf_sr_fused_u8 would take the tile-fused kernels for this configuration, 0 when it would fall back to the
  * direct kernels (host-side query, no device work) */
-int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind);
+int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind, double max_sigma);
 
 /* Frames of DIFFERENT sizes through ONE launch pair of the general tile-fused kernels (each workgroup finds its frame in a
  * descriptor table that travels in the kernel arguments; chunks of 16 frames per launch): what eltr.run does image by

@@ -144,7 +144,7 @@ def lib():
                                    C.POINTER(Plane), C.c_int64, C.c_void_p]
     L.lerf_rect_copy_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Rect), C.c_int, C.c_int,
                                     C.c_void_p]
-    L.lerf_sr_fused_supported.argtypes = [C.c_int, C.POINTER(Luts), C.POINTER(SrGeo), C.c_int, C.c_int, C.c_int]
+    L.lerf_sr_fused_supported.argtypes = [C.c_int, C.POINTER(Luts), C.POINTER(SrGeo), C.c_int, C.c_int, C.c_int, C.c_double]
     L.lerf_sr_ragged_workspace_bytes.restype = C.c_size_t
     L.lerf_sr_ragged_workspace_bytes.argtypes = [C.POINTER(SrItem), C.c_int, C.c_int]
     L.lerf_sr_fused_ragged_u8.argtypes = [C.POINTER(SrItem), C.c_int, C.c_int, C.POINTER(Luts), C.c_int, C.c_double, C.c_void_p,

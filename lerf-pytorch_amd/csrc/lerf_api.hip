@@ -380,13 +380,14 @@ static void fused_args_of(FusedArgs& f, int C, const lerf_luts_t* luts, const le
     f.tq_cap = geo->tie_queue_cap; f.pad_mode = geo->pad_mode;
 }
 
-int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind) {
+int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind, double max_sigma) {
     if (!luts || !geo || H < 1 || W < 1 || C < 1) return 0;
     if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return 0;
     if ((kind == LERF_KIND_GAUSS) != (luts->oC == 3)) return 0;
     FusedArgs f{};
     fused_args_of(f, C, luts, geo, H, W, kind);
     f.n = 1;
+    f.max_sigma = (float)max_sigma;
     f.workspace = (void*)1;          // "a workspace will be passed" (wrap padding needs the two-launch path)
     return fused_supported(f) ? 1 : 0;
 }
@@ -455,7 +456,7 @@ int lerf_sr_fused_ragged_u8(const lerf_sr_item_t* items, int n, int C, const ler
         const lerf_sr_item_t& s = items[i];
         if (!s.img || !s.out || s.H < 1 || s.W < 1 || !s.geo.left_r || !s.geo.left_c || !s.geo.dis_r || !s.geo.dis_c) return LERF_EINVAL;
         if (s.geo.S != items[0].geo.S || s.geo.pad_mode != items[0].geo.pad_mode) return LERF_EINVAL;
-        all = all && lerf_sr_fused_supported(C, luts, &s.geo, s.H, s.W, kind) && s.geo.roi_h == 0;
+        all = all && lerf_sr_fused_supported(C, luts, &s.geo, s.H, s.W, kind, max_sigma) && s.geo.roi_h == 0;
     }
     if (!all) {                       // some item has no tile-fused kernel: item by item (same results)
         for (int i = 0; i < n; ++i) {

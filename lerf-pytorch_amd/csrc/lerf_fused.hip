@@ -41,6 +41,7 @@ bool fused_supported(const FusedArgs& a) {
     if (!luts_packable(L) || !L->fused_pack) return false;
     if ((a.C != 1 && a.C != 3 && a.C != 4) || (a.S != 2 && a.S != 4)) return false;
     if (a.kind == LERF_KIND_LINEAR && a.S != 2) return false;
+    if (a.kind == LERF_KIND_GAUSS && !(a.max_sigma <= s3::kNoShiftMaxSigma)) return false;   // float64 direct kernel (lerf_stage3.h)
     if (a.pad_mode < LERF_PAD_CONSTANT || a.pad_mode > LERF_PAD_WRAP) return false;
     const bool roi = a.roi_h > 0 && a.roi_w > 0;
     if (a.pad_mode == LERF_PAD_WRAP && (a.workspace == nullptr || roi)) return false;      // far-side pixels come from the stage-1 output

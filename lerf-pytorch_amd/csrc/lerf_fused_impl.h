@@ -1343,9 +1343,8 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         const int ntask = ngrp * ndw;
         uint32_t* tq = reinterpret_cast<uint32_t*>(smem + D::OFF_TQ);
         int* tq_count = ctl + 23;                               // zeroed with the group table below
-        auto run_tasks = [&](auto gs_const, auto ns_const) {
+        auto run_tasks = [&](auto gs_const) {
         constexpr int GS = decltype(gs_const)::value;          // rows per group, 0 = read it per group
-        constexpr bool NS = decltype(ns_const)::value;         // Gaussian sums without the minimum shift (lerf_stage3.h)
         constexpr int GN = GS > 0 ? GS : GMAX;
         for (int t = tid; t < ntask; t += NT) {
             const int g = (int)__umulhi((unsigned)t, magic);
@@ -1410,7 +1409,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                                 else
                                     e[a * S + b] = s3::lin_factor(p0[a * S + b], dx, s3::dist_class_f(dx)) * ty[a * S + b];
                             }
-                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, SS, true, true, NS>(e, v);
+                        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, SS, true, true, true>(e, v);
                         if (DIST) {
                             packed[r] = s3::pack_u8_dist(xf, u, packed[r], &dist[DIST ? r * 4 + u : 0]);
                             dmax = __builtin_fmaxf(dmax, __builtin_fabsf(dist[DIST ? r * 4 + u : 0]));
@@ -1479,14 +1478,11 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         // the constant-size variants cover the integer scale factors (x2 -> 2 rows per group, ...); anything else reads
         // the group size per task
         constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
-        // max_sigma beyond kNoShiftMaxSigma (never the case with the reference's option defaults): the unshifted Gaussian sums
-        // could underflow, the generic loop with minimum-shifted weights takes over
-        const bool noshift = KIND != LERF_KIND_GAUSS || P.max_sigma <= s3::kNoShiftMaxSigma;
-        if (!noshift) run_tasks(std::integral_constant<int, 0>{}, std::false_type{});
-        else if (gsame == 2) run_tasks(std::integral_constant<int, 2>{}, std::true_type{});
-        else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{}, std::true_type{});
-        else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{}, std::true_type{});
-        else run_tasks(std::integral_constant<int, 0>{}, std::true_type{});
+        // (max_sigma <= s3::kNoShiftMaxSigma here: the host sends larger values to the float64 direct kernel, lerf_fused.hip)
+        if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});
+        else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{});
+        else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{});
+        else run_tasks(std::integral_constant<int, 0>{});
         // ---- tie pass: the queued outputs in float64, one per lane; each patches its byte behind the task loop's
         //      dword stores (drained and fenced by the barrier)
         if (P.dis_r64 != nullptr) {

@@ -183,7 +183,10 @@ template <> struct Loader<float> {
 template <typename T> struct Storer;
 template <> struct Storer<uint8_t> {
     // clip(np.round(x), 0, 255).astype(uint8)  (eval_lut_sr.py:663-665); NaN -> 0
-    template <typename A> static __device__ __forceinline__ void put(uint8_t* p, A v) { *p = s3::to_u8((float)v); }
+    template <typename A> static __device__ __forceinline__ void put(uint8_t* p, A v) {
+        if (sizeof(A) == 8) *p = s3::to_u8_d((double)v);      // float64 arithmetic: rounded once, from the double
+        else *p = s3::to_u8((float)v);
+    }
 };
 template <> struct Storer<float> {
     template <typename A> static __device__ __forceinline__ void put(float* p, A v) { *p = (float)v; }
@@ -216,10 +219,14 @@ struct TapAcc {
     __device__ __forceinline__ A finish() const {
         A num = 0, den = 0;
         if (KIND == LERF_KIND_GAUSS) {
+            // float32: shifted by the minimum (see above).  float64: NOT shifted -- the reference's own arithmetic
+            // (np.exp(-0.5 e), resize_right2d_numpy.py:150-160), including where its weights run into the denormal range
+            // for large max_sigma and lose mantissa bits: a shift would be more accurate than the reference, i.e. different
             A emin = e[0];
 #pragma unroll
             for (int k = 1; k < MAXT; ++k)
                 if (k < n) emin = e[k] < emin ? e[k] : emin;
+            if (sizeof(A) == 8) emin = (A)0;
 #pragma unroll
             for (int k = 0; k < MAXT; ++k)
                 if (k < n) {
@@ -231,8 +238,8 @@ struct TapAcc {
                     num += w * v[k];
                     den += w;
                 }
-            // float64 reference: every weight underflows to 0 -> 0/0 = NaN
-            if (emin * (A)0.5 > (A)745.2) return (A)(0.0 / 0.0);
+            // float64 reference: every weight underflows to 0 -> 0/0 = NaN (float32: emulated; float64: it happens by itself)
+            if (sizeof(A) == 4 && emin * (A)0.5 > (A)745.2) return (A)(0.0 / 0.0);
             return num / den;
         } else {
 #pragma unroll
@@ -321,11 +328,9 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                 }
             }
         }
-        // the unshifted sums only where they cannot underflow (lerf_stage3.h: kNoShiftMaxSigma); same choice as the fused kernel
+        // unshifted sums: max_sigma <= s3::kNoShiftMaxSigma on this path (launch_resize sends larger values to the float64 one)
         constexpr bool U8P = sizeof(TH) == 1 && sizeof(TO) == 1;
-        const float xf = (U8P && (float)max_sigma <= s3::kNoShiftMaxSigma)
-                             ? s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1, U8P, true>(e, v)
-                             : s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1, U8P, false>(e, v);
+        const float xf = s3::finish<KIND == LERF_KIND_GAUSS, MAXS * MAXS, sizeof(TO) == 1, U8P, U8P>(e, v);
         if (sizeof(TH) == 1 && sizeof(TO) == 1 && dis_r64 != nullptr && s3::near_tie(xf)) {
             double dx64[MAXS], dy64[MAXS];
 #pragma unroll
@@ -386,7 +391,7 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                     A tx = sx * dx, ty = sy * dy;
                     A e = tx * tx - (A)2 * rho * (tx * ty) + ty * ty;
                     if (pass == 0) {
-                        emin = (a == 0 && b == 0) ? e : (e < emin ? e : emin);
+                        emin = sizeof(A) == 8 ? (A)0 : ((a == 0 && b == 0) ? e : (e < emin ? e : emin));   // float64: unshifted, as TapAcc
                         continue;
                     }
                     w = sizeof(A) == 4 ? (A)__expf((float)((A)-0.5 * (e - emin))) : (A)exp((double)((A)-0.5 * (e - emin)));
@@ -436,7 +441,13 @@ int launch_resize(const ResizeArgs& a, hipStream_t st) {
     if (a.S < 1 || a.S > LERF_MAX_SUPPORT) return LERF_EUNSUPPORTED;
     if (a.kind >= LERF_KIND_NEAREST && a.kind <= LERF_KIND_LANCZOS3) return launch_resize_fixed(a, st);
     if (a.in_dtype == LERF_U8 && a.h_dtype == LERF_U8) {
-        if (a.out_dtype == LERF_U8) return resize_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
+        if (a.out_dtype == LERF_U8) {
+            // float32 production arithmetic + tie guard, sized for max_sigma <= 13 (lerf_stage3.h); beyond that the
+            // reference's own float64 arithmetic, rounded once
+            if (a.kind == LERF_KIND_GAUSS && a.max_sigma > (double)s3::kNoShiftMaxSigma)
+                return resize_dispatch_kind<uint8_t, uint8_t, uint8_t, double>(a, st);
+            return resize_dispatch_kind<uint8_t, uint8_t, uint8_t, float>(a, st);
+        }
         if (a.out_dtype == LERF_F32) return resize_dispatch_kind<uint8_t, uint8_t, float, double>(a, st);   // float64 arithmetic, rounded once
         if (a.out_dtype == LERF_F64) return resize_dispatch_kind<uint8_t, uint8_t, double, double>(a, st);
     } else if (a.in_dtype == LERF_F32 && a.h_dtype == LERF_F32) {
@@ -603,7 +614,7 @@ warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
                     A tx = sx * dx, ty = sy * dy;
                     A e = tx * tx - (A)2 * rho * (tx * ty) + ty * ty;
                     if (pass == 0) {
-                        emin = (a == 0 && b == 0) ? e : (e < emin ? e : emin);
+                        emin = sizeof(A) == 8 ? (A)0 : ((a == 0 && b == 0) ? e : (e < emin ? e : emin));   // float64: unshifted, as TapAcc
                         continue;
                     }
                     w = sizeof(A) == 4 ? (A)__expf((float)((A)-0.5 * (e - emin))) : (A)exp((double)((A)-0.5 * (e - emin)));

@@ -104,12 +104,13 @@ __device__ __forceinline__ float lin_factor(float alpha, float x, int cls) {
     return f < 0.0f ? 0.0f : f;                                            // negative weights clipped (:240)
 }
 
-// The unshifted Gaussian branch of finish() is safe only while exp2(-e') of the NEAREST tap is a normal float32: on an SR
-// grid that tap lies within half a pixel on both axes, so e' <= 0.5 log2(e) (0.25 + 0.25 + 0.5) max_sigma^2 =
-// 0.7214 max_sigma^2, which stays below 126 for max_sigma <= 13.2.  max_sigma is a free parameter of the reference's
-// classes (resize_right2d_numpy.py:143) and of the C ABI: every caller picks NOSHIFT = (max_sigma <= kNoShiftMaxSigma)
-// on the host side of the launch or by a wave-uniform branch, and larger values take the minimum-shifted sums, whose
-// largest weight is exactly 1 (the reference's float64 arithmetic never underflows there either).
+// The float32 production arithmetic of the uint8 paths (pre-scaled quadratic forms, unshifted exp2 sums, tie guard of
+// 1.5e-4) is sized for max_sigma <= kNoShiftMaxSigma: on an SR grid the nearest tap lies within half a pixel on both
+// axes, so its pre-scaled form is at most 0.5 log2(e) (0.25 + 0.25 + 0.5) max_sigma^2 = 0.7214 max_sigma^2 < 126 and
+// exp2 of it stays a normal float32 (the denominator cannot vanish), and the float32 rounding of forms of that size stays
+// far inside the tie guard.  max_sigma is a free parameter of the reference's classes (resize_right2d_numpy.py:143,
+// option.py:29 default 10) and of the C ABI: the HOST sends larger values through the float64 direct kernel
+// (launch_resize, fused_supported), whose arithmetic is the reference's own.
 constexpr float kNoShiftMaxSigma = 13.0f;
 
 // normalised weighted sum over N taps; e[] are quadratic forms (GAUSS) or weights

@@ -173,6 +173,219 @@ def sr_frame_strips(engine, own_rows, H, scale, group=None, gather=False):
     return gather_strips(out, counts, group)
 
 
+# --------------------------------------------------------------------------- 2-D block partition ("2x4 blocks")
+def block_grid(world: int):
+    """(rows, cols) of the block grid for `world` ranks: as square as possible with cols >= rows (8 -> 2 x 4, 4 -> 2 x 2,
+    6 -> 2 x 3, primes -> 1 x world)."""
+    gy = int(np.floor(np.sqrt(world)))
+    while world % gy:
+        gy -= 1
+    return gy, world // gy
+
+
+class BlockPlan:
+    """2-D partition of an H x W frame over a gy x gx grid of ranks (rank = ry * gx + rx) for a given SR geometry.
+
+    Why blocks when strips exist: a 2160x3840 frame in 8 strips is 270 + 14 rows x 3840 columns per rank = 5 x 60 = 300
+    tiles of 64 x 64 on 256 CUs (1.17 rounds of workgroups); in 2 x 4 blocks a rank owns 1080 x 960 LR pixels = 17 x 15 =
+    255 tiles -- ONE round -- because the tile-fused kernel lays its tiles over the OWNED block only (lerf_sr_geo_t roi)
+    and the halo pixels serve as tile halos.  Price: up to 8 neighbours (4 edges + 4 corners) in the halo exchange, still
+    one batch_isend_irecv (one RCCL group).
+
+    Ownership = the fused kernel's tile rule on both axes: output row i belongs to the block row that contains
+    left_r[i] + S/2, output column j to the block column that contains left_c[j] + S/2.  The halo is 3 + 3 + S/2 pixels;
+    the local column range is widened to multiples of `align` pixels (default 4) so that the local row pitch stays a
+    4-byte multiple and interior tiles keep their aligned dword loads -- a wider halo is harmless.
+    """
+
+    def __init__(self, H, W, grid, rank, support, left_r, left_c, align=4):
+        gy, gx = int(grid[0]), int(grid[1])
+        world = gy * gx
+        if not (0 <= rank < world):
+            raise ValueError("bad rank/grid")
+        if H < gy or W < gx:
+            raise ValueError("fewer rows / columns than blocks")
+        self.H, self.W, self.grid, self.world, self.rank, self.S = int(H), int(W), (gy, gx), world, int(rank), int(support)
+        self.ry, self.rx = rank // gx, rank % gx
+        self.halo = halo_rows(self.S)
+        self.y0, self.y1 = self.ry * H // gy, (self.ry + 1) * H // gy            # owned LR rows / columns
+        self.x0, self.x1 = self.rx * W // gx, (self.rx + 1) * W // gx
+        self.ylo, self.yhi = max(self.y0 - self.halo, 0), min(self.y1 + self.halo, H)
+        a = max(int(align), 1)
+        self.xlo = max((self.x0 - self.halo) // a * a, 0)
+        self.xhi = min(-((-(self.x1 + self.halo)) // a) * a, W)
+        kr = np.asarray(left_r, dtype=np.int64) + self.S // 2
+        kc = np.asarray(left_c, dtype=np.int64) + self.S // 2
+        self.i0 = 0 if self.ry == 0 else int(np.searchsorted(kr, self.y0, side="left"))
+        self.i1 = len(kr) if self.ry == gy - 1 else int(np.searchsorted(kr, self.y1, side="left"))
+        self.j0 = 0 if self.rx == 0 else int(np.searchsorted(kc, self.x0, side="left"))
+        self.j1 = len(kc) if self.rx == gx - 1 else int(np.searchsorted(kc, self.x1, side="left"))
+
+    # local frame = rows [ylo, yhi) x columns [xlo, xhi); the owned block sits at `roi` inside it
+    @property
+    def local_hw(self):
+        return self.yhi - self.ylo, self.xhi - self.xlo
+
+    @property
+    def roi(self):
+        return self.y0 - self.ylo, self.x0 - self.xlo, self.y1 - self.y0, self.x1 - self.x0
+
+    def out_rect(self):
+        return self.i0, self.i1, self.j0, self.j1
+
+    def neighbours(self):
+        """[(rank, dy, dx)] of the up to 8 blocks this one exchanges halos with."""
+        gy, gx = self.grid
+        out = []
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ny, nx = self.ry + dy, self.rx + dx
+                if (dy or dx) and 0 <= ny < gy and 0 <= nx < gx:
+                    out.append((ny * gx + nx, dy, dx))
+        return out
+
+    def _overlap(self, other: "BlockPlan"):
+        """global rectangle of `other`'s OWNED block that lies inside this rank's local frame: (y, x, h, w) or None"""
+        ya, yb = max(self.ylo, other.y0), min(self.yhi, other.y1)
+        xa, xb = max(self.xlo, other.x0), min(self.xhi, other.x1)
+        if ya >= yb or xa >= xb:
+            return None
+        return ya, xa, yb - ya, xb - xa
+
+    def check_support(self, left_r, left_c):
+        """every source pixel of every owned output pixel is held locally"""
+        lr = np.asarray(left_r)[self.i0:self.i1]
+        lc = np.asarray(left_c)[self.j0:self.j1]
+        if len(lr) == 0 or len(lc) == 0:
+            return True
+        r12 = STAGE1_RADIUS + STAGE2_RADIUS
+        ok_r = max(lr.min() - r12, 0) >= self.ylo and min(lr.max() + self.S - 1 + r12, self.H - 1) < self.yhi
+        ok_c = max(lc.min() - r12, 0) >= self.xlo and min(lc.max() + self.S - 1 + r12, self.W - 1) < self.xhi
+        return bool(ok_r and ok_c)
+
+
+class BlockBuffer:
+    """Persistent storage of one rank's block INCLUDING its halo: `ext` [N, yhi-ylo, xhi-xlo, C] is what the fused kernel
+    reads; `own` is the view of the rank's own block inside it (the producer writes there).  Per step: ONE pack launch
+    gathers the up to 8 outgoing rectangles into one staging tensor (lerf_rect_copy_u8; torch slicing on CPU tensors for the
+    gloo tests), one batch_isend_irecv moves a contiguous segment per neighbour, ONE unpack launch scatters the received
+    segments into the halo of `ext`."""
+
+    def __init__(self, plan: BlockPlan, N, C, dtype=None, device=None, left_r=None, left_c=None):
+        import torch
+        self.plan, self.N, self.C = plan, int(N), int(C)
+        dtype = dtype if dtype is not None else torch.uint8
+        lh, lw = plan.local_hw
+        self.ext = torch.empty((N, lh, lw, C), dtype=dtype, device=device)
+        ry, rx, rh, rw = plan.roi
+        self.own = self.ext[:, ry:ry + rh, rx:rx + rw]
+        # rectangles, in LOCAL coordinates of the sender / the receiver; both sides derive them from the same two plans
+        self.sends, self.recvs = [], []          # (peer, (y, x, h, w), byte offset, bytes)
+        so = ro = 0
+        for peer, _, _ in plan.neighbours():
+            other = BlockPlan(plan.H, plan.W, plan.grid, peer, plan.S, left_r if left_r is not None else np.zeros(1),
+                              left_c if left_c is not None else np.zeros(1))
+            out = other._overlap(plan)           # part of MY block the peer holds as halo
+            if out is not None:
+                y, x, h, w = out
+                nb = N * h * w * C
+                self.sends.append((peer, (y - plan.ylo, x - plan.xlo, h, w), so, nb))
+                so += nb
+            inc = plan._overlap(other)           # part of the PEER's block I hold as halo
+            if inc is not None:
+                y, x, h, w = inc
+                nb = N * h * w * C
+                self.recvs.append((peer, (y - plan.ylo, x - plan.xlo, h, w), ro, nb))
+                ro += nb
+        self.send_buf = torch.empty(max(so, 1), dtype=dtype, device=device)
+        self.recv_buf = torch.empty(max(ro, 1), dtype=dtype, device=device)
+
+    def _copy(self, rects, staging, to_staging):
+        if not rects:
+            return
+        if self.ext.is_cuda:
+            from . import ops
+            ops.rect_copy(self.ext, staging, [(y, x, h, w, off) for _, (y, x, h, w), off, _ in rects], to_staging)
+            return
+        for _, (y, x, h, w), off, nb in rects:   # host tensors (gloo tests): plain slicing
+            seg = staging[off:off + nb].view(self.N, h, w, self.C)
+            if to_staging:
+                seg.copy_(self.ext[:, y:y + h, x:x + w])
+            else:
+                self.ext[:, y:y + h, x:x + w].copy_(seg)
+
+    def exchange(self, group=None):
+        """Fill the halo of `ext` from the neighbouring blocks.  Returns `ext`.  World of 1: no-op."""
+        import torch.distributed as dist
+        if self.plan.world == 1:
+            return self.ext
+        self._copy(self.sends, self.send_buf, True)
+        ops_ = []
+        for peer, _, off, nb in self.sends:
+            ops_.append(dist.P2POp(dist.isend, self.send_buf[off:off + nb], peer, group))
+        for peer, _, off, nb in self.recvs:
+            ops_.append(dist.P2POp(dist.irecv, self.recv_buf[off:off + nb], peer, group))
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+        self._copy(self.recvs, self.recv_buf, False)
+        return self.ext
+
+
+def block_geometry(geo, plan: BlockPlan):
+    """the GLOBAL SrGeometry rebased to the rank's local frame, tiles laid over the owned block"""
+    lh, lw = plan.local_hw
+    return geo.block_slice(plan.ylo, lh, plan.i0, plan.i1, plan.xlo, lw, plan.j0, plan.j1, roi=plan.roi)
+
+
+def sr_block(engine, ext, plan: BlockPlan, geo, out=None):
+    """This rank's output rectangle [i0, i1) x [j0, j1) from its extended block.  ONE launch (no stage-1 workspace pass):
+    a block is sized to fill the chip once, and a second launch would only add its tail."""
+    from . import ops
+    return ops.sr_fused_u8(ext, engine.luts, block_geometry(geo, plan), engine.kind, engine.max_sigma, out=out, workspace=False)
+
+
+def gather_blocks(out_block, rects, out_hw, group=None):
+    """All ranks' output rectangles -> the whole frame on every rank: every rank contributes a (max rows x max cols) tile
+    (its own, zero-padded) to ONE all_gather_into_tensor, the frame is assembled from the valid parts.
+    out_block: [h, w, C] (or [N, h, w, C]); rects: [(i0, i1, j0, j1)] per rank."""
+    import torch
+    import torch.distributed as dist
+    batched = out_block.dim() == 4
+    x = out_block if batched else out_block.unsqueeze(0)
+    world = len(rects)
+    mh = max(r[1] - r[0] for r in rects)
+    mw = max(r[3] - r[2] for r in rects)
+    N, _, _, C = x.shape
+    mine = torch.zeros((N, mh, mw, C), dtype=x.dtype, device=x.device)
+    mine[:, :x.shape[1], :x.shape[2]].copy_(x)
+    allb = torch.empty((world, N, mh, mw, C), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(allb.view(world * N, mh, mw, C), mine, group=group)
+    frame = torch.empty((N, out_hw[0], out_hw[1], C), dtype=x.dtype, device=x.device)
+    for r, (i0, i1, j0, j1) in enumerate(rects):
+        frame[:, i0:i1, j0:j1].copy_(allb[r, :, :i1 - i0, :j1 - j0])
+    return frame if batched else frame[0]
+
+
+def sr_frame_blocks(engine, own_block, H, W, scale, grid=None, group=None, gather=False):
+    """SR of one H x W frame distributed over the process group by 2-D blocks (default grid: block_grid(world)).
+    own_block: this rank's pixels [y0:y1, x0:x1] (uint8 [h,w,C] on the GPU).  Returns this rank's output rectangle, or the
+    whole frame on every rank if gather=True."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    grid = grid or block_grid(world)
+    geo = engine.sr_geometry((H, W), scale)
+    lr, lc = geo.host["left_r"], geo.host["left_c"]
+    plan = BlockPlan(H, W, grid, rank, engine.support, lr, lc)
+    buf = BlockBuffer(plan, 1, own_block.shape[-1], own_block.dtype, own_block.device, lr, lc)
+    buf.own.copy_(own_block.unsqueeze(0))
+    out = sr_block(engine, buf.exchange(group), plan, geo)[0]
+    if not gather or world == 1:
+        return out
+    rects = [BlockPlan(H, W, grid, r, engine.support, lr, lc).out_rect() for r in range(world)]
+    return gather_blocks(out, rects, geo.out_hw, group)
+
+
 # --------------------------------------------------------------------------- data-parallel LUT fine-tuning
 def allreduce_grads(model, group=None):
     """Average the parameter gradients of a fine-tuning model over the ranks: the data-parallel counterpart of the

@@ -455,9 +455,10 @@ def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out
     return o4[0] if squeeze else o4
 
 
-def sr_fused_supported(Cn, luts, geo: SrGeometry, kind="gauss"):
+def sr_fused_supported(Cn, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0):
     """True when lerf_sr_fused_u8 takes the tile-fused kernels for this configuration (else: the three direct kernels)."""
-    return bool(_lib.lib().lerf_sr_fused_supported(int(Cn), luts.ref(), geo.ref(), geo.in_hw[0], geo.in_hw[1], KINDS[kind]))
+    return bool(_lib.lib().lerf_sr_fused_supported(int(Cn), luts.ref(), geo.ref(), geo.in_hw[0], geo.in_hw[1], KINDS[kind],
+                                                   float(max_sigma)))
 
 
 def sr_fused_ragged_u8(imgs_u8, luts, geos, kind="gauss", max_sigma=10.0, workspace=None):

@@ -77,6 +77,15 @@ class LerfEngine:
             out = ops.resize_hwc_u8(feat, hq, geo, self.kind, self.max_sigma, out="u8")
         return out.cpu().numpy() if as_np else out
 
+    def sr_many(self, imgs, scales):
+        """Frames of DIFFERENT sizes and scale factors in one ragged launch pair (ops.sr_fused_ragged_u8): what eltr.run
+        does image by image over a benchmark folder (eval_lut_sr.py:489-512).  imgs: list of uint8 [H_i,W_i,C];
+        scales: one scale (or (sh, sw)) per image.  Returns a list of uint8 [oH_i,oW_i,C] (numpy in -> numpy out)."""
+        xs, as_np = zip(*[self._dev(i) for i in imgs])
+        geos = [self.sr_geometry(x.shape[:2], s) for x, s in zip(xs, scales)]
+        outs = ops.sr_fused_ragged_u8(list(xs), self.luts, geos, self.kind, self.max_sigma)
+        return [o.cpu().numpy() if n else o for o, n in zip(outs, as_np)]
+
     def sr_float(self, img, scale):
         """float32 [oH,oW,C] before the final rounding (for tolerance checks)."""
         x, as_np = self._dev(img)
@@ -113,6 +122,26 @@ class LerfEngine:
         if as_np:
             return o.cpu().numpy(), (mask.cpu().numpy() if mask is not None else None)
         return o, mask
+
+
+    def warp_many(self, imgs, matrices, out_hws, border=4):
+        """The warp harness over a folder (eval_lut_warp.py:42-68): the LUT stages of ALL images in one ragged launch pair,
+        then one warp + one mask launch per image (every image has its own homography and size).
+        Returns [(uint8 [oH,oW,C], bool mask)] like warp()."""
+        torch = _lib.require_gpu()
+        xs, as_np = zip(*[self._dev(i) for i in imgs])
+        if not all(self._fused_stages_ok(x) for x in xs):
+            return [self.warp(x, M, hw, border) for x, M, hw in zip(xs, matrices, out_hws)]
+        packed = ops.stages_packed_ragged(list(xs), self.luts)
+        res = []
+        for x, pk, M, hw, n in zip(xs, packed, matrices, out_hws, as_np):
+            H, W, Cn = x.shape
+            o = ops.warp_packed(pk, ops.WarpGeometry((H, W), M, hw, self.support), self.kind, self.max_sigma, out="u8")
+            white = torch.zeros((H, W, Cn), dtype=torch.uint8, device=x.device)
+            white[border:H - border, border:W - border] = 255
+            mask = ops.warp_hwc_u8(white, None, ops.WarpGeometry((H, W), M, hw, 1), "nearest", 1.0, out="f32") == 255
+            res.append((o.cpu().numpy(), mask.cpu().numpy()) if n else (o, mask))
+        return res
 
 
 _ENGINES = {}

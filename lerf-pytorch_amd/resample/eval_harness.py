@@ -58,32 +58,41 @@ class Eltr:
         folder = os.path.join(self.opt.testDir, dataset, "HR")
         return sorted(f for f in os.listdir(folder) if "png" in f)
 
-    def run_sr(self, dataset, scale_h, scale_w):
-        """[[psnr, ssim], ...] per image (eval_lut_sr.py:487-512, 514-744)."""
+    def run_sr_many(self, dataset, scales):
+        """{(sh, sw): [[psnr, ssim], ...]}: every image of the dataset at every scale through ONE ragged launch pair
+        (the reference walks them one by one: eval_lut_sr.py:487-512, 514-744)."""
         from PIL import Image
-        rdir = self._result_dir("X{:.2f}_{:.2f}".format(scale_h, scale_w), dataset)
-        res = []
-        for f in self._files(dataset):
-            lr = _load_rgb(os.path.join(self.opt.testDir, dataset, "LR_bicubic/rrLR_X{:.2f}_{:.2f}".format(scale_h, scale_w), f))
-            gt = _load_rgb(os.path.join(self.opt.testDir, dataset, "HR", f))
-            out = self.engine.sr(self.engine._dev(lr)[0], (float(scale_h), float(scale_w)))
+        files = self._files(dataset)
+        jobs = [(sh, sw, f) for sh, sw in scales for f in files]
+        lrs = [_load_rgb(os.path.join(self.opt.testDir, dataset, "LR_bicubic/rrLR_X{:.2f}_{:.2f}".format(sh, sw), f)) for sh, sw, f in jobs]
+        outs = self.engine.sr_many([self.engine._dev(a)[0] for a in lrs], [(float(sh), float(sw)) for sh, sw, _ in jobs])
+        res = {tuple(sc): [] for sc in scales}
+        gts = {f: _load_rgb(os.path.join(self.opt.testDir, dataset, "HR", f)) for f in files}
+        for (sh, sw, f), out in zip(jobs, outs):
+            gt = gts[f]
+            rdir = self._result_dir("X{:.2f}_{:.2f}".format(sh, sw), dataset)
             if rdir:
                 Image.fromarray(out.cpu().numpy()).save(os.path.join(rdir, "{}_{}.png".format(f[:-4], self.opt.lutName)))
                 Image.fromarray(gt).save(os.path.join(rdir, "{}_gt.png".format(f[:-4])))
-            shave = max(int(scale_h), int(scale_w))
-            res.append([metrics.psnr_y(gt, out, shave), metrics.ssim_y(gt, out)])
+            shave = max(int(sh), int(sw))
+            res[(sh, sw)].append([metrics.psnr_y(gt, out, shave), metrics.ssim_y(gt, out)])
         return res
 
+    def run_sr(self, dataset, scale_h, scale_w):
+        """[[psnr, ssim], ...] per image (eval_lut_sr.py:487-512, 514-744)."""
+        return self.run_sr_many(dataset, [(scale_h, scale_w)])[(scale_h, scale_w)]
+
     def run_warp(self, dataset, mode):
-        """[[mpsnr], ...] per image (eval_lut_warp.py:42-68, 70-302)."""
+        """[[mpsnr], ...] per image (eval_lut_warp.py:42-68, 70-302); the LUT stages of all images run in one ragged launch"""
         from PIL import Image
         rdir = self._result_dir(dataset, mode)          # eval_lut_warp.py:51-56
+        files = self._files(dataset)
+        lrs = [_load_rgb(os.path.join(self.opt.testDir, dataset, mode, f)) for f in files]
+        gts = [_load_rgb(os.path.join(self.opt.testDir, dataset, "HR", f)) for f in files]
+        Ms = [_load_matrix(os.path.join(self.opt.testDir, dataset, mode, f[:-4])) for f in files]
+        outs = self.engine.warp_many([self.engine._dev(a)[0] for a in lrs], Ms, [g.shape[:2] for g in gts])
         res = []
-        for f in self._files(dataset):
-            lr = _load_rgb(os.path.join(self.opt.testDir, dataset, mode, f))
-            gt = _load_rgb(os.path.join(self.opt.testDir, dataset, "HR", f))
-            M = _load_matrix(os.path.join(self.opt.testDir, dataset, mode, f[:-4]))
-            out, mask = self.engine.warp(self.engine._dev(lr)[0], M, gt.shape[:2])
+        for f, gt, (out, mask) in zip(files, gts, outs):
             res.append([metrics.mpsnr(out, gt, mask)])
             if rdir:
                 m = mask.cpu().numpy()
@@ -100,8 +109,9 @@ def sr_table(etr, datasets=("Set5",), scales=((2, 2), (3, 3), (4, 4))):
     lines = ["\t".join(["Scale".ljust(15, " ")] + ["{:.1f}x{:.1f}\t".format(float(a), float(b)) for a, b in scales])]
     for ds in datasets:
         row = [ds.ljust(15, " ")]
+        allr = etr.run_sr_many(ds, [tuple(sc) for sc in scales])     # every image x every scale: one ragged launch pair
         for a, b in scales:
-            r = np.asarray(etr.run_sr(ds, a, b))
+            r = np.asarray(allr[(a, b)])
             row.append("{:.2f}/{:.4f}".format(np.mean(r[:, 0]), np.mean(r[:, 1])))
         lines.append("\t".join(row))
     return lines

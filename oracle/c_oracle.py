@@ -77,7 +77,13 @@ def resize(feat_u8, hq_u8, sh, sw, S=2, max_sigma=10.0, kind="gauss"):
     return out
 
 
-def sr_u8(img_u8, luts, sh, sw, S=2, max_sigma=10.0, linear=False, modes="sct", modes2="sct"):
+_SCRATCH = {}
+
+
+def sr_u8(img_u8, luts, sh, sw, S=2, max_sigma=10.0, linear=False, modes="sct", modes2="sct", out=None):
+    """uint8 HWC -> uint8 HWC.  The work area (stage outputs, geometry tables) is caller-owned in the C API and cached here
+    per shape, so a timing loop does not pay a quarter of a gigabyte of malloc + first-touch page faults per frame;
+    out: optional uint8 [oH,oW,C] array to write into (same reason)."""
     img = np.ascontiguousarray(img_u8, dtype=np.uint8)
     H, W, Cn = img.shape
     oC = 1 if linear else 3
@@ -85,10 +91,22 @@ def sr_u8(img_u8, luts, sh, sw, S=2, max_sigma=10.0, linear=False, modes="sct", 
         S, max_sigma = 2, 1.0
     s1, s2, keep = _lut_ptrs(luts, modes, modes2, oC)
     oH, oW = int(np.ceil(sh * H)), int(np.ceil(sw * W))
-    out = np.empty((oH, oW, Cn), np.uint8)
-    rc = lib().lerf_oracle_sr_u8(C.c_void_p(img.ctypes.data), H, W, Cn, modes.encode(), len(modes), s1,
-                                 modes2.encode(), len(modes2), s2, oC, C.c_double(sh), C.c_double(sw), int(S),
-                                 C.c_double(max_sigma), 1 if linear else 0, C.c_void_p(out.ctypes.data))
+    if out is None:
+        out = np.empty((oH, oW, Cn), np.uint8)
+    elif out.shape != (oH, oW, Cn) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+        raise ValueError("out must be a contiguous uint8 [oH,oW,C] array")
+    L = lib()
+    L.lerf_oracle_sr_scratch_bytes.restype = C.c_size_t
+    nb = int(L.lerf_oracle_sr_scratch_bytes(H, W, Cn, oC, C.c_double(sh), C.c_double(sw), int(S)))
+    key = (H, W, Cn, oC, float(sh), float(sw), int(S))
+    ws = _SCRATCH.get(key)
+    if ws is None or ws.nbytes < nb:
+        _SCRATCH.clear()                                          # one shape at a time
+        ws = _SCRATCH[key] = np.empty(nb, np.uint8)
+    rc = L.lerf_oracle_sr_u8_ws(C.c_void_p(img.ctypes.data), H, W, Cn, modes.encode(), len(modes), s1,
+                                modes2.encode(), len(modes2), s2, oC, C.c_double(sh), C.c_double(sw), int(S),
+                                C.c_double(max_sigma), 1 if linear else 0, C.c_void_p(out.ctypes.data),
+                                C.c_void_p(ws.ctypes.data))
     if rc:
         raise ValueError("lerf_oracle_sr_u8 failed")
     return out

@@ -87,7 +87,9 @@ static int lut_stage(const uint8_t* img, int H, int W, int C, const char* modes,
     for (int m = 0; m < n_modes; ++m)
         for (int r = 0; r < 4; ++r)
             if (rotated(modes[m], r, dy[m][r], dx[m][r])) return -1;
-#pragma omp parallel for schedule(static)
+    /* rows are dealt out dynamically in small chunks: with one static slab per thread the slowest hardware thread (SMT
+     * siblings, a busy core) sets the time of the whole stage */
+#pragma omp parallel for schedule(dynamic, 2)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x)
             for (int c = 0; c < C; ++c) {
@@ -140,19 +142,26 @@ static inline double lin_alpha(double x, double a) {   /* resize_right2d_numpy.p
 }
 
 /* stage 3 on the uint8 stage outputs (resize_right2d_numpy.py:162-223, 243-282).
- * feat [H][W][C], hq [H][W][C][oC]; out float64 [oH][oW][C]; kind 0 = gauss, 1 = linear */
-int lerf_oracle_resize(const uint8_t* feat, const uint8_t* hq, int H, int W, int C, int oC, double sh, double sw, int S,
-                       double max_sigma, int kind, double* out) {
+ * feat [H][W][C], hq [H][W][C][oC]; out float64 [oH][oW][C] and / or out8 uint8 [oH][oW][C] = clip(np.round(.)) of it
+ * (eval_lut_sr.py:663-665; either may be NULL); kind 0 = gauss, 1 = linear.  tables: scratch for the 1-D geometry,
+ * (oH + oW) ints + (oH + oW) * S doubles, or NULL (allocated here). */
+static int resize_core(const uint8_t* feat, const uint8_t* hq, int H, int W, int C, int oC, double sh, double sw, int S,
+                       double max_sigma, int kind, double* out, uint8_t* out8, void* tables) {
     int oH = (int)ceil(sh * H), oW = (int)ceil(sw * W);
-    int* lr = (int*)malloc(sizeof(int) * oH);
-    int* lc = (int*)malloc(sizeof(int) * oW);
-    double* dr = (double*)malloc(sizeof(double) * oH * S);
-    double* dc = (double*)malloc(sizeof(double) * oW * S);
-    if (!lr || !lc || !dr || !dc) return -1;
+    void* own = NULL;
+    if (!tables) {
+        own = malloc(sizeof(double) * (size_t)(oH + oW) * S + sizeof(int) * (size_t)(oH + oW));
+        if (!own) return -1;
+        tables = own;
+    }
+    double* dr = (double*)tables;
+    double* dc = dr + (size_t)oH * S;
+    int* lr = (int*)(dc + (size_t)oW * S);
+    int* lc = lr + oH;
     axis_tables(H, oH, sh, S, lr, dr);
     axis_tables(W, oW, sw, S, lc, dc);
     const float ms = (float)max_sigma;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < oH; ++i)
         for (int j = 0; j < oW; ++j)
             for (int c = 0; c < C; ++c) {
@@ -179,32 +188,57 @@ int lerf_oracle_resize(const uint8_t* feat, const uint8_t* hq, int H, int W, int
                         num += w * val;
                         den += w;
                     }
-                out[((size_t)i * oW + j) * C + c] = num / den;
+                const double v = num / den;
+                const size_t k = ((size_t)i * oW + j) * C + c;
+                if (out) out[k] = v;
+                if (out8) {
+                    double r = nearbyint(v);                 /* np.round: half to even (:663-665) */
+                    out8[k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+                }
             }
-    free(lr); free(lc); free(dr); free(dc);
+    free(own);
     return 0;
 }
 
-/* whole SR path, uint8 HWC -> uint8 HWC (eval_lut_sr.py:541-665) */
+int lerf_oracle_resize(const uint8_t* feat, const uint8_t* hq, int H, int W, int C, int oC, double sh, double sw, int S,
+                       double max_sigma, int kind, double* out) {
+    return resize_core(feat, hq, H, W, C, oC, sh, sw, S, max_sigma, kind, out, NULL, NULL);
+}
+
+/* whole SR path, uint8 HWC -> uint8 HWC (eval_lut_sr.py:541-665).
+ * scratch: caller-owned work area of lerf_oracle_sr_scratch_bytes() bytes (feat, hyper numerators, geometry tables), or
+ * NULL (allocated and freed per call).  A timing loop passes one buffer for all its calls: malloc'ing a quarter of a
+ * gigabyte per frame and first-touching it from 128 threads is page-fault time, not LeRF time.  The float64 frame of the
+ * reference is never materialised here: every value is rounded where it is produced (same bytes). */
+size_t lerf_oracle_sr_scratch_bytes(int H, int W, int C, int oC, double sh, double sw, int S) {
+    int oH = (int)ceil(sh * H), oW = (int)ceil(sw * W);
+    size_t a = ((size_t)H * W * C + 63) / 64 * 64, b = ((size_t)H * W * C * oC + 63) / 64 * 64;
+    return a + b + sizeof(double) * (size_t)(oH + oW) * S + sizeof(int) * (size_t)(oH + oW) + 64;
+}
+
+int lerf_oracle_sr_u8_ws(const uint8_t* img, int H, int W, int C, const char* modes1, int n1, const int8_t* const* s1,
+                         const char* modes2, int n2, const int8_t* const* s2, int oC, double sh, double sw, int S,
+                         double max_sigma, int kind, uint8_t* out, void* scratch) {
+    void* own = NULL;
+    if (!scratch) {
+        own = malloc(lerf_oracle_sr_scratch_bytes(H, W, C, oC, sh, sw, S));
+        if (!own) return -1;
+        scratch = own;
+    }
+    uint8_t* feat = (uint8_t*)scratch;
+    uint8_t* hq = feat + ((size_t)H * W * C + 63) / 64 * 64;
+    void* tables = hq + ((size_t)H * W * C * oC + 63) / 64 * 64;
+    tables = (void*)(((uintptr_t)tables + 7) & ~(uintptr_t)7);
+    int rc = lerf_oracle_lut_stages(img, H, W, C, modes1, n1, s1, modes2, n2, s2, oC, feat, hq);
+    if (!rc) rc = resize_core(feat, hq, H, W, C, oC, sh, sw, S, max_sigma, kind, NULL, out, tables);
+    free(own);
+    return rc;
+}
+
 int lerf_oracle_sr_u8(const uint8_t* img, int H, int W, int C, const char* modes1, int n1, const int8_t* const* s1,
                       const char* modes2, int n2, const int8_t* const* s2, int oC, double sh, double sw, int S,
                       double max_sigma, int kind, uint8_t* out) {
-    int oH = (int)ceil(sh * H), oW = (int)ceil(sw * W);
-    uint8_t* feat = (uint8_t*)malloc((size_t)H * W * C);
-    uint8_t* hq = (uint8_t*)malloc((size_t)H * W * C * oC);
-    double* o = (double*)malloc(sizeof(double) * (size_t)oH * oW * C);
-    if (!feat || !hq || !o) return -1;
-    int rc = lerf_oracle_lut_stages(img, H, W, C, modes1, n1, s1, modes2, n2, s2, oC, feat, hq);
-    if (!rc) rc = lerf_oracle_resize(feat, hq, H, W, C, oC, sh, sw, S, max_sigma, kind, o);
-    if (!rc) {
-        size_t n = (size_t)oH * oW * C;
-        for (size_t k = 0; k < n; ++k) {
-            double r = nearbyint(o[k]);                  /* np.round: half to even (:663-665) */
-            out[k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
-        }
-    }
-    free(feat); free(hq); free(o);
-    return rc;
+    return lerf_oracle_sr_u8_ws(img, H, W, C, modes1, n1, s1, modes2, n2, s2, oC, sh, sw, S, max_sigma, kind, out, NULL);
 }
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -257,7 +291,7 @@ int lerf_oracle_warp(const uint8_t* feat, const uint8_t* hq, int H, int W, int C
     lerf_oracle_warp_pads(minv, H, W, oH, oW, S, pads);
     const int plr = pads[0], plc = pads[2];
     const float ms = (float)max_sigma;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < oH; ++i)
         for (int j = 0; j < oW; ++j) {
             double gr, gc;
@@ -311,11 +345,13 @@ int lerf_oracle_warp_u8(const uint8_t* img, int H, int W, int C, const char* mod
     int rc = lerf_oracle_lut_stages(img, H, W, C, modes1, n1, s1, modes2, n2, s2, oC, feat, hq);
     if (!rc) rc = lerf_oracle_warp(feat, hq, H, W, C, oC, minv, oH, oW, S, max_sigma, kind, o);
     const size_t n = (size_t)oH * oW * C;
-    if (!rc)
+    if (!rc) {
+#pragma omp parallel for schedule(static)
         for (size_t k = 0; k < n; ++k) {
             double r = nearbyint(o[k]);                      /* NaN compares false everywhere -> 0 */
             out[k] = (uint8_t)(r > 0 ? (r > 255 ? 255 : r) : 0);
         }
+    }
     if (!rc && mask) {
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x)
@@ -323,8 +359,10 @@ int lerf_oracle_warp_u8(const uint8_t* img, int H, int W, int C, const char* mod
                     feat[((size_t)y * W + x) * C + c] =
                         (y >= border && y < H - border && x >= border && x < W - border) ? 255 : 0;
         rc = lerf_oracle_warp(feat, NULL, H, W, C, 0, minv, oH, oW, 1, 1.0, 2, o);
-        if (!rc)
+        if (!rc) {
+#pragma omp parallel for schedule(static)
             for (size_t k = 0; k < n; ++k) mask[k] = o[k] == 255.0;
+        }
     }
     free(feat); free(hq); free(o);
     return rc;

@@ -1,0 +1,107 @@
+"""CPU tests of the 2-D block partition (SURVEY.md 8e "2x4 blocks"): plan coverage, and gloo runs with world 4 (2 x 2)
+and 8 (2 x 4) in which the halo exchange (edges + corners, one batch_isend_irecv) delivers exactly the pixels each rank
+needs and the stitched per-block results reproduce the full frame.  The per-block compute here is the ORACLE (the
+checker); the product compute path needs a GPU (tests/test_gpu_general.py::test_blocks_emulated_equal_full_frame)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import lerf_pytorch_amd  # noqa: F401
+from lerf_pytorch_amd import dist as ldist
+
+
+@pytest.mark.parametrize("H,W,grid,S,scale", [(64, 96, (2, 4), 2, 2.0), (45, 50, (2, 2), 2, 1.5), (2160, 3840, (2, 4), 2, 2.0),
+                                              (1080, 1920, (2, 4), 4, 2.0), (77, 131, (2, 3), 2, 2.4), (90, 61, (1, 3), 4, 3.0)])
+def test_block_plan_covers_the_frame_and_its_support(oracle, H, W, grid, S, scale):
+    lr, _, _, _ = oracle.sr_axis_tables(H, oracle.out_size(H, scale), scale, S)
+    lc, _, _, _ = oracle.sr_axis_tables(W, oracle.out_size(W, scale), scale, S)
+    owned = np.zeros((H, W), np.int32)
+    outs = np.zeros((len(lr), len(lc)), np.int32)
+    for r in range(grid[0] * grid[1]):
+        p = ldist.BlockPlan(H, W, grid, r, S, lr, lc)
+        assert p.halo == 3 + 3 + S // 2
+        assert p.check_support(lr, lc)
+        owned[p.y0:p.y1, p.x0:p.x1] += 1
+        i0, i1, j0, j1 = p.out_rect()
+        outs[i0:i1, j0:j1] += 1
+        ry, rx, rh, rw = p.roi
+        assert (rh, rw) == (p.y1 - p.y0, p.x1 - p.x0) and ry + rh <= p.local_hw[0] and rx + rw <= p.local_hw[1]
+        if W % 4 == 0 and all((k * W // grid[1]) % 4 == 0 for k in range(grid[1] + 1)):
+            assert p.local_hw[1] % 4 == 0            # the local row pitch keeps the aligned dword loads of interior tiles
+    assert (owned == 1).all() and (outs == 1).all()
+
+
+def test_block_grid_and_single_round_of_tiles(oracle):
+    assert ldist.block_grid(8) == (2, 4) and ldist.block_grid(4) == (2, 2) and ldist.block_grid(2) == (1, 2)
+    H, W = 2160, 3840
+    lr, _, _, _ = oracle.sr_axis_tables(H, 2 * H, 2.0, 2)
+    lc, _, _, _ = oracle.sr_axis_tables(W, 2 * W, 2.0, 2)
+    for r in range(8):
+        p = ldist.BlockPlan(H, W, (2, 4), r, 2, lr, lc)
+        _, _, rh, rw = p.roi
+        assert -(-rh // 64) * -(-rw // 64) == 255     # one round of workgroups on 256 CUs (strips: 300)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, grid, port, H, W, scale, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import lerf_oracle as O
+    from conftest import ASSETS
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)        # same frame on every rank
+    lr, _, _, _ = O.sr_axis_tables(H, O.out_size(H, scale), scale, 2)
+    lc, _, _, _ = O.sr_axis_tables(W, O.out_size(W, scale), scale, 2)
+    plan = ldist.BlockPlan(H, W, grid, rank, 2, lr, lc)
+    buf = ldist.BlockBuffer(plan, 2, 3, torch.uint8, None, lr, lc)
+    own = torch.from_numpy(img[plan.y0:plan.y1, plan.x0:plan.x1].copy())
+    ok = True
+    for rep in range(2):                                          # persistent buffer, reused across steps
+        buf.ext.zero_()
+        buf.own.copy_(torch.stack([own, own]))
+        ext = buf.exchange()
+        ok = ok and ext.data_ptr() == buf.ext.data_ptr()
+        ok = ok and np.array_equal(ext[1].numpy(), img[plan.ylo:plan.yhi, plan.xlo:plan.xhi])
+    # per-block compute with the checker: LUT stages on the local frame alone (wrong only in the outer ring of an
+    # artificial border, which stage 3 of the owned outputs never reads), stage 3 with the GLOBAL geometry
+    luts = O.load_luts(os.path.join(ASSETS, "lerf-g"))
+    feat_s, hq_s = O.lut_stages(ext[0].numpy(), luts, 3)
+    feat = np.zeros((H, W, 3), np.uint8)
+    hq = np.zeros((H, W, 3, 3), np.uint8)
+    feat[plan.ylo:plan.yhi, plan.xlo:plan.xhi], hq[plan.ylo:plan.yhi, plan.xlo:plan.xhi] = feat_s, hq_s
+    i0, i1, j0, j1 = plan.out_rect()
+    mine = O.to_u8(O.resize_u8(feat, hq, scale, scale))[i0:i1, j0:j1]
+    rects = [ldist.BlockPlan(H, W, grid, r, 2, lr, lc).out_rect() for r in range(world)]
+    whole = ldist.gather_blocks(torch.from_numpy(mine.copy()), rects, (len(lr), len(lc)))
+    np.save(os.path.join(tmp, "whole_%d.npy" % rank), whole.numpy())
+    np.save(os.path.join(tmp, "ok_%d.npy" % rank), np.array([ok, plan.check_support(lr, lc)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W,scale,grid", [(45, 50, 2.0, (2, 2)), (43, 90, 1.5, (2, 4)), (50, 49, 3.0, (2, 2))])
+def test_gloo_block_halo_exchange_and_stitch(tmp_path, oracle, luts_g, H, W, scale, grid):
+    """world 4 and 8 incl. H % 2 != 0, W % 4 != 0 and a non-integer scale (unequal output rectangles)"""
+    world = grid[0] * grid[1]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, grid, port, H, W, scale, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    full = oracle.sr_pipeline(img, luts_g, scale, scale)
+    for r in range(world):
+        assert np.load(tmp_path / ("ok_%d.npy" % r)).all()
+        assert np.array_equal(np.load(tmp_path / ("whole_%d.npy" % r)), full)

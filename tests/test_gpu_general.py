@@ -1,0 +1,263 @@
+"""GPU parity of the GENERAL tile-fused kernels (round 3): channel counts 1 / 3 / 4, any 1..4 sampling patterns per stage
+(incl. 'd' and 'y'), scale factors up to x8, non-constant image padding, frames of different sizes in one launch, a region
+of interest (2-D block partition), the batched packed warp and the ABI-4 argument checks.  Every case: tile-fused ==
+direct kernels == the float64 oracle (resample/eval_lut_sr.py:24-470, 541-665; resize_right2d_numpy.py:18-282)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "GPU tests need an MI355X"
+    return t
+
+
+def _arrays(oracle, model, modes, modes2, seed=0):
+    """a LUT dictionary for arbitrary pattern strings: the shipped s/c/t tables dealt out to the requested patterns
+    (the pattern decides WHERE the four pixels are sampled, any table can be looked up with them)"""
+    linear = model == "lerf-l"
+    base = oracle.load_luts(os.path.join(ASSETS, model), linear=linear)
+    src = "sct"
+    d = {}
+    for i, m in enumerate(modes):
+        d["s1_%sr0" % m] = base["s1_%sr0" % src[(i + seed) % 3]]
+    for i, m in enumerate(modes2):
+        for r in (0, 1):
+            d["s2_%sr%d" % (m, r)] = base["s2_%sr%d" % (src[(i + seed + 1) % 3], r)]
+    return d
+
+
+def _engine(model, arrays, modes, modes2, S=2):
+    import lerf_pytorch_amd as L
+    luts = L.LutSet.from_arrays(arrays, modes, modes2)
+    assert luts.struct.fused_pack is not None
+    return L.LerfEngine(luts, support=S)
+
+
+CASES = [
+    # C, model, modes, modes2, S, H, W, scale
+    (1, "lerf-g", "sct", "sct", 2, 70, 200, 2),             # grey: 64 x 192 tiles
+    (1, "lerf-g", "sct", "sct", 2, 64, 192, (3.0, 1.5)),
+    (4, "lerf-g", "sct", "sct", 2, 70, 100, 2),             # RGBA: 64 x 48 tiles
+    (4, "lerf-l", "sct", "sct", 2, 66, 50, (1.5, 2.0)),
+    (4, "lerf-g", "sct", "sct", 4, 40, 60, 2),
+    (3, "lerf-g", "sdy", "yct", 2, 70, 75, 2),              # patterns d and y in both stages
+    (3, "lerf-l", "dy", "yd", 2, 65, 66, 3),
+    (3, "lerf-g", "s", "c", 2, 33, 47, 2),                  # one pattern per stage
+    (3, "lerf-g", "sdyc", "sdyt", 2, 30, 70, 2),            # four patterns per stage (the 16-bit sums' limit)
+    (3, "lerf-g", "sct", "sct", 2, 70, 66, 6),              # scale > 4.9: large geometry tables
+    (3, "lerf-g", "sct", "sct", 2, 20, 70, 8),
+    (3, "lerf-g", "sct", "sct", 4, 66, 20, (7.3, 5.0)),
+    (3, "lerf-l", "sct", "sct", 2, 64, 64, (8.0, 1.0)),
+    (1, "lerf-l", "tcs", "y", 2, 9, 200, 5),
+]
+
+
+@pytest.mark.parametrize("C,model,modes,modes2,S,H,W,scale", CASES)
+def test_general_fused_equals_direct_and_oracle(torch, oracle, C, model, modes, modes2, S, H, W, scale):
+    from lerf_pytorch_amd import ops
+    arrays = _arrays(oracle, model, modes, modes2)
+    eng = _engine(model, arrays, modes, modes2, S)
+    rng = np.random.default_rng(H * 131 + W * 7 + C)
+    img = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+    sc = scale if isinstance(scale, tuple) else (scale, scale)
+    geo = eng.sr_geometry((H, W), sc)
+    assert ops.sr_fused_supported(C, eng.luts, geo, eng.kind), "this configuration must take the tile-fused kernels"
+    a = eng.sr(img, sc, fused=True)
+    b = eng.sr(img, sc, fused=False)
+    assert np.array_equal(a, b), "fused != direct kernels"
+    ref = oracle.sr_pipeline(img, arrays, sc[0], sc[1], S=S, linear=(model == "lerf-l"), modes=modes, modes2=modes2)
+    assert a.shape == ref.shape
+    assert np.array_equal(a, ref), "fused != oracle (%d bytes differ)" % int((a != ref).sum())
+    # single launch (stage 1 recomputed per tile) == two launches
+    x = torch.from_numpy(img).cuda()
+    one = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma, workspace=False).cpu().numpy()
+    assert np.array_equal(one, a)
+    # the packed stage outputs of the general EMIT kernels == the direct stage kernels
+    f1, h1 = ops.unpack_stages(ops.stages_packed(x, eng.luts), eng.luts.oC)
+    f2, h2 = ops.lut_stages(x, eng.luts)
+    assert torch.equal(f1, f2) and torch.equal(h1, h2)
+
+
+def test_five_patterns_fall_back_to_the_direct_kernels(torch, oracle):
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import ops
+    arrays = _arrays(oracle, "lerf-g", "sdyct", "sct")
+    luts = L.LutSet.from_arrays(arrays, "sdyct", "sct")
+    assert luts.struct.fused_pack is None                     # five patterns overflow the packed 16-bit sums: no fused kernel
+    eng = L.LerfEngine(luts)
+    img = np.random.default_rng(3).integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    assert not ops.sr_fused_supported(3, luts, eng.sr_geometry((40, 50), 2), "gauss")
+    out = eng.sr(img, 2)                                      # lerf_sr_fused_u8 routes it through the workspace itself
+    assert np.array_equal(out, oracle.sr_pipeline(img, arrays, 2, 2, modes="sdyct", modes2="sct"))
+
+
+@pytest.mark.parametrize("pad", ["edge", "reflect", "symmetric", "wrap"])
+@pytest.mark.parametrize("model,C,H,W,scale,S", [("lerf-g", 3, 70, 80, 2, 2), ("lerf-l", 3, 33, 150, (1.5, 2.0), 2),
+                                                 ("lerf-g", 3, 130, 66, 3, 4), ("lerf-g", 1, 5, 6, 2, 2)])
+def test_pad_modes_on_the_fused_uint8_path(torch, oracle, luts_g, luts_l, pad, model, C, H, W, scale, S):
+    """pad_mode of the image operand (np.pad(input, pad_vec, mode=...), resize_right2d_numpy.py:143, 208) through the
+    tile-fused kernel, the direct kernel and the oracle; wrap reads the far side of the frame from the stage-1 output"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import _lib, ops
+    linear = model == "lerf-l"
+    arrays = luts_l if linear else luts_g
+    eng = L.LerfEngine(L.LutSet.from_arrays(arrays), support=S)
+    sc = scale if isinstance(scale, tuple) else (scale, scale)
+    img = np.random.default_rng(H + W).integers(0, 256, (H, W, C), dtype=np.uint8)
+    x = torch.from_numpy(img).cuda()
+    geo = ops.SrGeometry((H, W), list(sc), None, eng.support, "cuda", pad_mode=_lib.PAD_MODES[pad])
+    assert ops.sr_fused_supported(C, eng.luts, geo, eng.kind)
+    a = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma).cpu().numpy()
+    feat, hq = ops.lut_stages(x, eng.luts)
+    b = ops.resize_hwc_u8(feat, hq, geo, eng.kind, eng.max_sigma, out="u8").cpu().numpy()
+    assert np.array_equal(a, b), "fused != direct with pad_mode=%s" % pad
+    fo, ho = oracle.lut_stages(img, arrays, 1 if linear else 3)
+    p0, p1, p2 = oracle._split_hq(ho, eng.kind)
+    ref = oracle.resize_params_f32(np.transpose(fo.astype(np.float32), (2, 0, 1)), p0, p1, p2, sc[0], sc[1], eng.support,
+                                   eng.max_sigma, eng.kind, pad_mode=pad)
+    ref = oracle.to_u8(np.transpose(ref, (1, 2, 0)))
+    assert np.array_equal(a, ref), "fused != oracle with pad_mode=%s (%d bytes)" % (pad, int((a != ref).sum()))
+    if pad != "wrap":                                         # single launch: every source pixel is inside the tile
+        one = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma, workspace=False).cpu().numpy()
+        assert np.array_equal(one, a)
+
+
+@pytest.mark.parametrize("max_sigma", [13.0, 14.0, 20.0, 40.0])
+def test_large_max_sigma_takes_the_shifted_sums(torch, oracle, luts_g, max_sigma):
+    """max_sigma is a free constructor argument (resize_right2d_numpy.py:143).  Beyond 13.2 the unshifted exp2 sums of
+    the fast stage 3 can underflow to 0/0 (every tap beyond 2^-126); the kernels then take the minimum-shifted sums,
+    like the reference's float64 arithmetic never underflows.  Saturated hyper-parameters make the worst case."""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import ops
+    eng = L.LerfEngine(L.LutSet.from_arrays(luts_g), support=2, max_sigma=max_sigma)
+    rng = np.random.default_rng(11)
+    H, W = 48, 70
+    feat = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    hq = rng.integers(0, 256, (H, W, 3, 3), dtype=np.uint8)
+    hq[: H // 2, :, :, 1:] = 255                              # sigma_x = sigma_y = max_sigma: the largest exponents
+    geo = eng.sr_geometry((H, W), 2)
+    out = ops.resize_hwc_u8(torch.from_numpy(feat).cuda(), torch.from_numpy(hq).cuda(), geo, "gauss", max_sigma, out="u8").cpu().numpy()
+    ref = oracle.to_u8(oracle.resize_u8(feat, hq, 2, 2, 2, max_sigma, "gauss"))
+    assert np.array_equal(out, ref), "%d bytes differ at max_sigma=%g" % (int((out != ref).sum()), max_sigma)
+    # whole path through the tile-fused kernel (its hyper-parameters come from the LUTs)
+    img = rng.integers(0, 256, (70, 66, 3), dtype=np.uint8)
+    a = eng.sr(img, 2)
+    assert np.array_equal(a, eng.sr(img, 2, fused=False))
+    assert np.array_equal(a, oracle.sr_pipeline(img, luts_g, 2, 2, S=2, max_sigma=max_sigma))
+
+
+def test_ragged_launch_equals_frame_by_frame(torch, oracle, luts_g, luts_l):
+    """frames of different sizes AND scale factors through one launch pair (the benchmark-folder loop of eltr.run,
+    eval_lut_sr.py:489-512); 20 frames = two descriptor chunks"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import ops
+    rng = np.random.default_rng(5)
+    shapes = [(64, 64, 2), (100, 37, 3), (1, 1, 4), (129, 65, 2), (30, 200, (1.5, 2.0)), (70, 70, 4), (5, 300, 2), (66, 130, 3)]
+    shapes = shapes + [(h + 3, w + 1, s) for h, w, s in shapes] + shapes[:4]
+    for model, arrays in (("lerf-g", luts_g), ("lerf-l", luts_l)):
+        eng = L.LerfEngine(L.LutSet.from_arrays(arrays))
+        imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w, _ in shapes]
+        xs = [torch.from_numpy(i).cuda() for i in imgs]
+        geos = [eng.sr_geometry((h, w), s if isinstance(s, tuple) else (s, s)) for h, w, s in shapes]
+        outs = ops.sr_fused_ragged_u8(xs, eng.luts, geos, eng.kind, eng.max_sigma)
+        for img, (h, w, s), o in zip(imgs, shapes, outs):
+            assert np.array_equal(o.cpu().numpy(), eng.sr(img, s)), "ragged != single launch for %dx%d x%s" % (h, w, s)
+        sc = shapes[1][2]
+        assert np.array_equal(outs[1].cpu().numpy(), oracle.sr_pipeline(imgs[1], arrays, sc, sc, linear=(model == "lerf-l")))
+        packed = ops.stages_packed_ragged(xs, eng.luts)
+        for x, pk in zip(xs[:6], packed[:6]):
+            assert torch.equal(pk, ops.stages_packed(x, eng.luts))
+
+
+@pytest.mark.parametrize("H,W,scale,grid,S", [(200, 260, 2, (2, 4), 2), (150, 131, 1.5, (2, 2), 2), (140, 150, 3, (2, 3), 4),
+                                              (97, 128, 2.4, (1, 2), 2)])
+def test_blocks_emulated_equal_full_frame(torch, H, W, scale, grid, S):
+    """what every rank of a 2-D block partition runs (block + halo as the frame, tiles over the owned block, one launch),
+    rank by rank on one GPU, stitched == the full frame bit for bit"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import dist as ldist
+    eng = L.LerfEngine.shipped("lerf-g", support=S)
+    img = np.random.default_rng(H + W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    x = torch.from_numpy(img).cuda()
+    full = eng.sr(x, scale)
+    geo = eng.sr_geometry((H, W), scale)
+    lr, lc = geo.host["left_r"], geo.host["left_c"]
+    out = torch.zeros_like(full)
+    for r in range(grid[0] * grid[1]):
+        p = ldist.BlockPlan(H, W, grid, r, S, lr, lc)
+        ext = x[p.ylo:p.yhi, p.xlo:p.xhi].contiguous().unsqueeze(0)
+        i0, i1, j0, j1 = p.out_rect()
+        out[i0:i1, j0:j1] = ldist.sr_block(eng, ext, p, geo)[0]
+    assert torch.equal(out, full)
+
+
+def test_rect_copy_round_trip(torch):
+    from lerf_pytorch_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(1)
+    fr = torch.randint(0, 256, (3, 40, 50, 3), dtype=torch.uint8, generator=g).cuda()
+    rects, off = [], 0
+    for (y, x, h, w) in [(0, 0, 7, 50), (33, 0, 7, 50), (7, 0, 26, 8), (7, 42, 26, 8), (0, 0, 1, 1), (39, 49, 1, 1), (10, 10, 3, 5), (5, 6, 7, 8)]:
+        rects.append((y, x, h, w, off))
+        off += 3 * h * w * 3
+    st = torch.zeros(off, dtype=torch.uint8, device="cuda")
+    ops.rect_copy(fr, st, rects, True)
+    for y, x, h, w, o in rects:
+        assert torch.equal(st[o:o + 3 * h * w * 3].view(3, h, w, 3), fr[:, y:y + h, x:x + w])
+    fr2 = torch.zeros_like(fr)
+    ops.rect_copy(fr2, st, rects, False)
+    for y, x, h, w, o in rects:
+        assert torch.equal(fr2[:, y:y + h, x:x + w], fr[:, y:y + h, x:x + w])
+
+
+def test_batched_packed_warp_equals_frame_by_frame(torch):
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import ops
+    eng = L.LerfEngine.shipped("lerf-g")
+    M = np.array([[2.05, 0.12, 15.0], [-0.08, 1.95, 40.0], [1.5e-5, -1.0e-5, 1.0]])
+    x = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (3, 90, 120, 3), dtype=np.uint8)).cuda()
+    geo = ops.WarpGeometry((90, 120), M, (180, 240), 2)
+    packed = ops.stages_packed(x, eng.luts)
+    for out in ("u8", "f32"):
+        a = ops.warp_packed(packed, geo, "gauss", 10.0, out=out)
+        for b in range(3):
+            one = ops.warp_packed(packed[b], geo, "gauss", 10.0, out=out)
+            assert torch.equal(torch.nan_to_num(a[b].float()), torch.nan_to_num(one.float()))
+
+
+def test_abi4_argument_checks(torch):
+    import ctypes as C
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import _lib, ops
+    eng = L.LerfEngine.shipped("lerf-g")
+    x = torch.zeros((2, 70, 70, 3), dtype=torch.uint8, device="cuda")
+    geo = eng.sr_geometry((70, 70), 2)
+    out = torch.empty((2, 140, 140, 3), dtype=torch.uint8, device="cuda")
+    need = _lib.lib().lerf_sr_fused_workspace_bytes(70, 70, 3, 2)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    lib = _lib.lib()
+    call = lambda nbytes: lib.lerf_sr_fused_u8(x.data_ptr(), x.stride(0), 2, 70, 70, 3, eng.luts.ref(), geo.ref(), 0, 10.0,
+                                               out.data_ptr(), out.stride(0), ws.data_ptr(), nbytes, _lib.current_stream())
+    assert call(need) == 0
+    assert call(2 * 14704 - 1) == -1                          # shorter than the stage-1 output of the batch: LERF_EINVAL, no launch
+    pk = torch.empty((2, 70, 70, 3), dtype=torch.int32, device="cuda")
+    assert lib.lerf_stages_packed_u8(x.data_ptr(), x.stride(0), 2, 70, 70, 3, eng.luts.ref(), pk.data_ptr(), pk.stride(0),
+                                     ws.data_ptr(), 100, _lib.current_stream()) == -1
+    with pytest.raises(ValueError):
+        ops.sr_fused_u8(x, eng.luts, geo, workspace=torch.empty(10, dtype=torch.uint8, device="cuda"))
+    g2 = _lib.SrGeo()
+    C.memmove(C.byref(g2), geo.ref(), C.sizeof(g2))
+    g2.pad_mode = 9
+    assert lib.lerf_sr_fused_u8(x.data_ptr(), x.stride(0), 2, 70, 70, 3, eng.luts.ref(), C.byref(g2), 0, 10.0, out.data_ptr(),
+                                out.stride(0), ws.data_ptr(), need, _lib.current_stream()) == -1
+    g2.pad_mode = 0
+    g2.roi_y, g2.roi_x, g2.roi_h, g2.roi_w = 10, 10, 70, 70  # outside the frame
+    assert lib.lerf_sr_fused_u8(x.data_ptr(), x.stride(0), 2, 70, 70, 3, eng.luts.ref(), C.byref(g2), 0, 10.0, out.data_ptr(),
+                                out.stride(0), ws.data_ptr(), need, _lib.current_stream()) == -1

@@ -45,3 +45,32 @@ torch.cuda.synchronize(); d8 = (time.perf_counter() - t) / 5
 full8 = 8 * dt / B
 print("8 frames, one rank's strips in one launch: %.3f ms vs 1/8 of the whole-frame batch %.3f ms -> strong-scaling efficiency of the "
       "compute part %.0f %% (%.1f Gpix/s over 8 GPUs before the halo exchange)" % (d8 * 1e3, full8 / 8 * 1e3, 100 * full8 / 8 / d8, 8 * 4320 * 7680 / d8 / 1e9))
+
+# ---- 2 x 4 blocks of one frame (round 3), emulated rank by rank: block + halo as the frame, tiles over the owned block
+#      (255 per rank = one round of workgroups), ONE launch per rank (stage 1 recomputed on the tile halos)
+lr_, lc_ = geo.host["left_r"], geo.host["left_c"]
+outb = torch.zeros_like(out[0]); tb = []
+for r in range(8):
+    plan = ldist.BlockPlan(2160, 3840, (2, 4), r, 2, lr_, lc_)
+    ext = x[0, plan.ylo:plan.yhi, plan.xlo:plan.xhi].contiguous().unsqueeze(0)
+    lg = ldist.block_geometry(geo, plan)
+    i0, i1, j0, j1 = plan.out_rect()
+    o = ops.sr_fused_u8(ext, eng.luts, lg, "gauss", 10.0, workspace=False)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): ops.sr_fused_u8(ext, eng.luts, lg, "gauss", 10.0, out=o, workspace=False)
+    torch.cuda.synchronize(); tb.append((time.perf_counter() - t) / 10)
+    outb[i0:i1, j0:j1] = o[0]
+print("8 blocks (2 x 4) stitched == full frame:", bool(torch.equal(outb, out[0])))
+print("per-block kernel time (1080 x 960 LR pixels + halo, 255 tiles, one launch): %.3f ms max, %.3f ms mean -> one frame over 8 GPUs ~ %.1f Mpix/s + halo "
+      "exchange; strips: %.3f ms max (300 tiles, two launches)" % (max(tb) * 1e3, np.mean(tb) * 1e3, 4320 * 7680 / max(tb) / 1e6, max(ts) * 1e3))
+print("single-frame efficiency against 1/8 of a whole frame in a batch (%.3f ms): blocks %.0f %%, strips %.0f %%"
+      % (dt / B / 8 * 1e3, 100 * dt / B / 8 / max(tb), 100 * dt / B / 8 / max(ts)))
+# the two-launch variant on a block (288 + 272 workgroups) for comparison
+plan = ldist.BlockPlan(2160, 3840, (2, 4), 5, 2, lr_, lc_)
+ext = x[0, plan.ylo:plan.yhi, plan.xlo:plan.xhi].contiguous().unsqueeze(0)
+lgw = geo.block_slice(plan.ylo, plan.local_hw[0], plan.i0, plan.i1, plan.xlo, plan.local_hw[1], plan.j0, plan.j1)    # no roi: tiles over block + halo
+o = ops.sr_fused_u8(ext, eng.luts, lgw, "gauss", 10.0)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(10): ops.sr_fused_u8(ext, eng.luts, lgw, "gauss", 10.0, out=o)
+torch.cuda.synchronize()
+print("block 5 without the region of interest (tiles over block + halo: 18 x 16 = 288, two launches): %.3f ms" % ((time.perf_counter() - t) / 10 * 1e3))
