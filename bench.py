@@ -86,6 +86,36 @@ def kernel_source_sha():
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline legs
+def host_cpu_budget():
+    """(threads the baseline may use, why): min of the visible processors, the affinity mask and the cgroup CPU quota.
+    The boxes of the pool show 256 processors to a container that is granted 16 (cpu.max): OpenMP threads beyond the
+    quota are throttled, not run (profiles/r03_cpu_scaling.txt)."""
+    n = os.cpu_count() or 1
+    why = "os.cpu_count()"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "affinity mask"
+    except AttributeError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, why = max(1, int(quota)), "cgroup CPU quota of this container (%d processors visible)" % (os.cpu_count() or 1)
+    return n, why
+
+
 def _oracle_luts(model):
     from oracle import lerf_oracle
     return lerf_oracle.load_luts(os.path.join(ROOT, "lerf-pytorch_amd", "assets", "models", model), linear=model == "lerf-l")
@@ -95,8 +125,8 @@ def cpu_baseline_sr(frames_u8, model, sh, sw, budget_s=12.0, threads=None, max_n
     """C port of the oracle (oracle/lerf_oracle.c, OpenMP) on this host, bounded sample.  threads=1: one core."""
     from oracle import c_oracle
     luts = _oracle_luts(model)
-    if threads is not None:
-        c_oracle.set_threads(threads)
+    budget_thr, why = host_cpu_budget()
+    c_oracle.set_threads(min(threads, budget_thr) if threads is not None else budget_thr)
     thr = c_oracle.threads()
     # one untimed call: the work area and the output frame are allocated and first-touched here (caller-owned scratch of
     # lerf_oracle_sr_u8_ws, cached by the wrapper), not inside the timed loop
@@ -112,14 +142,15 @@ def cpu_baseline_sr(frames_u8, model, sh, sw, budget_s=12.0, threads=None, max_n
     H, W = frames_u8.shape[1:3]
     return {
         "value": round(n * out.shape[0] * out.shape[1] / dt / 1e6, 4), "unit": "Mpix/s", "cores": thr, "kind": "port",
-        "sample": "%d frame(s) %dx%d->%dx%d, same synthetic input, oracle/lerf_oracle.c (OpenMP, %d threads), %.1f s"
-                  % (n, W, H, out.shape[1], out.shape[0], thr, dt),
+        "sample": "%d frame(s) %dx%d->%dx%d, same synthetic input, oracle/lerf_oracle.c (OpenMP, %d threads; host budget %d = %s), %.1f s"
+                  % (n, W, H, out.shape[1], out.shape[0], thr, budget_thr, why, dt),
     }, out, n
 
 
 def cpu_baseline_warp(frame_u8, matrix, out_hw, budget_s=12.0):
     from oracle import c_oracle
     luts = _oracle_luts("lerf-g")
+    c_oracle.set_threads(host_cpu_budget()[0])
     thr = c_oracle.threads()
     t0 = time.perf_counter()
     n = 0
@@ -520,17 +551,17 @@ def main():
                 tile = np.random.default_rng(0).integers(0, 256, (1, 256, 256, C), dtype=np.uint8)
                 cb1, _, _ = cpu_baseline_sr(tile, model, scale[0], scale[1], budget_s=5.0, threads=1, max_n=8)
                 res["cpu_baseline_single_thread"] = cb1
-                cb32, _, _ = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=5.0, threads=32, S=S)
-                res["cpu_baseline_32_threads"] = cb32
-                from oracle import c_oracle
-                c_oracle.set_threads(0)
+                half = max(1, host_cpu_budget()[0] // 2)
+                cbh, _, _ = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=5.0, threads=half, S=S)
+                res["cpu_baseline_half_budget"] = cbh
             cb, cpu_out, n_cpu = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=budget, S=S)
             res["cpu_baseline"] = cb
             if cfg == 2 and S == 2:
                 cb["scaling"] = {"threads_1_mpix_s": res["cpu_baseline_single_thread"]["value"],
-                                 "threads_32_mpix_s": res["cpu_baseline_32_threads"]["value"],
-                                 "threads_all_mpix_s": cb["value"],
-                                 "all_vs_single": round(cb["value"] / max(res["cpu_baseline_single_thread"]["value"], 1e-9), 1)}
+                                 "threads_%d_mpix_s" % res["cpu_baseline_half_budget"]["cores"]: res["cpu_baseline_half_budget"]["value"],
+                                 "threads_%d_mpix_s" % cb["cores"]: cb["value"],
+                                 "speedup_over_one_thread": round(cb["value"] / max(res["cpu_baseline_single_thread"]["value"], 1e-9), 1),
+                                 "note": "threads = the CPU budget of this container, see profiles/r03_cpu_scaling.txt"}
             # the timed product output must equal the checker's (<= 1 LSB)
             ref_idx = (n_cpu - 1) % len(host)
             step()

@@ -205,9 +205,12 @@ struct TapAcc {
     int n = 0;
 
     __device__ __forceinline__ void add_gauss(A rho, A sx, A sy, A dx, A dy, A val) {
-        // resize_right2d_numpy.py:150-160
-        A tx = sx * dx, ty = sy * dy;
-        e[n] = tx * tx - (A)2 * rho * (tx * ty) + ty * ty;
+#pragma clang fp contract(off)
+        // resize_right2d_numpy.py:150-160, in the reference's operation order and without FMA contraction: the uint8 outputs
+        // of the float64 path (max_sigma > 13) must round like numpy's even where two taps carry EQUAL weights and the
+        // value is an exact half (x_norm = (sx dx)^2, y_norm = (sy dy)^2, xy = sx dx sy dy left to right)
+        const A xn = (sx * dx) * (sx * dx), yn = (sy * dy) * (sy * dy), xy = sx * dx * sy * dy;
+        e[n] = xn - (A)2 * rho * xy + yn;
         v[n] = val;
         ++n;
     }
@@ -217,6 +220,7 @@ struct TapAcc {
         ++n;
     }
     __device__ __forceinline__ A finish() const {
+#pragma clang fp contract(off)
         A num = 0, den = 0;
         if (KIND == LERF_KIND_GAUSS) {
             // float32: shifted by the minimum (see above).  float64: NOT shifted -- the reference's own arithmetic

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input "$@" > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input --sustained 0 "$@" > $out/bench.json 2> $out/bench.err
 f=$(find $out/stats -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

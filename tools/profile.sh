@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd $GRAFT_REPO_ROOT
-B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input $*"
+B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input --sustained 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- $B > $out/bench.json 2> $out/bench.err
 i=0
 for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \

@@ -25,6 +25,8 @@ def short(name):
         return "stage1"
     if "sr_fused_kernel" in name:
         return "stage23"
+    if "warp_packed" in name:
+        return "warp"
     return None
 
 
@@ -41,9 +43,10 @@ for f in sorted(glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=T
             per[kn][(grp, c)].append(v)
 
 avg_us = {}
+extra_args = " ".join(a for a in sys.argv[3:] if a != "--no-json")
 out = ["rocprofv3 summary (%s): %s" % (label, bench["config"]["workload"]),
-       "command: bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input ; %d frames per launch, %s input; one --pmc pass per counter group"
-       % (bench["config"]["frames_per_step_per_gpu"], bench["config"]["input"]),
+       "command: bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-input --sustained 0 %s; %d frames per launch, %s input; one --pmc pass per counter group"
+       % (extra_args, bench["config"]["frames_per_step_per_gpu"], bench["config"]["input"]),
        "bench line of the traced run: %.1f Mpix/s, %.4f ms per step (events: %.4f ms)" % (bench["value"], bench["ms_per_step"], bench["roofline"]["kernel_ms"]), ""]
 for r in csv.DictReader(open(ks)):
     kn = short(r["Name"])
@@ -56,7 +59,7 @@ out.append("")
 
 tot = collections.defaultdict(float)
 summary = {}
-for kn in ("stage1", "stage23"):
+for kn in ("stage1", "stage23", "warp"):
     if kn not in per:
         continue
     m = {}
@@ -96,7 +99,7 @@ out += ["", "one step (both launches):",
            tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]))]
 open(os.path.join(dst, label + "_pmc_summary.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
-if "--no-json" not in sys.argv:
+if "--no-json" not in sys.argv and bench["config"]["baseline_config"] == 2 and not extra_args:
     import bench as B
     json.dump({"frames": bench["config"]["frames_per_step_per_gpu"], "input": bench["config"]["input"], "bytes_per_launch": int(2 * fetch + write),
                "valu_instr_per_cu_cycle": round(tot["SQ_INSTS_VALU"] / cu, 3),

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/traffic_$tag
 rm -rf $out; mkdir -p $out
 cd $GRAFT_REPO_ROOT
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-input $*"
+B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-input --sustained 0 $*"
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/p1 -o c -- $B > /dev/null 2> $out/p1.err
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $out/p2 -o c -- $B > /dev/null 2> $out/p2.err
 python3 - $out <<'PY'
