@@ -165,7 +165,12 @@ struct Params {
 #define LERF_STAMP(k) do { if (tid == 0) P.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define LERF_STAMP_ADD(k, t0) do { if (tid == 0) P.stamps[(size_t)blockIdx.x * 16 + (k)] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define LERF_NOW() __builtin_amdgcn_s_memtime()
+// the constant 100 MHz counter beside the shader-clock one: (s_memtime ticks) / (s_memrealtime ticks) x 100 MHz = the clock
+// the chip ran this tile at (tools/stamps.py prints it; slots 13 / 14 of a tile's stamps)
+#define LERF_STAMP_RT(k) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); \
+                                              P.stamps[(size_t)blockIdx.x * 16 + (k)] = t_; } } while (0)
 #else
+#define LERF_STAMP_RT(k) do {} while (0)
 #define LERF_STAMP(k) do {} while (0)
 #define LERF_STAMP_ADD(k, t0) do {} while (0)
 #define LERF_NOW() 0ull
@@ -749,6 +754,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         }
     };
 
+    LERF_STAMP_RT(13);
     LERF_STAMP(0);
 #ifdef LERF_STAMPS
     if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
@@ -1512,6 +1518,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 #ifdef LERF_STAMPS
     __syncthreads();
     LERF_STAMP(12);
+    LERF_STAMP_RT(14);
 #endif
 }
 

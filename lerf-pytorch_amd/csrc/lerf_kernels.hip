@@ -770,7 +770,11 @@ warp_packed_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, int H
 // The same, one thread per output PIXEL of an RGB frame with S = 2: the float64 projection, the support and the
 // four tap positions / distances are computed once and shared by the three channels (the per-channel kernel above
 // spends most of its time repeating the two float64 divisions of the projection).
-template <typename TO, int KIND>
+// PROD (uint8 outputs, max_sigma <= s3::kNoShiftMaxSigma): the float32 production arithmetic of the SR kernels -- forms
+// pre-scaled by 0.5 log2(e) straight from the uint8 numerators (lerf_stage3.h gauss_form_u8), exp2 weights shifted by the
+// support's minimum, reciprocal + Newton step -- instead of the exact float32 parameter formation: 75 instead of 140 VALU
+// instructions per output value, same bytes (the tie guard re-evaluates anything within 1.5e-4 of a rounding tie in float64).
+template <typename TO, int KIND, bool PROD = false>
 __global__ void __launch_bounds__(256)
 warp_packed_px_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, int H, int W, WarpGeo g, float max_sigma,
                       TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn) {
@@ -815,11 +819,46 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, in
     for (int a = 0; a < S; ++a)
 #pragma unroll
         for (int b = 0; b < S; ++b) pos[a * S + b] = ((int64_t)rrow[b] * W + rcol[a]) * C;
+    float dxs[S], dys[S];
+    const float gsc = (PROD && KIND == LERF_KIND_GAUSS) ? s3::gauss_scale(max_sigma) : 1.0f;
+    const float ms255 = max_sigma * (1.0f / 255.0f);
+#pragma unroll
+    for (int b = 0; b < S; ++b) { dxs[b] = dx[b] * gsc; dys[b] = dy[b] * gsc; }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         uint32_t d[S * S];
 #pragma unroll
         for (int t = 0; t < S * S; ++t) d[t] = packed[pos[t] + c];
+        if constexpr (PROD) {
+            float e[S * S], v[S * S];
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int b = 0; b < S; ++b) {
+                    const uint32_t q = d[a * S + b];
+                    if (KIND == LERF_KIND_GAUSS) {
+                        e[a * S + b] = s3::gauss_form_u8((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), dxs[b], dys[a]);
+                    } else {
+                        const float alpha = s3::lin_alpha_u8((float)(q & 0xFFu), ms255);
+                        e[a * S + b] = s3::lin_factor(alpha, dx[b], cx[b]) * s3::lin_factor(alpha, dy[a], cy[a]);
+                    }
+                    v[a * S + b] = (in_r[b] && in_c[a]) ? (float)(q >> 24) : 0.0f;
+                }
+            float res = s3::finish<KIND == LERF_KIND_GAUSS, S * S, true, true, false>(e, v);
+            if (KIND == LERF_KIND_GAUSS) {
+                // every weight underflows in the reference's float64 (exp(-e/2) = 0 for e/2 > 745.2): its 0/0 = NaN; in the
+                // pre-scaled units e' = 0.5 log2(e) e that is e' > 1075.1
+                const float emin = fminf(fminf(e[0], e[1]), fminf(e[2], e[3]));
+                if (emin > 1075.1f) res = __builtin_nanf("");
+            }
+            TO* dst = out + i * oy + j * ox + c * oc;
+            if (sizeof(TO) == 1) {
+                auto tap = [&](int rcl, int ccl) -> uint32_t { return packed[((int64_t)rcl * W + ccl) * C + c]; };
+                if (warp_tie_guard<KIND>(res, S, H, W, g, lr, lc, gr, gc, max_sigma, tap, reinterpret_cast<uint8_t*>(dst))) continue;
+            }
+            Storer<TO>::put(dst, res);
+            continue;
+        }
         float e[S * S], emin = 0.0f, num = 0.0f, den = 0.0f;
 #pragma unroll
         for (int a = 0; a < S; ++a)
@@ -862,13 +901,18 @@ int launch_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, 
     if (C == 3 && geo.S == 2 && (kind == LERF_KIND_GAUSS || kind == LERF_KIND_LINEAR) &&
         (out_dtype == LERF_U8 || out_dtype == LERF_F32)) {
         dim3 blockp(256), gridp((geo.oW + 255) / 256, geo.oH, n);
-#define LERF_WPX(TO, KIND)                                                                                            \
-    hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND>), gridp, blockp, 0, st, packed, packed_sn, H, W, geo, max_sigma, (TO*)out, \
+#define LERF_WPX(TO, KIND, PROD)                                                                                      \
+    hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND, PROD>), gridp, blockp, 0, st, packed, packed_sn, H, W, geo, max_sigma, (TO*)out, \
                        oy, ox, oc, out_sn)
+        const bool prod = out_dtype == LERF_U8 && max_sigma <= s3::kNoShiftMaxSigma;     // production arithmetic + tie guard
         if (kind == LERF_KIND_GAUSS) {
-            if (out_dtype == LERF_U8) LERF_WPX(uint8_t, LERF_KIND_GAUSS); else LERF_WPX(float, LERF_KIND_GAUSS);
+            if (prod) LERF_WPX(uint8_t, LERF_KIND_GAUSS, true);
+            else if (out_dtype == LERF_U8) LERF_WPX(uint8_t, LERF_KIND_GAUSS, false);
+            else LERF_WPX(float, LERF_KIND_GAUSS, false);
         } else {
-            if (out_dtype == LERF_U8) LERF_WPX(uint8_t, LERF_KIND_LINEAR); else LERF_WPX(float, LERF_KIND_LINEAR);
+            if (prod) LERF_WPX(uint8_t, LERF_KIND_LINEAR, true);
+            else if (out_dtype == LERF_U8) LERF_WPX(uint8_t, LERF_KIND_LINEAR, false);
+            else LERF_WPX(float, LERF_KIND_LINEAR, false);
         }
 #undef LERF_WPX
         return LERF_OK;

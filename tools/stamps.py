@@ -51,7 +51,12 @@ def main():
         d["finalise+geo"] = st[:, 11] - st[:, 10]
         d["stage3"] = st[:, 12] - st[:, 11]
         d["TOTAL"] = st[:, 12] - st[:, 0]
-        print("== %s: cycles per tile (mean over %d tiles; s_memtime ticks = shader clock, about 2.0-2.1 GHz under this load; stamped on wave 0)" % (kind, tiles))
+        rt = st[:, 14] - st[:, 13]                       # s_memrealtime ticks (100 MHz) over the same interval as TOTAL
+        mhz = d["TOTAL"] / np.maximum(rt, 1) * 100.0
+        wall = (st[:, 14].max() - st[:, 13].min()) / 100.0          # us, first tile start -> last tile end
+        print("== %s: cycles per tile (mean over %d tiles; s_memtime ticks, stamped on wave 0).  Shader clock during the tiles: "
+              "s_memtime / s_memrealtime x 100 MHz = %.0f MHz mean (%.0f .. %.0f); launch = %.1f us by the 100 MHz counter"
+              % (kind, tiles, mhz.mean(), mhz.min(), mhz.max(), wall))
         tot = d["TOTAL"].mean()
         for k, v in d.items():
             print("  %-14s %10.0f  %5.1f%%" % (k, v.mean(), 100 * v.mean() / tot))

@@ -71,7 +71,7 @@ for kn in ("stage1", "stage23", "warp"):
     d = dict(cycles=cyc, clock_ghz=cyc / (avg_us[kn] * 1e3),
              valu_instr_per_cu_cycle=m["SQ_INSTS_VALU"] / cu,
              valu_busy=m["SQ_ACTIVE_INST_VALU"] * 4 / m["SQ_WAVE_CYCLES"] * (m["SQ_WAVE_CYCLES"] / (m["SQ_BUSY_CYCLES"] / 8 * 256 * 4 * 4) if False else 1.0),
-             lds_busy=m["SQ_LDS_IDX_ACTIVE"] / cu, lds_conflict_share=m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"],
+             lds_busy=m["SQ_LDS_IDX_ACTIVE"] / cu, lds_conflict_share=m["SQ_LDS_BANK_CONFLICT"] / max(m["SQ_LDS_IDX_ACTIVE"], 1.0),
              wait_any=m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], wait_inst_any=m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"],
              wait_inst_lds=m["SQ_WAIT_INST_LDS"] / m["SQ_WAVE_CYCLES"], lds_instr=m["SQ_INSTS_LDS"],
              l2_hit=m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]),
@@ -95,7 +95,7 @@ out += ["", "one step (both launches):",
         "algorithmic bytes per launch: %.3f MB -> traffic/algorithmic = %.2f (fetch doubled) / %.2f (raw)" % (alg / 1e6, (2 * fetch + write) / alg, (fetch + write) / alg),
         "roofline: %.3f MB / %.1f us = %.1f GB/s = %.4f of 8 TB/s" % (alg / 1e6, step_us, alg / step_us / 1e3, alg / step_us / 1e3 / 8000),
         "VALU issue %.2f wave-instr per CU-cycle; LDS array busy %.0f %%, bank-conflict share %.0f %%; L2 hit %.3f"
-        % (tot["SQ_INSTS_VALU"] / cu, 100 * tot["SQ_LDS_IDX_ACTIVE"] / cu, 100 * tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_LDS_IDX_ACTIVE"],
+        % (tot["SQ_INSTS_VALU"] / cu, 100 * tot["SQ_LDS_IDX_ACTIVE"] / cu, 100 * tot["SQ_LDS_BANK_CONFLICT"] / max(tot["SQ_LDS_IDX_ACTIVE"], 1.0),
            tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]))]
 open(os.path.join(dst, label + "_pmc_summary.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
@@ -105,7 +105,7 @@ if "--no-json" not in sys.argv and bench["config"]["baseline_config"] == 2 and n
                "valu_instr_per_cu_cycle": round(tot["SQ_INSTS_VALU"] / cu, 3),
                "valu_busy": round(tot["SQ_ACTIVE_INST_VALU"] * 4 / tot["SQ_WAVE_CYCLES"], 3),
                "lds_array_busy": round(tot["SQ_LDS_IDX_ACTIVE"] / cu, 3),
-               "lds_bank_conflict_share": round(tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_LDS_IDX_ACTIVE"], 3),
+               "lds_bank_conflict_share": round(tot["SQ_LDS_BANK_CONFLICT"] / max(tot["SQ_LDS_IDX_ACTIVE"], 1.0), 3),
                "l2_hit_rate": round(tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 4),
                "kernel_trace_avg_us": round(step_us, 1), "fetch_size_bytes_raw": int(fetch), "write_size_bytes": int(write),
                "kernel_src_sha16": B.kernel_source_sha(),
