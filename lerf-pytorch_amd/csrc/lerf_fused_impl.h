@@ -593,13 +593,13 @@ __device__ __forceinline__ int wave_lower_bound(const int* __restrict__ a, int n
 //      coordinates (np.pad(..., 'edge') in every rotated frame).  Every load of a thread is issued before its first
 //      LDS store (one L2/HBM latency); `between()` runs while the loads are in flight.
 template <int IY, int IPB, int IP, typename F>
-__device__ __forceinline__ int load_input_tile(uint8_t* Ct, const uint8_t* __restrict__ img, const Params& P, int H, int W, int iy0,
+__device__ __forceinline__ int load_input_tile(uint8_t* Ct, const uint8_t* __restrict__ img, int H, int W, int iy0,
                                                int ix0, bool interior, int tid, F between) {
     int cphase = 0;
     const int64_t row0 = ((int64_t)iy0 * W + ix0) * CH;                     // first byte of the region in the frame
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(img) + (uintptr_t)row0;
-    const bool dwords = interior && ((W * CH) & 3) == 0 && (P.in_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.img) & 3) == 0 &&
-                        (iy0 + IY < P.H || (ix0 * CH - (int)(a0 & 3)) + IP <= W * CH);   // never read past the frame
+    const bool dwords = interior && ((W * CH) & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 &&
+                        (iy0 + IY < H || (ix0 * CH - (int)(a0 & 3)) + IP <= W * CH);   // never read past the frame
     if (dwords) {
         cphase = (int)(a0 & 3);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a0 - (uintptr_t)cphase);
@@ -668,27 +668,41 @@ __device__ __forceinline__ int xcd_order(int b, int total) {
 // GEN = true: the general kernels -- any 1..4 sampling patterns per stage (run-time neighbour offsets), scale factors up to
 // x8 (large geometry tables, staged late), frames of different sizes in one launch (RaggedTable).  GEN = false: the
 // specialised kernels of the published configuration (modes "sct" / "sct", scale < 4.9, one frame size).
+// What a workgroup needs to know about ITS frame, as plain values (never a modified copy of the kernel arguments: a
+// 600-byte struct that is written through a reference ends up in scratch memory and every later P.x becomes a scratch load --
+// the first version of the general kernels ran at half speed for that reason).
+struct FrameView {
+    const uint8_t* img; uint8_t* out; uint8_t* feat; uint32_t* emit;
+    const int* left_r; const float* dis_r; const int* left_c; const float* dis_c;
+    const double* dis_r64; const double* dis_c64;
+    int H, W, oH, oW, tiles_x, tiles_y;
+};
 template <bool GEN>
-__device__ __forceinline__ int select_frame(Params& P, const std::conditional_t<GEN, RaggedTable, NoTable>& T, int& bid) {
+__device__ __forceinline__ FrameView frame_view(const Params& P, const std::conditional_t<GEN, RaggedTable, NoTable>& T, int& bid) {
+    FrameView F;
     if constexpr (GEN) {
         if (T.n > 0) {
             int f = 0;
             for (int k = 1; k < T.n; ++k)
                 if (bid >= T.d[k].first_block) f = k;
-            const FrameDesc& d = T.d[f];
-            bid -= d.first_block;
-            P.img = d.img; P.out = d.out; P.feat = d.feat; P.emit = d.emit;
-            P.in_sn = 0; P.out_sn = 0; P.feat_sn = 0; P.emit_sn = 0;
-            P.left_r = d.left_r; P.dis_r = d.dis_r; P.left_c = d.left_c; P.dis_c = d.dis_c;
-            P.dis_r64 = d.dis_r64; P.dis_c64 = d.dis_c64;
-            P.H = d.H; P.W = d.W; P.oH = d.oH; P.oW = d.oW; P.tiles_x = d.tiles_x; P.tiles_y = d.tiles_y;
-            return 0;
+            bid -= T.d[f].first_block;
+            F.img = T.d[f].img; F.out = T.d[f].out; F.feat = T.d[f].feat; F.emit = T.d[f].emit;
+            F.left_r = T.d[f].left_r; F.dis_r = T.d[f].dis_r; F.left_c = T.d[f].left_c; F.dis_c = T.d[f].dis_c;
+            F.dis_r64 = T.d[f].dis_r64; F.dis_c64 = T.d[f].dis_c64;
+            F.H = T.d[f].H; F.W = T.d[f].W; F.oH = T.d[f].oH; F.oW = T.d[f].oW;
+            F.tiles_x = T.d[f].tiles_x; F.tiles_y = T.d[f].tiles_y;
+            return F;
         }
     }
     const int tiles = P.tiles_y * P.tiles_x;
     const int frame = bid / tiles;
     bid -= frame * tiles;
-    return frame;
+    F.img = P.img + frame * P.in_sn; F.out = P.out + frame * P.out_sn;
+    F.feat = P.feat + frame * P.feat_sn; F.emit = P.emit + frame * P.emit_sn;
+    F.left_r = P.left_r; F.dis_r = P.dis_r; F.left_c = P.left_c; F.dis_c = P.dis_c;
+    F.dis_r64 = P.dis_r64; F.dis_c64 = P.dis_c64;
+    F.H = P.H; F.W = P.W; F.oH = P.oH; F.oW = P.oW; F.tiles_x = P.tiles_x; F.tiles_y = P.tiles_y;
+    return F;
 }
 
 template <int S, int KIND, bool EMIT, bool FROM_FEAT = false, bool GEN = false>
@@ -701,12 +715,12 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     const int wave = tid >> 6;
 
     int bid = xcd_order((int)blockIdx.x, (int)gridDim.x);
-    const int frame = select_frame<GEN>(P, T, bid);
-    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const FrameView F = frame_view<GEN>(P, T, bid);
+    const int tyi = bid / F.tiles_x, txi = bid - tyi * F.tiles_x;
     const int ty0 = P.ty_org + tyi * TH, tx0 = P.tx_org + txi * TW;
-    const int H = P.H, W = P.W;
-    const uint8_t* __restrict__ img = P.img + frame * P.in_sn;
-    uint8_t* __restrict__ outp = P.out + frame * P.out_sn;
+    const int H = F.H, W = F.W;
+    const uint8_t* __restrict__ img = F.img;
+    uint8_t* __restrict__ outp = F.out;
 
     // region origins in frame coordinates
     const int hy0 = ty0 - D::R3, hx0 = tx0 - D::R3;
@@ -717,9 +731,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     int* ctl = reinterpret_cast<int*>(smem + D::OFF_CTL);
     // interior tile: the whole input region lies inside the frame, so no coordinate is ever clamped and the
     // centre addresses reduce to a multiply-add (center_addr's H < 0 path); ~80 % of the tiles of a 1080p frame
-    const bool interior = FROM_FEAT ? (fy0 >= 0 && fx0 >= 0 && fy0 + D::FY <= P.H && fx0 + D::FX <= P.W)
-                                    : (iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= P.H && ix0 + D::IX <= P.W);
-    const int Hc = interior ? -1 : P.H, Wc = P.W;
+    const bool interior = FROM_FEAT ? (fy0 >= 0 && fx0 >= 0 && fy0 + D::FY <= F.H && fx0 + D::FX <= F.W)
+                                    : (iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= F.H && ix0 + D::IX <= F.W);
+    const int Hc = interior ? -1 : F.H, Wc = F.W;
 
     int* g_lr = reinterpret_cast<int*>(smem + D::OFF_GEO);
     float* g_dr = reinterpret_cast<float*>(g_lr + D::GEO_ROWS);
@@ -729,9 +743,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     auto geo_search = [&]() {
         if (wave < 4) {
             const bool rows = wave < 2;
-            const int* tab = rows ? P.left_r : P.left_c;
-            const int n = rows ? P.oH : P.oW;
-            const int ti = rows ? tyi : txi, tn = rows ? P.tiles_y : P.tiles_x, t0 = rows ? ty0 : tx0;
+            const int* tab = rows ? F.left_r : F.left_c;
+            const int n = rows ? F.oH : F.oW;
+            const int ti = rows ? tyi : txi, tn = rows ? F.tiles_y : F.tiles_x, t0 = rows ? ty0 : tx0;
             int r;
             if (!(wave & 1)) r = ti == 0 ? 0 : wave_lower_bound(tab, n, t0 - D::R3, lane);
             else r = ti == tn - 1 ? n : wave_lower_bound(tab, n, t0 + (rows ? TH : TW) - D::R3, lane);
@@ -743,14 +757,14 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         const int gi0 = ctl[16], gi1 = ctl[17], gj0 = ctl[18], gj1 = ctl[19];
         const float gscale = KIND == LERF_KIND_GAUSS ? s3::gauss_scale(P.max_sigma) : 1.0f;
         for (int e = tid; e < gi1 - gi0; e += NT) {
-            g_lr[e] = P.left_r[gi0 + e] - hy0;
+            g_lr[e] = F.left_r[gi0 + e] - hy0;
 #pragma unroll
-            for (int b = 0; b < S; ++b) g_dr[e * S + b] = P.dis_r[(gi0 + e) * S + b] * gscale;
+            for (int b = 0; b < S; ++b) g_dr[e * S + b] = F.dis_r[(gi0 + e) * S + b] * gscale;
         }
         for (int e = tid; e < gj1 - gj0; e += NT) {
-            g_lc[e] = P.left_c[gj0 + e] - hx0;
+            g_lc[e] = F.left_c[gj0 + e] - hx0;
 #pragma unroll
-            for (int a = 0; a < S; ++a) g_dc[e * S + a] = P.dis_c[(gj0 + e) * S + a] * gscale;
+            for (int a = 0; a < S; ++a) g_dc[e * S + a] = F.dis_c[(gj0 + e) * S + a] * gscale;
         }
     };
 
@@ -761,7 +775,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 #endif
     if (!FROM_FEAT) {
     // ---- input tile (load_input_tile), the geometry search riding behind its loads
-    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, P, H, W, iy0, ix0, interior, tid,
+    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, H, W, iy0, ix0, interior, tid,
                                                              [&]() { if (D::GEO_EARLY && !EMIT) geo_search(); });
 
     // ---- stage 1: three byte LUTs, 4 rotations each (eval_lut_sr.py:541-577)
@@ -828,9 +842,8 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     } else {
         // ---- feat tile (with its halo) from the stage-1 launch; out-of-frame positions take the clamped pixel,
         //      which is what stage 1 evaluates for them
-        const uint8_t* __restrict__ fsrc = P.feat + frame * P.feat_sn;
-        const bool dwords = interior && (D::FP & 3) == 0 && ((W * CH) & 3) == 0 && (P.feat_sn & 3) == 0 &&
-                            (reinterpret_cast<uintptr_t>(P.feat) & 3) == 0 && ((fx0 * CH) & 3) == 0;
+        const uint8_t* __restrict__ fsrc = F.feat;
+        const bool dwords = interior && (D::FP & 3) == 0 && ((W * CH) & 3) == 0 && (reinterpret_cast<uintptr_t>(F.feat) & 3) == 0 && ((fx0 * CH) & 3) == 0;
         if (dwords) {
             constexpr int RD = D::FP / 4, ND = D::FY * RD, KD = (ND + NT - 1) / NT;
             const uint32_t* src = reinterpret_cast<const uint32_t*>(fsrc + ((int64_t)fy0 * W + fx0) * CH);
@@ -884,7 +897,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         const int sy = pad_index(gy, H, P.pad_mode, &zy), sx = pad_index(gx, W, P.pad_mode, &zx);
         const int ry = sy - fy0, rx = sx - fx0;
         if (ry >= 0 && ry < D::FY && rx >= 0 && rx < D::FX) return (uint32_t)Bt[ry * D::FP + rx * CH + c];
-        if (FROM_FEAT) return (uint32_t)(P.feat + frame * P.feat_sn)[((int64_t)sy * W + sx) * CH + c];
+        if (FROM_FEAT) return (uint32_t)F.feat[((int64_t)sy * W + sx) * CH + c];
         return 0u;                      // not reached: the host sends wrap padding through the two-launch path
     };
 
@@ -1277,7 +1290,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 
     if (EMIT) {
         __syncthreads();
-        uint32_t* eo = P.emit + frame * P.emit_sn;
+        uint32_t* eo = F.emit;
         const int rows = min(TH, H - ty0), cols3 = min(TW, W - tx0) * CH;
         for (int il = wave; il < rows; il += NW) {
             const uint32_t* srow = Dt + (il + D::R3) * D::HP + D::R3 * CH;
@@ -1307,8 +1320,8 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         constexpr int GMAX = S == 2 ? 5 : 3;                      // rows per group (larger runs are split)
         int* g_grp = reinterpret_cast<int*>(g_dc + D::GEO_COLS * S);
         const int ncolc = ncol * CH;
-        const int64_t rowpitch = (int64_t)P.oW * CH;
-        uint8_t* seg0 = outp + ((int64_t)i0 * P.oW + j0) * CH;
+        const int64_t rowpitch = (int64_t)F.oW * CH;
+        uint8_t* seg0 = outp + ((int64_t)i0 * F.oW + j0) * CH;
         const bool rows_align = (rowpitch & 3) == 0;              // dword columns line up across the rows of a group
         // dword columns per row: when every row of the block starts on a 4-byte boundary (a0 == 0 below) the block needs
         // no slack column, and a 384-byte tile row is exactly 96 dwords = whole 128-byte lines per wave store
@@ -1427,7 +1440,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                     }
                 }
             }
-            if ((DIST ? dmax > 0.5f - s3::kTieEps : tiebits != 0) && P.dis_r64 != nullptr) {
+            if ((DIST ? dmax > 0.5f - s3::kTieEps : tiebits != 0) && F.dis_r64 != nullptr) {
                 unsigned tiemask = tiebits;
                 if (DIST) {
 #pragma unroll
@@ -1452,9 +1465,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                     uint32_t dd[SS];
                     double dx64[S], dy64[S];
 #pragma unroll
-                    for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il0 + r) * S + b];
+                    for (int b = 0; b < S; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il0 + r) * S + b];
 #pragma unroll
-                    for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
+                    for (int a = 0; a < S; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl) * S + a];
 #pragma unroll
                     for (int a = 0; a < S; ++a)
 #pragma unroll
@@ -1491,7 +1504,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         else run_tasks(std::integral_constant<int, 0>{});
         // ---- tie pass: the queued outputs in float64, one per lane; each patches its byte behind the task loop's
         //      dword stores (drained and fenced by the barrier)
-        if (P.dis_r64 != nullptr) {
+        if (F.dis_r64 != nullptr) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int nq = min(*tq_count, P.tq_cap);
@@ -1504,9 +1517,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 uint32_t dd[SS];
                 double dx64[S], dy64[S];
 #pragma unroll
-                for (int b = 0; b < S; ++b) dx64[b] = P.dis_r64[(int64_t)(i0 + il) * S + b];
+                for (int b = 0; b < S; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il) * S + b];
 #pragma unroll
-                for (int a = 0; a < S; ++a) dy64[a] = P.dis_c64[(int64_t)(j0 + jl) * S + a];
+                for (int a = 0; a < S; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl) * S + a];
 #pragma unroll
                 for (int a = 0; a < S; ++a)
 #pragma unroll
@@ -1544,17 +1557,17 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     int bid = xcd_order((int)blockIdx.x, (int)gridDim.x);
-    const int frame = select_frame<GEN>(P, T, bid);
-    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const FrameView F = frame_view<GEN>(P, T, bid);
+    const int tyi = bid / F.tiles_x, txi = bid - tyi * F.tiles_x;
     const int fy0 = tyi * TH, fx0 = txi * TW;
     const int iy0 = fy0 - R1, ix0 = fx0 - R1;
-    const int H = P.H, W = P.W;
-    const uint8_t* __restrict__ img = P.img + frame * P.in_sn;
+    const int H = F.H, W = F.W;
+    const uint8_t* __restrict__ img = F.img;
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= H && ix0 + D::IX <= W;
     const int Hc = interior ? -1 : H, Wc = W;
     uint8_t* Ft = smem + D::OFF_F;
 
-    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, P, H, W, iy0, ix0, interior, tid, []() {});
+    const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, H, W, iy0, ix0, interior, tid, []() {});
     {
         const uint8_t* Ct = smem + D::OFF_C + cphase;
         int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
@@ -1593,9 +1606,9 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         }
     }
     // the block's rows to P.feat
-    uint8_t* __restrict__ fdst = P.feat + frame * P.feat_sn;
+    uint8_t* __restrict__ fdst = F.feat;
     const int rows = min(TH, H - fy0), cols3 = min(TW, W - fx0) * CH;
-    const bool dwords = cols3 == D::FP && ((W * CH) & 3) == 0 && (P.feat_sn & 3) == 0 && (reinterpret_cast<uintptr_t>(P.feat) & 3) == 0;
+    const bool dwords = cols3 == D::FP && ((W * CH) & 3) == 0 && (reinterpret_cast<uintptr_t>(F.feat) & 3) == 0;
     if (dwords) {
         constexpr int RD = D::FP / 4;
         uint32_t* dst = reinterpret_cast<uint32_t*>(fdst + ((int64_t)fy0 * W + fx0) * CH);
