@@ -240,6 +240,28 @@ for scale in (2.0, 1.5):
         assert torch.equal(whole, full[b]), "stitched strips differ from the full frame (scale %s)" % scale
         single = ldist.sr_frame_strips(eng, torch.from_numpy(img[b, plan.y0:plan.y1]).cuda(), H, scale, gather=True)
         assert torch.equal(single, full[b])
+# 2-D blocks over the same ranks (8 ranks: 2 x 4; 2 ranks: 1 x 2): edges + corners in one batch_isend_irecv, one pack and
+# one unpack launch, tiles over the owned block, one launch per frame batch
+grid = ldist.block_grid(world)
+for scale in (2.0, 1.5):
+    geo = eng.sr_geometry((H, W), scale)
+    lr, lc = geo.host["left_r"], geo.host["left_c"]
+    plan = ldist.BlockPlan(H, W, grid, rank, eng.support, lr, lc)
+    buf = ldist.BlockBuffer(plan, N, 3, torch.uint8, torch.device("cuda"), lr, lc)
+    for rep in range(2):
+        buf.ext.zero_()
+        buf.own.copy_(torch.from_numpy(np.ascontiguousarray(img[:, plan.y0:plan.y1, plan.x0:plan.x1])).cuda())
+        ext = buf.exchange()
+    torch.cuda.synchronize()
+    assert np.array_equal(ext.cpu().numpy(), img[:, plan.ylo:plan.yhi, plan.xlo:plan.xhi]), "block halo differs"
+    mine = ldist.sr_block(eng, ext, plan, geo)                       # [N, h, w, 3]
+    rects = [ldist.BlockPlan(H, W, grid, r, eng.support, lr, lc).out_rect() for r in range(world)]
+    full = eng.sr(torch.from_numpy(img).cuda(), scale)
+    whole = ldist.gather_blocks(mine, rects, geo.out_hw)
+    assert torch.equal(whole, full), "stitched blocks differ from the full frames (scale %s)" % scale
+    single = ldist.sr_frame_blocks(eng, torch.from_numpy(np.ascontiguousarray(img[0, plan.y0:plan.y1, plan.x0:plan.x1])).cuda(), H, W, scale,
+                                   gather=True)
+    assert torch.equal(single, full[0])
 dist.barrier()
 dist.destroy_process_group()
 print("rank %d ok" % rank)
@@ -247,10 +269,12 @@ print("rank %d ok" % rank)
 
 
 def test_rccl_two_rank_halo_exchange_and_stitch(torch, tmp_path):
-    """2 processes, one GPU each, backend nccl (= RCCL): halo rows arrive in place, the stitched strips equal the
-    full frame at x2 and x1.5 (unequal strips).  Skipped on a 1-GPU box."""
+    """min(device_count, 8) processes (at least 2), one GPU each, backend nccl (= RCCL): halo rows (strips) and halo
+    rectangles (2-D blocks, edges + corners) arrive in place, the stitched strips / blocks equal the full frame at x2
+    and x1.5 (unequal parts).  Skipped on a 1-GPU box."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    world = min(torch.cuda.device_count(), 8)
     script = tmp_path / "nccl_worker.py"
     script.write_text(_NCCL_WORKER)
     s = socket.socket()
@@ -258,14 +282,14 @@ def test_rccl_two_rank_halo_exchange_and_stitch(torch, tmp_path):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LERF_REPO=REPO)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=600)
+            o, _ = p.communicate(timeout=900)
         except subprocess.TimeoutExpired:
             p.kill()
             o, _ = p.communicate()
