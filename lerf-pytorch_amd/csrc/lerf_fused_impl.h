@@ -529,6 +529,105 @@ __device__ __forceinline__ void byte_phase(const int8_t* lut, const uint8_t* src
     }
 }
 
+// ---------------------------------------------------------------------------
+// Stage-1 positions of INTERIOR tiles with the pixel reads on the vector-memory path (s1_kernel): stage 1 is bound by the
+// LDS (the byte-LUT gathers keep its array 82 % busy, PMC) while the texture path idles -- so the 9 / 13 neighbourhood
+// pixels of a position are fetched straight from the frame (global_load_ubyte_d16_hi: the same "byte in bits 16..23" form
+// the LDS reads deliver; L1 / L2 hits, the tile's rows are read 13 times over), one position AHEAD of the lookups, and the
+// LDS serves the LUT gathers and the partial sums only.  Addresses cost nothing: address = row base (one SGPR pair per
+// dy in -3..3) + the position's byte offset (one VGPR) + dx * CH (immediate).
+// ---------------------------------------------------------------------------
+struct DyDx { int dy[3], dx[3]; };
+__host__ __device__ constexpr DyDx pattern_dydx(char mode, int rot) {
+    int dy[4] = {0, 0, 0, 0}, dx[4] = {0, 0, 0, 0};
+    switch (mode) {
+        case 's': dy[1] = 0; dx[1] = 1; dy[2] = 1; dx[2] = 0; dy[3] = 1; dx[3] = 1; break;
+        case 'd': dy[1] = 0; dx[1] = 2; dy[2] = 2; dx[2] = 0; dy[3] = 2; dx[3] = 2; break;
+        case 'y': dy[1] = 1; dx[1] = 1; dy[2] = 1; dx[2] = 2; dy[3] = 2; dx[3] = 1; break;
+        case 'c': dy[1] = 0; dx[1] = 1; dy[2] = 0; dx[2] = 2; dy[3] = 0; dx[3] = 3; break;
+        default:  dy[1] = 1; dx[1] = 1; dy[2] = 2; dx[2] = 2; dy[3] = 3; dx[3] = 3; break;   // 't'
+    }
+    DyDx r{};
+    for (int k = 1; k < 4; ++k) {
+        int y = dy[k], x = dx[k];
+        for (int i = 0; i < (rot & 3); ++i) { int t = y; y = x; x = -t; }
+        r.dy[k - 1] = y;
+        r.dx[k - 1] = x;
+    }
+    return r;
+}
+template <int IMM>
+__device__ __forceinline__ uint32_t gl_pixel_hi(uint32_t voff, uint64_t rowbase) {
+    uint32_t r;
+    asm volatile("global_load_ubyte_d16_hi %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(rowbase), "n"(IMM));
+    return r;
+}
+struct PixSet { uint32_t a, b[4], c[4], d[4]; };
+// rows[dy + 3] = address of the region's first centre pixel, dy rows away
+template <char MODE>
+__device__ __forceinline__ void pix_issue(PixSet& P, uint32_t voff, const uint64_t (&rows)[7]) {
+    P.a = gl_pixel_hi<0>(voff, rows[3]);
+#define LERF_PX(R, K) gl_pixel_hi<pattern_dydx(MODE, R).dx[K] * CH>(voff, rows[pattern_dydx(MODE, R).dy[K] + 3])
+    if constexpr (MODE == 's') {
+        // the four rotations of the 2x2 pattern cover the 3x3 block: its edge neighbours E, S, W, N are pixel b of one
+        // rotation and pixel c of the previous one -- 8 loads serve the 12 operands (pix_ready hands them out)
+        P.b[0] = LERF_PX(0, 0); P.b[1] = LERF_PX(1, 0); P.b[2] = LERF_PX(2, 0); P.b[3] = LERF_PX(3, 0);
+        P.d[0] = LERF_PX(0, 2); P.d[1] = LERF_PX(1, 2); P.d[2] = LERF_PX(2, 2); P.d[3] = LERF_PX(3, 2);
+    } else {
+        P.b[0] = LERF_PX(0, 0); P.c[0] = LERF_PX(0, 1); P.d[0] = LERF_PX(0, 2);
+        P.b[1] = LERF_PX(1, 0); P.c[1] = LERF_PX(1, 1); P.d[1] = LERF_PX(1, 2);
+        P.b[2] = LERF_PX(2, 0); P.c[2] = LERF_PX(2, 1); P.d[2] = LERF_PX(2, 2);
+        P.b[3] = LERF_PX(3, 0); P.c[3] = LERF_PX(3, 1); P.d[3] = LERF_PX(3, 2);
+    }
+#undef LERF_PX
+}
+template <char MODE>
+__device__ __forceinline__ void pix_ready(PixSet& P) {
+    if constexpr (MODE == 's') {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(P.a), "+v"(P.b[0]), "+v"(P.b[1]), "+v"(P.b[2]), "+v"(P.b[3]), "+v"(P.d[0]), "+v"(P.d[1]),
+                     "+v"(P.d[2]), "+v"(P.d[3]));
+        static_assert(pattern_dydx('s', 0).dy[1] == pattern_dydx('s', 1).dy[0] && pattern_dydx('s', 0).dx[1] == pattern_dydx('s', 1).dx[0],
+                      "pixel c of rotation r = pixel b of rotation r + 1");
+        P.c[0] = P.b[1]; P.c[1] = P.b[2]; P.c[2] = P.b[3]; P.c[3] = P.b[0];
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(P.a), "+v"(P.b[0]), "+v"(P.c[0]), "+v"(P.d[0]), "+v"(P.b[1]), "+v"(P.c[1]), "+v"(P.d[1]), "+v"(P.b[2]),
+                       "+v"(P.c[2]), "+v"(P.d[2]), "+v"(P.b[3]), "+v"(P.c[3]), "+v"(P.d[3]));
+    }
+}
+// one byte-LUT phase over the NDST = FY x FP positions of an interior s1 tile; origin = address of the tile's first pixel
+// in the frame, pitch = bytes per frame row.  PHASE as in byte_position.
+template <int NDST, int DPc, char MODE, int PHASE>
+__device__ __forceinline__ void byte_phase_vmem(const int8_t* lut, const uint8_t* __restrict__ origin, int pitch, int16_t* acc16,
+                                                uint8_t* dst8, int div, int bias, int tid) {
+    static_assert(NDST % (2 * NT) == 0, "positions come in pairs per thread (ping-pong pixel registers)");
+    const uint32_t lut_a = lds_addr(lut);
+    uint64_t rows[7];
+#pragma unroll
+    for (int dy = -3; dy <= 3; ++dy) rows[dy + 3] = (uint64_t)reinterpret_cast<uintptr_t>(origin + (int64_t)dy * pitch);
+    auto voff_of = [&](int p) { const int ry = p / DPc; return (uint32_t)(ry * pitch + (p - ry * DPc)); };
+    auto finish = [&](const PixSet& X, int p) {
+        int v = byte_walks<4>(lut_a, X.a, X.b, X.c, X.d);
+        if (PHASE != 0) v += (int)acc16[p];
+        if (PHASE == 2)
+            dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
+        else
+            acc16[p] = (int16_t)v;
+    };
+    PixSet A, B;
+    pix_issue<MODE>(A, voff_of(tid), rows);
+#pragma unroll 1
+    for (int k = 0; k < NDST / NT; k += 2) {
+        const int p = tid + k * NT;
+        pix_ready<MODE>(A);
+        pix_issue<MODE>(B, voff_of(p + NT), rows);
+        finish(A, p);
+        pix_ready<MODE>(B);
+        if (k + 2 < NDST / NT) pix_issue<MODE>(A, voff_of(p + 2 * NT), rows);
+        finish(B, p + NT);
+    }
+}
+
 // General kernels: the same phase with the pattern offsets `o` (see byte_lookups_rt) and the phase kind at run time --
 // `first`: store the partial sums, otherwise add; `last`: finalise with (div, bias) into dst8.  All wave-uniform.
 template <int NROT>
@@ -1567,6 +1666,35 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     const int Hc = interior ? -1 : H, Wc = W;
     uint8_t* Ft = smem + D::OFF_F;
 
+#ifndef LERF_S1_LDS_PIXELS
+    // interior tiles of the specialised kernel: pixel reads on the vector-memory path (byte_phase_vmem), no input tile in LDS
+    const bool vmem_pixels = !GEN && interior;
+#else
+    const bool vmem_pixels = false;
+#endif
+    if (vmem_pixels) {
+        int8_t* lut = reinterpret_cast<int8_t*>(smem + D::OFF_LUT);
+        int16_t* acc = reinterpret_cast<int16_t*>(smem + D::OFF_ACC);
+        const int div1 = kQ * 3;
+        const uint8_t* org = img + ((int64_t)fy0 * W + fx0) * CH;
+        const int pitch = W * CH;
+        constexpr int L1N = (LERF_LUT_ENTRIES + 15) / 16, L1TAIL = L1N - 5 * NT;
+        uint4 n0, n1, n2, n3, n4, n5 = make_uint4(0, 0, 0, 0);
+        copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
+        __syncthreads();
+        LERF_S1_LOAD(P.pack + 1 * LUT_PAD);
+        byte_phase_vmem<D::NF, D::FP, 's', 0>(lut, org, pitch, acc, Ft, div1, 0, tid);
+        __syncthreads();
+        LERF_S1_STORE();
+        __syncthreads();
+        LERF_S1_LOAD(P.pack + 2 * LUT_PAD);
+        byte_phase_vmem<D::NF, D::FP, 'c', 1>(lut, org, pitch, acc, Ft, div1, 0, tid);
+        __syncthreads();
+        LERF_S1_STORE();
+        __syncthreads();
+        byte_phase_vmem<D::NF, D::FP, 't', 2>(lut, org, pitch, acc, Ft, div1, 0, tid);
+        __syncthreads();
+    } else {
     const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, H, W, iy0, ix0, interior, tid, []() {});
     {
         const uint8_t* Ct = smem + D::OFF_C + cphase;
@@ -1604,6 +1732,7 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         byte_phase<D::NF, D::FP, D::IP, 't', 0, 4, 1, 2, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, div1, 0, tid);
         __syncthreads();
         }
+    }
     }
     // the block's rows to P.feat
     uint8_t* __restrict__ fdst = F.feat;
