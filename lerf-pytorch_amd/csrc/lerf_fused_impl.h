@@ -563,12 +563,12 @@ __device__ __forceinline__ uint32_t gl_pixel_hi(uint32_t voff, uint64_t rowbase)
     return r;
 }
 struct PixSet { uint32_t a, b[4], c[4], d[4]; };
-// rows[dy + 3] = address of the region's first centre pixel, dy rows away
-template <char MODE>
+// rows[dy + 3] = address of the region's first centre pixel, dy rows away; rotations ROT0 + i * RSTEP, i < NROT
+template <char MODE, int ROT0, int NROT, int RSTEP>
 __device__ __forceinline__ void pix_issue(PixSet& P, uint32_t voff, const uint64_t (&rows)[7]) {
     P.a = gl_pixel_hi<0>(voff, rows[3]);
-#define LERF_PX(R, K) gl_pixel_hi<pattern_dydx(MODE, R).dx[K] * CH>(voff, rows[pattern_dydx(MODE, R).dy[K] + 3])
-    if constexpr (MODE == 's') {
+#define LERF_PX(I, K) gl_pixel_hi<pattern_dydx(MODE, ROT0 + (I) * RSTEP).dx[K] * CH>(voff, rows[pattern_dydx(MODE, ROT0 + (I) * RSTEP).dy[K] + 3])
+    if constexpr (MODE == 's' && NROT == 4 && ROT0 == 0 && RSTEP == 1) {
         // the four rotations of the 2x2 pattern cover the 3x3 block: its edge neighbours E, S, W, N are pixel b of one
         // rotation and pixel c of the previous one -- 8 loads serve the 12 operands (pix_ready hands them out)
         P.b[0] = LERF_PX(0, 0); P.b[1] = LERF_PX(1, 0); P.b[2] = LERF_PX(2, 0); P.b[3] = LERF_PX(3, 0);
@@ -576,38 +576,48 @@ __device__ __forceinline__ void pix_issue(PixSet& P, uint32_t voff, const uint64
     } else {
         P.b[0] = LERF_PX(0, 0); P.c[0] = LERF_PX(0, 1); P.d[0] = LERF_PX(0, 2);
         P.b[1] = LERF_PX(1, 0); P.c[1] = LERF_PX(1, 1); P.d[1] = LERF_PX(1, 2);
-        P.b[2] = LERF_PX(2, 0); P.c[2] = LERF_PX(2, 1); P.d[2] = LERF_PX(2, 2);
-        P.b[3] = LERF_PX(3, 0); P.c[3] = LERF_PX(3, 1); P.d[3] = LERF_PX(3, 2);
+        if constexpr (NROT == 4) {
+            P.b[2] = LERF_PX(2, 0); P.c[2] = LERF_PX(2, 1); P.d[2] = LERF_PX(2, 2);
+            P.b[3] = LERF_PX(3, 0); P.c[3] = LERF_PX(3, 1); P.d[3] = LERF_PX(3, 2);
+        }
     }
 #undef LERF_PX
 }
-template <char MODE>
+template <char MODE, int ROT0, int NROT, int RSTEP>
 __device__ __forceinline__ void pix_ready(PixSet& P) {
-    if constexpr (MODE == 's') {
+    if constexpr (MODE == 's' && NROT == 4 && ROT0 == 0 && RSTEP == 1) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(P.a), "+v"(P.b[0]), "+v"(P.b[1]), "+v"(P.b[2]), "+v"(P.b[3]), "+v"(P.d[0]), "+v"(P.d[1]),
                      "+v"(P.d[2]), "+v"(P.d[3]));
         static_assert(pattern_dydx('s', 0).dy[1] == pattern_dydx('s', 1).dy[0] && pattern_dydx('s', 0).dx[1] == pattern_dydx('s', 1).dx[0],
                       "pixel c of rotation r = pixel b of rotation r + 1");
         P.c[0] = P.b[1]; P.c[1] = P.b[2]; P.c[2] = P.b[3]; P.c[3] = P.b[0];
-    } else {
+    } else if constexpr (NROT == 4) {
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(P.a), "+v"(P.b[0]), "+v"(P.c[0]), "+v"(P.d[0]), "+v"(P.b[1]), "+v"(P.c[1]), "+v"(P.d[1]), "+v"(P.b[2]),
                        "+v"(P.c[2]), "+v"(P.d[2]), "+v"(P.b[3]), "+v"(P.c[3]), "+v"(P.d[3]));
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(P.a), "+v"(P.b[0]), "+v"(P.c[0]), "+v"(P.d[0]), "+v"(P.b[1]), "+v"(P.c[1]), "+v"(P.d[1]));
     }
 }
-// one byte-LUT phase over the NDST = FY x FP positions of an interior s1 tile; origin = address of the tile's first pixel
-// in the frame, pitch = bytes per frame row.  PHASE as in byte_position.
-template <int NDST, int DPc, char MODE, int PHASE>
+// one byte-LUT phase over the NDST positions (row pitch DPc) of an INTERIOR region; origin = address of the region's first
+// centre pixel in the frame (stage 1: the input, stage 2 of LeRF-L: the stage-1 output), pitch = bytes per frame row.
+// PHASE as in byte_position.  Threads past the last position of the final round repeat it (loads only).
+template <int NDST, int DPc, char MODE, int ROT0, int NROT, int RSTEP, int PHASE>
 __device__ __forceinline__ void byte_phase_vmem(const int8_t* lut, const uint8_t* __restrict__ origin, int pitch, int16_t* acc16,
                                                 uint8_t* dst8, int div, int bias, int tid) {
-    static_assert(NDST % (2 * NT) == 0, "positions come in pairs per thread (ping-pong pixel registers)");
+    constexpr int ROUNDS = (NDST + NT - 1) / NT, PAIRS = (ROUNDS + 1) / 2;
     const uint32_t lut_a = lds_addr(lut);
     uint64_t rows[7];
 #pragma unroll
     for (int dy = -3; dy <= 3; ++dy) rows[dy + 3] = (uint64_t)reinterpret_cast<uintptr_t>(origin + (int64_t)dy * pitch);
-    auto voff_of = [&](int p) { const int ry = p / DPc; return (uint32_t)(ry * pitch + (p - ry * DPc)); };
+    auto voff_of = [&](int p) {
+        p = p < NDST ? p : NDST - 1;
+        const int ry = p / DPc;
+        return (uint32_t)(ry * pitch + (p - ry * DPc));
+    };
     auto finish = [&](const PixSet& X, int p) {
-        int v = byte_walks<4>(lut_a, X.a, X.b, X.c, X.d);
+        if (NDST % NT != 0 && p >= NDST) return;
+        int v = byte_walks<NROT>(lut_a, X.a, X.b, X.c, X.d);
         if (PHASE != 0) v += (int)acc16[p];
         if (PHASE == 2)
             dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
@@ -615,16 +625,16 @@ __device__ __forceinline__ void byte_phase_vmem(const int8_t* lut, const uint8_t
             acc16[p] = (int16_t)v;
     };
     PixSet A, B;
-    pix_issue<MODE>(A, voff_of(tid), rows);
+    pix_issue<MODE, ROT0, NROT, RSTEP>(A, voff_of(tid), rows);
 #pragma unroll 1
-    for (int k = 0; k < NDST / NT; k += 2) {
-        const int p = tid + k * NT;
-        pix_ready<MODE>(A);
-        pix_issue<MODE>(B, voff_of(p + NT), rows);
+    for (int k = 0; k < PAIRS; ++k) {
+        const int p = tid + 2 * k * NT;
+        pix_ready<MODE, ROT0, NROT, RSTEP>(A);
+        pix_issue<MODE, ROT0, NROT, RSTEP>(B, voff_of(p + NT), rows);
         finish(A, p);
-        pix_ready<MODE>(B);
-        if (k + 2 < NDST / NT) pix_issue<MODE>(A, voff_of(p + 2 * NT), rows);
-        finish(B, p + NT);
+        pix_ready<MODE, ROT0, NROT, RSTEP>(B);
+        if (k + 1 < PAIRS) pix_issue<MODE, ROT0, NROT, RSTEP>(A, voff_of(p + 2 * NT), rows);
+        if (2 * k + 1 < ROUNDS) finish(B, p + NT);
     }
 }
 
@@ -873,7 +883,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
 #endif
     if (!FROM_FEAT) {
-    // ---- input tile (load_input_tile), the geometry search riding behind its loads
+    // ---- input tile (load_input_tile), the geometry search riding behind its loads.  (The vector-memory pixel path of
+    //      s1_kernel was tried here too -- 72 x 72 positions per tile -- and did not pay: 0.191 vs 0.184 ms per 1080 x 960
+    //      block; this kernel's stage 1 shares the CU with nothing else that uses the LDS less.)
     const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, H, W, iy0, ix0, interior, tid,
                                                              [&]() { if (D::GEO_EARLY && !EMIT) geo_search(); });
 
@@ -1024,9 +1036,19 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             d_[tid] = m0; d_[tid + NT] = m1; d_[tid + 2 * NT] = m2; d_[tid + 3 * NT] = m3; d_[tid + 4 * NT] = m4; \
             if (tid < L2TAIL) d_[tid + 5 * NT] = m5;                                               \
         } while (0)
+        // interior tiles of the two-launch path: the seven neighbourhood pixels of a position come from the stage-1 output
+        // in HBM/L2 over the vector-memory path, one position ahead (byte_phase_vmem); these phases are LDS-bound like stage 1
+#ifndef LERF_S1_LDS_PIXELS
+        const bool vm2 = FROM_FEAT && !GEN && interior;
+#else
+        const bool vm2 = false;
+#endif
+        const uint8_t* forg = FROM_FEAT ? F.feat + ((int64_t)hy0 * W + hx0) * CH : nullptr;
+        const int fpitch = W * CH;
 #define LERF_L2(NEXT, MODE, PAR, PH)                                                                       \
         if ((NEXT) < 6) LERF_L2_LOAD(NEXT);                                                                \
-        byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, Hc, Wc, div2, 127, tid); \
+        if (vm2) byte_phase_vmem<D::NH, D::HP, MODE, PAR, 2, 2, PH>(lut, forg, fpitch, acc, hq8, div2, 127, tid); \
+        else byte_phase<D::NH, D::HP, D::FP, MODE, PAR, 2, 2, PH>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, Hc, Wc, div2, 127, tid); \
         __syncthreads();                                                                                   \
         if ((NEXT) < 6) {                                                                                  \
             LERF_L2_STORE();                                                                               \
@@ -1683,16 +1705,16 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
         __syncthreads();
         LERF_S1_LOAD(P.pack + 1 * LUT_PAD);
-        byte_phase_vmem<D::NF, D::FP, 's', 0>(lut, org, pitch, acc, Ft, div1, 0, tid);
+        byte_phase_vmem<D::NF, D::FP, 's', 0, 4, 1, 0>(lut, org, pitch, acc, Ft, div1, 0, tid);
         __syncthreads();
         LERF_S1_STORE();
         __syncthreads();
         LERF_S1_LOAD(P.pack + 2 * LUT_PAD);
-        byte_phase_vmem<D::NF, D::FP, 'c', 1>(lut, org, pitch, acc, Ft, div1, 0, tid);
+        byte_phase_vmem<D::NF, D::FP, 'c', 0, 4, 1, 1>(lut, org, pitch, acc, Ft, div1, 0, tid);
         __syncthreads();
         LERF_S1_STORE();
         __syncthreads();
-        byte_phase_vmem<D::NF, D::FP, 't', 2>(lut, org, pitch, acc, Ft, div1, 0, tid);
+        byte_phase_vmem<D::NF, D::FP, 't', 0, 4, 1, 2>(lut, org, pitch, acc, Ft, div1, 0, tid);
         __syncthreads();
     } else {
     const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, H, W, iy0, ix0, interior, tid, []() {});
