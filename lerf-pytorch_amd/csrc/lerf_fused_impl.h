@@ -380,15 +380,34 @@ __device__ __forceinline__ int byte_walks(uint32_t lut_a, uint32_t ra, const uin
     const unsigned ka = key_of(ra, sa);
     const int basea = (int)(__umul24(msb_of(ra), kStrideA) + lut_a);      // LDS address of the base corner
     Walk<1> W[NROT];
+    int e[NROT][5];
+#ifndef LERF_S1_SPLIT
+#define LERF_S1_SPLIT 1
+#endif
+#if LERF_S1_SPLIT > 0
+    // the gathers of a walk (LERF_S1_SPLIT walks) are issued as soon as its indices exist and fly under the next walk (all
+    // 4 walks first, then all 20 gathers = LERF_S1_SPLIT 0: 0.8 % slower; groups of two: 0.2 % slower; A/B on one box): the
+    // LDS starts on a position's gathers ~100 instructions earlier.  The same split in the stage-2 slot LOST 0.25 %.
+#pragma unroll
+    for (int h = 0; h < NROT; h += LERF_S1_SPLIT) {
+#pragma unroll
+        for (int i = h; i < h + LERF_S1_SPLIT; ++i) W[i] = simplex_walk<1>(ka, basea, rb[i], rc[i], rd[i], sb, sc, sd);
+#pragma unroll
+        for (int i = h; i < h + LERF_S1_SPLIT; ++i)
+#pragma unroll
+            for (int n = 0; n < 5; ++n) e[i][n] = W[i].ldi8(n);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < NROT; ++i) W[i] = simplex_walk<1>(ka, basea, rb[i], rc[i], rd[i], sb, sc, sd);
     // stage C: all LUT gathers in flight together
-    int e[NROT][5];
 #pragma unroll
     for (int i = 0; i < NROT; ++i)
 #pragma unroll
         for (int n = 0; n < 5; ++n) e[i][n] = W[i].ldi8(n);
     __builtin_amdgcn_sched_barrier(0);
+#endif
     // stage D: sum_n w_n P_n = 16 P_0 + sum_n f_n (P_{n+1} - P_n)   (w_0 = 16 - f_0, w_n = f_{n-1} - f_n, w_4 = f_3):
     //          four multiply-adds and four subtractions per lookup instead of five weights + five multiply-adds
     int acc = 0, sum0 = 0;
