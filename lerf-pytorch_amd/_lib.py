@@ -115,6 +115,14 @@ def lib():
         raise LerfError(
             "liblerf_hip.so not found at %s -- build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    # ONE HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so and liblerf_hip.so depends on the same
+    # SONAME, so whichever is loaded first serves both.  With liblerf_hip.so first, torch ends up on the system runtime it
+    # was not built for and the first kernel launch fails with "no ROCm-capable device" (seen when a numpy-class test ran
+    # before anything had imported torch); torch first, and both use torch's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.lerf_abi_version.restype = C.c_int
     L.lerf_strerror.restype = C.c_char_p

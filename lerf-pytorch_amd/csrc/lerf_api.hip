@@ -10,12 +10,13 @@ using namespace lerf;
 
 namespace {
 
-inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-inline int check_launch() {
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+// every device entry point converts its stream before it launches anything: the place to drop stale error codes
+inline hipStream_t as_stream(void* s) {
+    clear_stale_error();
+    return reinterpret_cast<hipStream_t>(s);
 }
+
+inline int check_launch() { return launch_status(); }
 
 inline bool plane_ok(const lerf_plane_t* p) { return p && p->ptr; }
 

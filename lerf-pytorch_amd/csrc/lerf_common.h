@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "lerf_hip.h"
 
@@ -114,6 +116,16 @@ __device__ __forceinline__ SimplexPath simplex_path(int v0, int v1, int v2, int 
 }
 
 __host__ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Launch errors are what hipGetLastError() reports after the launches of an entry point -- but the thread's error state also
+// carries what the CALLER's HIP traffic left there (PyTorch polls its events: hipErrorNotReady).  Entry points drop stale
+// codes before they launch (clear_stale_error) and do not take "not ready" for a launch failure.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && e != hipErrorNotReady && getenv("LERF_DEBUG")) fprintf(stderr, "lerf: HIP error %d: %s\n", (int)e, hipGetErrorString(e));
+    return (e == hipSuccess || e == hipErrorNotReady) ? LERF_OK : LERF_ELAUNCH;
+}
 
 // Source index of padded position i (unpadded coordinates, may lie outside [0, n)) under the padding rule of the IMAGE
 // operand: np.pad(input, pad_vec, mode=self.pad_mode) (resize_right/resize_right2d_numpy.py:208, :560) /

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "lerf_hip.h"
+#include "lerf_common.h"
 
 namespace lerf {
 namespace metrics {
@@ -143,7 +143,7 @@ int lerf_metric_y_sse_u8(const uint8_t* gt, int64_t gt_sy, const uint8_t* out, i
     const int h = H - 2 * shave, w = W - 2 * shave;
     if (hipMemsetAsync(result, 0, 2 * sizeof(double), st) != hipSuccess) return LERF_ELAUNCH;
     hipLaunchKernelGGL(y_sse_kernel, dim3(grid_for((int64_t)h * w)), dim3(256), 0, st, gt, gt_sy, out, out_sy, h, w, shave, result);
-    return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+    return lerf::launch_status();
 }
 
 int lerf_metric_ssim_y_u8(const uint8_t* gt, int64_t gt_sy, const uint8_t* out, int64_t out_sy, int H, int W,
@@ -163,7 +163,7 @@ int lerf_metric_ssim_y_u8(const uint8_t* gt, int64_t gt_sy, const uint8_t* out, 
     if (hipMemsetAsync(result, 0, 2 * sizeof(double), st) != hipSuccess) return LERF_ELAUNCH;
     hipLaunchKernelGGL(ssim_y_kernel, dim3((ow + TO - 1) / TO, (oh + TO - 1) / TO), dim3(256), 0, st, gt, gt_sy, out, out_sy, H, W,
                        win, result);
-    return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+    return lerf::launch_status();
 }
 
 int lerf_metric_masked_sse_u8(const uint8_t* sr, const uint8_t* hr, const uint8_t* mask, int64_t n, double* result, void* stream) {
@@ -171,7 +171,7 @@ int lerf_metric_masked_sse_u8(const uint8_t* sr, const uint8_t* hr, const uint8_
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(result, 0, 2 * sizeof(double), st) != hipSuccess) return LERF_ELAUNCH;
     hipLaunchKernelGGL(masked_sse_kernel, dim3(grid_for(n)), dim3(256), 0, st, sr, hr, mask, n, result);
-    return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+    return lerf::launch_status();
 }
 
 }  // extern "C"

@@ -341,7 +341,7 @@ int lerf_swf2lut_interp_f32(const float* weight, int oC, char mode, const float*
     if (oC == 1) hipLaunchKernelGGL(interp_fwd_kernel<1>, grid, block, 0, st, weight, img, n_planes, h, w, bd, pt, out);
     else if (oC == 3) hipLaunchKernelGGL(interp_fwd_kernel<3>, grid, block, 0, st, weight, img, n_planes, h, w, bd, pt, out);
     else return LERF_EUNSUPPORTED;
-    return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+    return lerf::launch_status();
 }
 
 int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const float* img, const float* grad_out, int n_planes,
@@ -369,7 +369,7 @@ int lerf_swf2lut_interp_bwd_f32(const float* weight, int oC, char mode, const fl
                            bands, gim_lds, pt, grad_weight, grad_img);
     else
         return LERF_EUNSUPPORTED;
-    return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+    return lerf::launch_status();
 }
 
 int lerf_resize_bwd_f32(const float* feat, const float* h0, const float* h1, const float* h2, int N, int H, int W,
@@ -390,7 +390,7 @@ int lerf_resize_bwd_f32(const float* feat, const float* h0, const float* h1, con
         hipLaunchKernelGGL(resize_bwd_kernel<LERF_KIND_LINEAR>, grid, block, 0, st, feat, h0, h1, h2, N, H, W, geo->S, geo->out_h,
                            geo->out_w, geo->left_r, geo->dis_r, geo->left_c, geo->dis_c, (float)max_sigma, grad_out, grad_feat,
                            grad_h0, nullptr, nullptr);
-    return hipGetLastError() == hipSuccess ? LERF_OK : LERF_ELAUNCH;
+    return lerf::launch_status();
 }
 
 }  // extern "C"
