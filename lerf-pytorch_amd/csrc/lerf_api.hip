@@ -285,6 +285,8 @@ int lerf_stages_packed_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W
     f.emit = packed; f.emit_sn = packed_sn; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
     if (!fused_stages_supported(f)) return LERF_EUNSUPPORTED;
     if (workspace && workspace_bytes < fused_workspace_bytes(f)) return LERF_EINVAL;
+    hipPointerAttribute_t pa;
+    f.host_input = hipPointerGetAttributes(&pa, img) == hipSuccess && pa.type == hipMemoryTypeHost;
     int rc = launch_stages_fused(f, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
@@ -409,6 +411,10 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
     f.max_sigma = (float)max_sigma; f.out = out; f.out_sn = out_sn; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
     if (fused_supported(f)) {
         if (workspace && !roi && workspace_bytes < fused_workspace_bytes(f)) return LERF_EINVAL;
+        // frames in pinned host memory (read over PCIe from inside the kernel, lerf-pytorch_amd/stream.py) are fetched once per
+        // tile into LDS; device frames let stage 1 read its neighbourhood pixels over the vector-memory path (L1 / L2 hits)
+        hipPointerAttribute_t pa;
+        f.host_input = hipPointerGetAttributes(&pa, img) == hipSuccess && pa.type == hipMemoryTypeHost;
         int rc = launch_sr_fused(f, as_stream(stream));
         return rc != LERF_OK ? rc : check_launch();
     }

@@ -159,6 +159,7 @@ struct Params {
     unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
     int tq_cap;                      // stage-3 tie queue entries in use (<= Dims::TQ_CAP; lerf_sr_geo_t.tie_queue_cap)
     int pad_mode;                    // LERF_PAD_* of the image operand of stage 3 at the true frame borders
+    int host_input;                  // the input frames live in (pinned) HOST memory: read every pixel once (LDS tile), never 39 times
 };
 
 #ifdef LERF_STAMPS
@@ -1709,7 +1710,7 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 
 #ifndef LERF_S1_LDS_PIXELS
     // interior tiles of the specialised kernel: pixel reads on the vector-memory path (byte_phase_vmem), no input tile in LDS
-    const bool vmem_pixels = !GEN && interior;
+    const bool vmem_pixels = !GEN && interior && !P.host_input;      // pinned host frames (stream.StreamingSR) cross PCIe uncached
 #else
     const bool vmem_pixels = false;
 #endif
@@ -1829,6 +1830,7 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     Params P{};
     P.tq_cap = a.tq_cap == 0 ? D::TQ_CAP : (a.tq_cap < 0 ? 0 : (a.tq_cap > D::TQ_CAP ? D::TQ_CAP : a.tq_cap));
     P.pad_mode = a.pad_mode;
+    P.host_input = a.host_input ? 1 : 0;
     P.img = a.img; P.in_sn = a.in_sn; P.out = a.out; P.out_sn = a.out_sn;
     P.H = a.H; P.W = a.W; P.oH = a.oH; P.oW = a.oW;
     const bool roi = a.roi_h > 0 && a.roi_w > 0;

@@ -72,6 +72,7 @@ struct FusedArgs {
     int roi_y, roi_x, roi_h, roi_w;       // lerf_sr_geo_t region of interest (roi_h = 0: whole frame)
     int tq_cap;                           // lerf_sr_geo_t.tie_queue_cap
     int pad_mode;                         // LERF_PAD_* of the image operand
+    bool host_input;                      // img is (pinned) host memory: the kernels must not re-read pixels from it
     const FusedItem* items; int n_items;  // ragged launch (general kernels): frames of different sizes; img/out/H/W/... above unused
 };
 bool fused_supported(const FusedArgs& a);          // some tile-fused kernel covers the configuration

@@ -6,7 +6,7 @@ import numpy as np, torch
 import lerf_pytorch_amd as L
 import bench
 eng = L.LerfEngine.shipped("lerf-g")
-img = bench.synth_frames("noise", 1, 3)[0]
+img = bench.synth_frames("noise", 1, 3, 1080, 1920)[0]
 for _ in range(3): eng.sr(img, 2)
 torch.cuda.synchronize(); t = time.perf_counter(); n = 20
 for _ in range(n): out = eng.sr(img, 2)
