@@ -154,6 +154,8 @@ struct Params {
     int n1, n2;                      // modes per stage (1..MAXM); the pack holds n1 stage-1 and 2 * n2 stage-2 LUTs
     int s2off[2 * MAXM][6];          // stage-2 LUT l: feat-tile byte offsets of pixels b,c,d for rotations par, par+2
     int s1off[MAXM][12];             // general kernels: stage-1 LUT m: input-tile byte offsets of b,c,d for rotations 0..3
+    int s1dyx[MAXM][12];             // the same pixels as (dy << 16) | (dx & 0xFFFF) in the frame (vector-memory pixel path)
+    int s2dyx[2 * MAXM][6];          // stage-2 LUT l, rotations par / par + 2
     uint32_t* emit; int64_t emit_sn;   // EMIT kernels: packed stage outputs, frame stride in dwords
     uint8_t* feat; int64_t feat_sn;    // two-launch path: stage-1 output [N][H][W][C] between s1_kernel and the FROM_FEAT kernel
     unsigned long long* stamps;      // diagnostic builds (-DLERF_STAMPS) only: [blocks][16] cycle stamps
@@ -658,6 +660,72 @@ __device__ __forceinline__ void byte_phase_vmem(const int8_t* lut, const uint8_t
     }
 }
 
+// The same for the general kernels: pattern offsets at run time.  dyx[3 i + k] = (dy << 16) | (dx & 0xFFFF) of pixel k + 1 of
+// rotation i (frame coordinates, wave-uniform kernel arguments); a pixel's address = origin + (position offset + dy * pitch
+// + dx * CH): one VALU add per pixel, like the LDS path of byte_lookups_rt.
+__device__ __forceinline__ uint32_t gl_pixel_hi_rt(uint32_t voff, uint64_t origin) {
+    uint32_t r;
+    asm volatile("global_load_ubyte_d16_hi %0, %1, %2" : "=v"(r) : "v"(voff), "s"(origin));
+    return r;
+}
+template <int NDST, int DPc, int NROT>
+__device__ __forceinline__ void byte_phase_vmem_rt(const int8_t* lut, const uint8_t* __restrict__ origin, int pitch, int16_t* acc16,
+                                                   uint8_t* dst8, int div, int bias, int tid, const int* __restrict__ dyx, bool first,
+                                                   bool last) {
+    constexpr int ROUNDS = (NDST + NT - 1) / NT, PAIRS = (ROUNDS + 1) / 2;
+    const uint32_t lut_a = lds_addr(lut);
+    // the VGPR offset of a global load is UNSIGNED: the base is moved up-left by the largest pattern reach (3 rows, 3 pixels;
+    // inside the frame for an interior region) so that every pixel offset is non-negative
+    const int reach = 3 * pitch + 3 * CH;
+    const uint64_t org = (uint64_t)reinterpret_cast<uintptr_t>(origin - reach);
+    int off[NROT * 3];
+#pragma unroll
+    for (int i = 0; i < NROT * 3; ++i) off[i] = (dyx[i] >> 16) * pitch + (int)(int16_t)(dyx[i] & 0xFFFF) * CH;
+    auto voff_of = [&](int p) {
+        p = p < NDST ? p : NDST - 1;
+        const int ry = p / DPc;
+        return (uint32_t)(ry * pitch + (p - ry * DPc) + reach);
+    };
+    auto issue = [&](PixSet& X, uint32_t voff) {
+        X.a = gl_pixel_hi_rt(voff, org);
+#pragma unroll
+        for (int i = 0; i < NROT; ++i) {
+            X.b[i] = gl_pixel_hi_rt(voff + (uint32_t)off[3 * i], org);
+            X.c[i] = gl_pixel_hi_rt(voff + (uint32_t)off[3 * i + 1], org);
+            X.d[i] = gl_pixel_hi_rt(voff + (uint32_t)off[3 * i + 2], org);
+        }
+    };
+    auto ready = [&](PixSet& X) {
+        if constexpr (NROT == 4)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(X.a), "+v"(X.b[0]), "+v"(X.c[0]), "+v"(X.d[0]), "+v"(X.b[1]), "+v"(X.c[1]), "+v"(X.d[1]), "+v"(X.b[2]),
+                           "+v"(X.c[2]), "+v"(X.d[2]), "+v"(X.b[3]), "+v"(X.c[3]), "+v"(X.d[3]));
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(X.a), "+v"(X.b[0]), "+v"(X.c[0]), "+v"(X.d[0]), "+v"(X.b[1]), "+v"(X.c[1]), "+v"(X.d[1]));
+    };
+    auto finish = [&](const PixSet& X, int p) {
+        if (NDST % NT != 0 && p >= NDST) return;
+        int v = byte_walks<NROT>(lut_a, X.a, X.b, X.c, X.d);
+        if (!first) v += (int)acc16[p];
+        if (last)
+            dst8[p] = (uint8_t)rne_div_clip255_fast(v + bias * div, div);
+        else
+            acc16[p] = (int16_t)v;
+    };
+    PixSet A, B;
+    issue(A, voff_of(tid));
+#pragma unroll 1
+    for (int k = 0; k < PAIRS; ++k) {
+        const int p = tid + 2 * k * NT;
+        ready(A);
+        issue(B, voff_of(p + NT));
+        finish(A, p);
+        ready(B);
+        if (k + 1 < PAIRS) issue(A, voff_of(p + 2 * NT));
+        if (2 * k + 1 < ROUNDS) finish(B, p + NT);
+    }
+}
+
 // General kernels: the same phase with the pattern offsets `o` (see byte_lookups_rt) and the phase kind at run time --
 // `first`: store the partial sums, otherwise add; `last`: finalise with (div, bias) into dst8.  All wave-uniform.
 template <int NROT>
@@ -1083,6 +1151,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             for (int l = 0; l < nl; ++l) {
                 const bool more = l + 1 < nl;
                 if (more) LERF_L2_LOAD(l + 1);
+                if (FROM_FEAT && interior)
+                    byte_phase_vmem_rt<D::NH, D::HP, 2>(lut, forg, fpitch, acc, hq8, dv, 127, tid, P.s2dyx[l], l == 0, !more);
+                else
                 byte_phase_rt<D::NH, D::HP, D::FP, 2>(lut, Bt, acc, hq8, hy0, hx0, fy0, fx0, Hc, Wc, dv, 127, tid, P.s2off[l], l == 0, !more);
                 __syncthreads();
                 if (more) {
@@ -1749,10 +1820,15 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         __syncthreads();
         if constexpr (GEN) {
             const int dv = kQ * P.n1;
+            // interior tiles: neighbourhood pixels over the vector-memory path (byte_phase_vmem_rt), like the specialised kernel
+            const bool vmg = interior && !P.host_input;
+            const uint8_t* vorg = img + ((int64_t)fy0 * W + fx0) * CH;
 #pragma unroll 1
             for (int m = 0; m < P.n1; ++m) {
                 const bool more = m + 1 < P.n1;
                 if (more) LERF_S1_LOAD(P.pack + (size_t)(m + 1) * LUT_PAD);
+                if (vmg) byte_phase_vmem_rt<D::NF, D::FP, 4>(lut, vorg, W * CH, acc, Ft, dv, 0, tid, P.s1dyx[m], m == 0, !more);
+                else
                 byte_phase_rt<D::NF, D::FP, D::IP, 4, true>(lut, Ct, acc, Ft, fy0, fx0, iy0, ix0, Hc, Wc, dv, 0, tid, P.s1off[m], m == 0, !more);
                 __syncthreads();
                 if (more) {
@@ -1851,6 +1927,16 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
             P.s2off[l][3 + i] = o1.o[i];
         }
     }
+    for (int m = 0; m < P.n1; ++m)
+        for (int r = 0; r < 4; ++r) {
+            const DyDx q = pattern_dydx(L->modes1[m], r);
+            for (int i = 0; i < 3; ++i) P.s1dyx[m][3 * r + i] = (q.dy[i] << 16) | (q.dx[i] & 0xFFFF);
+        }
+    for (int l = 0; l < 2 * P.n2; ++l)
+        for (int h = 0; h < 2; ++h) {
+            const DyDx q = pattern_dydx(L->modes2[l >> 1], (l & 1) + 2 * h);
+            for (int i = 0; i < 3; ++i) P.s2dyx[l][3 * h + i] = (q.dy[i] << 16) | (q.dx[i] & 0xFFFF);
+        }
     P.emit = (uint32_t*)a.emit; P.emit_sn = a.emit_sn;
     P.feat = nullptr; P.feat_sn = 0;
     auto set_s1off = [&](Params& Q, int pitch_kind) {          // stage-1 pattern offsets in the input tile of the kernel that runs it

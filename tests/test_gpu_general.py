@@ -57,6 +57,15 @@ CASES = [
     (3, "lerf-g", "sct", "sct", 4, 66, 20, (7.3, 5.0)),
     (3, "lerf-l", "sct", "sct", 2, 64, 64, (8.0, 1.0)),
     (1, "lerf-l", "tcs", "y", 2, 9, 200, 5),
+    # frames large enough for INTERIOR tiles (region + halo inside the frame): the vector-memory pixel path of the general
+    # kernels (byte_phase_vmem_rt), stage 1 and the LeRF-L stage 2
+    (3, "lerf-g", "sdy", "yct", 2, 210, 220, 2),
+    (3, "lerf-l", "dyc", "ts", 2, 215, 205, (1.5, 2.0)),
+    (1, "lerf-g", "sct", "sct", 2, 150, 600, 2),
+    (1, "lerf-l", "yd", "cs", 2, 140, 620, 3),
+    (4, "lerf-g", "tys", "dc", 2, 160, 170, 2),
+    (4, "lerf-l", "sct", "sct", 2, 141, 163, 2),
+    (3, "lerf-g", "sct", "sct", 2, 150, 215, 5),
 ]
 
 
