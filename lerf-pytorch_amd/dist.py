@@ -73,37 +73,62 @@ class StripBuffer:
         import torch
         self.plan = plan
         dtype = dtype if dtype is not None else torch.uint8
+        self.N, self.W, self.C = int(N), int(W), int(C)
         self.ext = torch.empty((N, plan.yhi - plan.ylo, W, C), dtype=dtype, device=device)
         self.own = self.ext[:, plan.need_top:plan.need_top + (plan.y1 - plan.y0)]
-        mk = lambda rows: torch.empty((N, rows, W, C), dtype=dtype, device=device)
-        self.send_up, self.send_dn = mk(plan.halo), mk(plan.halo)
-        self.recv_top, self.recv_bot = mk(plan.need_top), mk(plan.need_bot)
+        # one contiguous staging tensor per direction of travel, a segment per neighbour (RCCL / gloo point-to-point
+        # transfers need contiguous memory; a [N, halo] slice of `ext` is not)
+        seg = lambda rows: N * rows * W * C
+        h = plan.y1 - plan.y0
+        self.sends, self.recvs = [], []          # (peer, (y, x, h, w) in `ext`, byte offset, bytes)
+        so = ro = 0
+        if plan.rank > 0:
+            self.sends.append((plan.rank - 1, (plan.need_top, 0, plan.halo, W), so, seg(plan.halo)))
+            so += seg(plan.halo)
+            if plan.need_top:
+                self.recvs.append((plan.rank - 1, (0, 0, plan.need_top, W), ro, seg(plan.need_top)))
+                ro += seg(plan.need_top)
+        if plan.rank < plan.world - 1:
+            self.sends.append((plan.rank + 1, (plan.need_top + h - plan.halo, 0, plan.halo, W), so, seg(plan.halo)))
+            so += seg(plan.halo)
+            if plan.need_bot:
+                self.recvs.append((plan.rank + 1, (plan.need_top + h, 0, plan.need_bot, W), ro, seg(plan.need_bot)))
+                ro += seg(plan.need_bot)
+        self.send_buf = torch.empty(max(so, 1), dtype=dtype, device=device)
+        self.recv_buf = torch.empty(max(ro, 1), dtype=dtype, device=device)
+
+    def _copy(self, rects, staging, to_staging):
+        if not rects:
+            return
+        if self.ext.is_cuda:                     # ONE launch for all rectangles (lerf_rect_copy_u8)
+            from . import ops
+            ops.rect_copy(self.ext, staging, [(y, x, h, w, off) for _, (y, x, h, w), off, _ in rects], to_staging)
+            return
+        for _, (y, x, h, w), off, nb in rects:   # host tensors (gloo tests): plain slicing
+            seg = staging[off:off + nb].view(self.N, h, w, self.C)
+            if to_staging:
+                seg.copy_(self.ext[:, y:y + h, x:x + w])
+            else:
+                self.ext[:, y:y + h, x:x + w].copy_(seg)
 
     def exchange(self, group=None):
-        """Fill the halo rows of `ext` from the neighbouring ranks: one send/recv pair per neighbour inside one
-        batch_isend_irecv (= one ncclGroupStart/End on RCCL).  Returns `ext`.  World of 1: no-op."""
+        """Fill the halo rows of `ext` from the neighbouring ranks: one pack launch, one send/recv pair per neighbour
+        inside one batch_isend_irecv (= one ncclGroupStart/End on RCCL), one unpack launch.  Returns `ext`.  World of 1: no-op."""
         import torch.distributed as dist
         p = self.plan
         if p.world == 1:
             return self.ext
         if (p.H // p.world) < p.halo:
             raise ValueError("strips thinner than the halo (%d rows) are not supported" % p.halo)
-        h = p.y1 - p.y0
-        ops = []
-        if p.rank > 0:                              # exchange with the strip above
-            self.send_up.copy_(self.own[:, :p.halo])
-            ops.append(dist.P2POp(dist.isend, self.send_up, p.rank - 1, group))
-            ops.append(dist.P2POp(dist.irecv, self.recv_top, p.rank - 1, group))
-        if p.rank < p.world - 1:                    # exchange with the strip below
-            self.send_dn.copy_(self.own[:, h - p.halo:])
-            ops.append(dist.P2POp(dist.isend, self.send_dn, p.rank + 1, group))
-            ops.append(dist.P2POp(dist.irecv, self.recv_bot, p.rank + 1, group))
-        for w in dist.batch_isend_irecv(ops):
+        self._copy(self.sends, self.send_buf, True)
+        ops_ = []
+        for peer, _, off, nb in self.sends:
+            ops_.append(dist.P2POp(dist.isend, self.send_buf[off:off + nb], peer, group))
+        for peer, _, off, nb in self.recvs:
+            ops_.append(dist.P2POp(dist.irecv, self.recv_buf[off:off + nb], peer, group))
+        for w in dist.batch_isend_irecv(ops_):
             w.wait()
-        if p.need_top:
-            self.ext[:, :p.need_top].copy_(self.recv_top)
-        if p.need_bot:
-            self.ext[:, p.need_top + h:].copy_(self.recv_bot)
+        self._copy(self.recvs, self.recv_buf, False)
         return self.ext
 
 

@@ -270,3 +270,27 @@ def test_abi4_argument_checks(torch):
     g2.roi_y, g2.roi_x, g2.roi_h, g2.roi_w = 10, 10, 70, 70  # outside the frame
     assert lib.lerf_sr_fused_u8(x.data_ptr(), x.stride(0), 2, 70, 70, 3, eng.luts.ref(), C.byref(g2), 0, 10.0, out.data_ptr(),
                                 out.stride(0), ws.data_ptr(), need, _lib.current_stream()) == -1
+
+
+def test_halo_buffers_pack_and_unpack_on_the_device(torch, oracle):
+    """the pack / unpack launches of StripBuffer and BlockBuffer (lerf_rect_copy_u8) without a process group: what the ranks
+    send is the right rectangles of their own pixels, what they receive lands in the right halo rectangles"""
+    from lerf_pytorch_amd import dist as ldist
+    H, W, N, C = 200, 260, 2, 3
+    lr, _, _, _ = oracle.sr_axis_tables(H, 2 * H, 2.0, 2)
+    lc, _, _, _ = oracle.sr_axis_tables(W, 2 * W, 2.0, 2)
+    bufs = [ldist.StripBuffer(ldist.StripPlan(H, 3, 1, 2, lr), N, W, C, torch.uint8, torch.device("cuda")),
+            ldist.BlockBuffer(ldist.BlockPlan(H, W, (2, 4), 5, 2, lr, lc), N, C, torch.uint8, torch.device("cuda"), lr, lc)]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for buf in bufs:
+        assert len(buf.sends) == len(buf.recvs) and len(buf.sends) in (2, 8)
+        buf.ext.copy_(torch.randint(0, 256, tuple(buf.ext.shape), dtype=torch.uint8, generator=g))
+        buf._copy(buf.sends, buf.send_buf, True)
+        for _, (y, x, h, w), off, nb in buf.sends:
+            assert torch.equal(buf.send_buf[off:off + nb].view(N, h, w, C), buf.ext[:, y:y + h, x:x + w])
+        buf.recv_buf.copy_(torch.randint(0, 256, tuple(buf.recv_buf.shape), dtype=torch.uint8, generator=g))
+        before = buf.own.clone()
+        buf._copy(buf.recvs, buf.recv_buf, False)
+        for _, (y, x, h, w), off, nb in buf.recvs:
+            assert torch.equal(buf.ext[:, y:y + h, x:x + w], buf.recv_buf[off:off + nb].view(N, h, w, C))
+        assert torch.equal(buf.own, before)                    # the halo writes never touch the owned pixels
