@@ -123,6 +123,12 @@ struct Dims {
     static constexpr int OFF_TQ = GEO_EARLY ? OFF_D + up16(NH * 4) : END3;
     static_assert(OFF_TQ + TQ_CAP * 4 <= OFF_X + PIECE_LDS, "tie queue fits under the piece");
     static_assert(GEO_EARLY || END3 <= OFF_X + PIECE_LDS, "late geometry fits under the piece");
+    // stage 3, block tasks (integer x2 tiles: 2 x 2 outputs share their taps): the tile's output bytes are assembled in LDS
+    // (behind the tie queue, over the dead LUT piece) and leave as whole 16-byte chunks; the rows sit at the phase of their
+    // global address modulo 16
+    static constexpr int OUT_ROWS = 2 * TH + 4, OUT_PITCH = up16(2 * TW * CH + 16 + 15);
+    static constexpr int OFF_OUT = up16(OFF_TQ + TQ_CAP * 4);
+    static constexpr bool OUT_FITS = OFF_OUT + OUT_ROWS * OUT_PITCH <= OFF_X + PIECE_LDS;
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int LDS_BYTES = cmax(END1, cmax(END2, GEO_EARLY ? END3 : 0)) + 512;  // + small control block
     static constexpr int OFF_CTL = LDS_BYTES - 512;
@@ -273,6 +279,12 @@ __device__ __forceinline__ unsigned key_of(uint32_t r, unsigned stride) {
     return k;
 }
 __device__ __forceinline__ unsigned msb_of(uint32_t r) { return r >> 20; }
+
+// acc + w.lo16 * d.hi16: the upper half of a packed stage-2 entry multiplied in place (op_sel picks the high half of src1)
+__device__ __forceinline__ uint32_t mad_hi16(uint32_t w, uint32_t d, uint32_t acc) {
+    asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[0,1,0,0]" : "+v"(acc) : "v"(w), "v"(d));
+    return acc;
+}
 
 template <int STRIDE_SCALE>
 struct Walk {
@@ -968,7 +980,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     LERF_STAMP_RT(13);
     LERF_STAMP(0);
 #ifdef LERF_STAMPS
-    if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; }
+    if (tid == 0) { P.stamps[(size_t)blockIdx.x * 16 + 8] = 0; P.stamps[(size_t)blockIdx.x * 16 + 9] = 0; P.stamps[(size_t)blockIdx.x * 16 + 15] = 0; }
 #endif
     if (!FROM_FEAT) {
     // ---- input tile (load_input_tile), the geometry search riding behind its loads.  (The vector-memory pixel path of
@@ -1321,7 +1333,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         }
         __syncthreads();
         // slots -> registers.  Per slot: the feat-tile address of its centre (16 bits, two slots per VGPR) and three
-        // 16-bit accumulators (accA: e0 | e2 << 16; accB: e1).  Padding lanes of a partly filled wave repeat the wave's
+        // accumulators (accA: e0 | e2 << 16 in 16-bit fields; accB: e2 + 256 e1).  Padding lanes of a partly filled wave repeat the wave's
         // first real position (same bin, same LDS words: broadcast reads) into accumulators nobody reads, so the lookup
         // loop needs no per-lane test; `vmask` remembers which slots are real, and the position id comes back out of the
         // address when the sums are finalised (listed positions are inside the frame: the address is not clamped).
@@ -1438,25 +1450,40 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                     const Walk<4> W1 = simplex_walk<4>(ka, basea, rb1, rc1, rd1, st_b, st_c, st_d);
                     // stage C: ten dword gathers in flight together
                     uint32_t d0[5], d1[5];
+#if defined(LERF_DBG_GATHER) && LERF_DBG_GATHER == 1      // timing experiment only: conflict-free gathers (wrong results)
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) d0[n] = lds_ld32(qbase + (uint32_t)lane * 4u + (uint32_t)n * 256u + ((uint32_t)W0.a(n) >> 30));
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) d1[n] = lds_ld32(qbase + (uint32_t)lane * 4u + (uint32_t)n * 256u + 2048u + ((uint32_t)W1.a(n) >> 30));
+#elif defined(LERF_DBG_GATHER) && LERF_DBG_GATHER == 2    // timing experiment only: no gathers at all
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) d0[n] = W0.a(n);
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) d1[n] = W1.a(n);
+#else
 #pragma unroll
                     for (int n = 0; n < 5; ++n) d0[n] = W0.ld32(n);
 #pragma unroll
                     for (int n = 0; n < 5; ++n) d1[n] = W1.ld32(n);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
-                    // stage D: two 24-bit MADs per corner: the entry is e0 | 0 << 8 | e2 << 16 | e1 << 24, and a 24-bit
-                    // multiply reads bits 0..23 only, so the (e0, e2) pair needs no mask; e1 is shifted down
+                    // stage D: two multiply-adds per corner.  The entry is e0 | 0 << 8 | e2 << 16 | e1 << 24: a 24-bit multiply reads
+                    // bits 0..23 only, so the (e0, e2) pair needs no mask; the second one multiplies the entry's HIGH HALF
+                    // (e2 + 256 e1, v_mad_u32_u16 with op_sel) without a shift -- accB = sum w e2 + 256 sum w e1, and the e2
+                    // sum is already in accA's upper field, so the finalisation takes it out again (round 3: 3 -> 2
+                    // instructions per corner, 87 -> 77 per slot)
                     const unsigned w0[5] = {(unsigned)kQ - W0.f0, W0.f0 - W0.f1, W0.f1 - W0.f2, W0.f2 - W0.f3, W0.f3};
                     const unsigned w1[5] = {(unsigned)kQ - W1.f0, W1.f0 - W1.f1, W1.f1 - W1.f2, W1.f2 - W1.f3, W1.f3};
                     uint32_t a = accA[k], bb = accB[k];
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
                         a += __umul24(w0[n], d0[n]);
-                        bb += __umul24(w0[n], d0[n] >> 24);
+                        bb = mad_hi16(w0[n], d0[n], bb);
                     }
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
                         a += __umul24(w1[n], d1[n]);
-                        bb += __umul24(w1[n], d1[n] >> 24);
+                        bb = mad_hi16(w1[n], d1[n], bb);
                     }
                     accA[k] = a;
                     accB[k] = bb;
@@ -1475,7 +1502,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 const int div2 = GEN ? kQ * 4 * P.n2 : kQ * 12;     // general kernels: 4 rotations x n2 patterns (same bias algebra)
                 int n0 = (int)(accA[k] & 0xFFFFu) - div2;
                 int n2 = (int)(accA[k] >> 16) - div2;
-                int n1 = (int)accB[k] - div2;
+                int n1 = (int)((accB[k] - (accA[k] >> 16)) >> 8) - div2;      // accB = (e2 sum) + 256 (e1 sum), see the slot's MACs
                 uint32_t h0 = (uint32_t)rne_div_clip255_fast(n0, div2);
                 uint32_t h1 = (uint32_t)rne_div_clip255_fast(n1, div2);
                 uint32_t h2 = (uint32_t)rne_div_clip255_fast(n2, div2);
@@ -1565,6 +1592,15 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 ctl[22] = uniform ? g0 : 0;
                 ctl[23] = 0;
             }
+        } else if (wave == 1) {
+            // the columns: do columns 2h and 2h + 1 share their taps for every h? (block tasks below)
+            bool ok = (ncol & 1) == 0;
+            for (int base = 0; base < ncol; base += 128) {
+                const int jl = base + 2 * lane;
+                if (jl + 1 < ncol && g_lc[jl + 1] != g_lc[jl]) ok = false;
+            }
+            const bool pairs = __ballot(!ok) == 0ull;
+            if (lane == 0) ctl[24] = pairs ? 1 : 0;
         }
         __syncthreads();
         const int ngrp = ctl[21];
@@ -1706,17 +1742,195 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             }
         }
         };
+        // ---- block tasks: tiles whose output rows AND columns come in pairs that share their taps (integer x2, away from
+        //      the frame's top and left).  One task = the 2 x 2 outputs of a (row pair, column pair), all CH channels: the
+        //      four tap dwords of a channel are loaded and converted once for four outputs instead of once for two, the
+        //      column-only terms serve both rows and the row-only products both columns (43 instead of 63 VALU instructions
+        //      per output), and a tile is exactly 4 tasks per thread.  The bytes are assembled in an LDS image of the tile's
+        //      output block (ties are patched there) and leave as whole 16-byte chunks.  Same arithmetic, operation for
+        //      operation, as run_tasks: the outputs are bit-identical.
+        constexpr bool BLK = KIND == LERF_KIND_GAUSS && S == 2 && D::OUT_FITS;
+        uint8_t* outt = smem + D::OFF_OUT;
+        const int ophase = (int)(reinterpret_cast<uintptr_t>(seg0) & 15u);
+#ifndef LERF_NO_BLOCK_TASKS
+        const bool blk = BLK && __builtin_amdgcn_readfirstlane((gsame == 2 && ctl[24] != 0 && (rowpitch & 15) == 0 && nrow <= D::OUT_ROWS &&
+                                                                ophase + ncolc <= D::OUT_PITCH) ? 1 : 0) != 0;
+#else
+        const bool blk = false;
+#endif
+        auto run_blocks = [&]() {
+            if constexpr (BLK) {
+            constexpr int SS2 = 4;
+            const int ncg = ncol >> 1;
+            const int nblk = (nrow >> 1) * ncg;
+            const unsigned magicc = (unsigned)((0x100000000ull + (unsigned)ncg - 1) / (unsigned)(ncg > 0 ? ncg : 1));
+            for (int t = tid; t < nblk; t += NT) {
+                const int g = (int)__umulhi((unsigned)t, magicc);
+                const int h = t - g * ncg;
+                const int il0 = 2 * g, jl0 = 2 * h;
+                const int lr = g_lr[il0], lc = g_lc[jl0];
+                const float4 dxv = *reinterpret_cast<const float4*>(g_dr + il0 * 2);     // [row r][row tap b]
+                const float4 dyv = *reinterpret_cast<const float4*>(g_dc + jl0 * 2);     // [column q][column tap a]
+                const float dx[2][2] = {{dxv.x, dxv.y}, {dxv.z, dxv.w}};
+                const float dy[2][2] = {{dyv.x, dyv.y}, {dyv.z, dyv.w}};
+                const uint32_t* dp = Dt + lr * D::HP + lc * CH;
+                uint8_t* ob = outt + il0 * D::OUT_PITCH + ophase + jl0 * CH;
+                float dist[4 * CH];                                  // [c][r][q]
+                float dmax = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    float v[SS2], k1[SS2], ty2[2][SS2], p0[2][SS2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const uint32_t d = dp[b * D::HP + a * CH + c];
+                            v[a * 2 + b] = (float)(d >> 24);
+                            k1[a * 2 + b] = (float)((d >> 8) & 0xFFu);
+                            const float m2rho = s3::gauss_m2rho_u8((float)(d & 0xFFu));
+                            const float k2 = (float)((d >> 16) & 0xFFu);
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const float tyv = s3::gauss_t_u8(k2, dy[q][a]);
+                                p0[q][a * 2 + b] = m2rho * tyv;
+                                ty2[q][a * 2 + b] = tyv * tyv;
+                            }
+                        }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        float tx[SS2];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) tx[a * 2 + b] = s3::gauss_t_u8(k1[a * 2 + b], dx[r][b]);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            float e[SS2];
+#pragma unroll
+                            for (int k = 0; k < SS2; ++k) e[k] = s3::gauss_form_cols(tx[k], ty2[q][k], p0[q][k]);
+                            const float xf = s3::finish<true, SS2, true, true, true>(e, v);
+                            const float rr = __builtin_rintf(xf);
+                            const float ds = xf - rr;
+                            dist[(c * 2 + r) * 2 + q] = ds;
+                            dmax = __builtin_fmaxf(dmax, __builtin_fabsf(ds));
+                            ob[r * D::OUT_PITCH + q * CH + c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(rr, 0u, 0u);
+                        }
+                    }
+                }
+                if (dmax > 0.5f - s3::kTieEps && F.dis_r64 != nullptr) {
+                    unsigned tiemask = 0;
+#pragma unroll
+                    for (int q = 0; q < 4 * CH; ++q)
+                        if (__builtin_fabsf(dist[q]) > 0.5f - s3::kTieEps) tiemask |= 1u << q;
+#pragma unroll 1
+                    for (int q = 0; q < 4 * CH; ++q) {
+                        if (!((tiemask >> q) & 1u)) continue;
+                        const int c = q >> 2, r = (q >> 1) & 1, qq = q & 1;
+                        const int il = il0 + r, xc = (jl0 + qq) * CH + c;
+                        const int slot = atomicAdd(tq_count, 1);
+                        if (slot < P.tq_cap) {
+                            tq[slot] = ((uint32_t)il << 16) | (uint32_t)xc;
+                            continue;
+                        }
+                        // queue full: evaluated on the spot (float64, the reference's own dtype chain), patched behind the store above
+                        uint32_t dd[SS2];
+                        double dx64[2], dy64[2];
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il) * 2 + b];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl0 + qq) * 2 + a];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) dd[a * 2 + b] = dp[b * D::HP + a * CH + c];
+                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<true, 2>(dd, dx64, dy64, P.max_sigma));
+                    }
+                }
+            }
+            }
+        };
+        // the LDS image of the output block -> the frame: whole 16-byte chunks with streaming stores, the ragged ends of a
+        // row (the neighbouring tiles' bytes share those chunks) dword by dword and byte by byte
+        auto flush_blocks = [&]() {
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            const int nchunk = (ophase + ncolc + 15) >> 4;
+            const unsigned magicf = (unsigned)((0x100000000ull + (unsigned)nchunk - 1) / (unsigned)nchunk);
+            uint8_t* gbase = seg0 - ophase;
+            const int total = nrow * nchunk;
+            const int full_lo = ophase == 0 ? 0 : 1, full_hi = ((ophase + ncolc) & 15) == 0 ? nchunk : nchunk - 1;   // whole chunks of a row
+            for (int i = tid; i < total; i += NT) {
+                const int row = (int)__umulhi((unsigned)i, magicf);
+                const int ch = i - row * nchunk;
+                if (ch >= full_lo && ch < full_hi) {
+                    const v4u x = *reinterpret_cast<const v4u*>(outt + row * D::OUT_PITCH + ch * 16);
+                    __builtin_nontemporal_store(x, reinterpret_cast<v4u*>(gbase + row * rowpitch + ch * 16));
+                }
+            }
+            // the ragged chunks, two per row at most, in a loop of their own (a few waves take it once, instead of every
+            // wave dragging the byte path through every round of the loop above)
+            for (int i = tid; i < 2 * nrow; i += NT) {
+                const int row = i >> 1;
+                const int ch = (i & 1) ? nchunk - 1 : 0;
+                if (ch >= full_lo && ch < full_hi) continue;             // that end of the row is a whole chunk
+                if ((i & 1) && nchunk == 1) continue;                    // a one-chunk row: its first-chunk lane has it
+                const uint8_t* src = outt + row * D::OUT_PITCH + ch * 16;
+                uint8_t* dst = gbase + row * rowpitch + ch * 16;
+                const int lo = max(ophase - ch * 16, 0), hi = min(ophase + ncolc - ch * 16, 16);
+                const v4u x = *reinterpret_cast<const v4u*>(src);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w = x[k];
+                    if (lo <= 4 * k && hi >= 4 * k + 4) {
+                        __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(dst + 4 * k));
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (4 * k + u >= lo && 4 * k + u < hi) dst[4 * k + u] = (uint8_t)(w >> (8 * u));
+                    }
+                }
+            }
+        };
         // the constant-size variants cover the integer scale factors (x2 -> 2 rows per group, ...); anything else reads
         // the group size per task
         constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
         // (max_sigma <= s3::kNoShiftMaxSigma here: the host sends larger values to the float64 direct kernel, lerf_fused.hip)
-        if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});
+        if (blk) run_blocks();
+        else if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});
         else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{});
         else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{});
         else run_tasks(std::integral_constant<int, 0>{});
         // ---- tie pass: the queued outputs in float64, one per lane; each patches its byte behind the task loop's
         //      dword stores (drained and fenced by the barrier)
-        if (F.dis_r64 != nullptr) {
+        if (blk) {
+            // block tasks: the queued outputs are patched in the LDS image, which then leaves in one piece
+            __syncthreads();
+            LERF_STAMP(15);
+            if (F.dis_r64 != nullptr) {
+                const int nq = min(*tq_count, P.tq_cap);
+                if (nq > 0) {
+                    for (int i = tid; i < nq; i += NT) {
+                        const uint32_t e = tq[i];
+                        const int il = (int)(e >> 16), xc = (int)(e & 0xFFFFu);
+                        const int jl = xc / CH;
+                        const int c = xc - jl * CH;
+                        const int lr = g_lr[il], lc = g_lc[jl];
+                        uint32_t dd[SS];
+                        double dx64[S], dy64[S];
+#pragma unroll
+                        for (int b = 0; b < S; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il) * S + b];
+#pragma unroll
+                        for (int a = 0; a < S; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl) * S + a];
+#pragma unroll
+                        for (int a = 0; a < S; ++a)
+#pragma unroll
+                            for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
+                    }
+                    __syncthreads();
+                }
+            }
+            flush_blocks();
+        } else if (F.dis_r64 != nullptr) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int nq = min(*tq_count, P.tq_cap);

@@ -280,7 +280,7 @@ def test_halo_buffers_pack_and_unpack_on_the_device(torch, oracle):
     lr, _, _, _ = oracle.sr_axis_tables(H, 2 * H, 2.0, 2)
     lc, _, _, _ = oracle.sr_axis_tables(W, 2 * W, 2.0, 2)
     bufs = [ldist.StripBuffer(ldist.StripPlan(H, 3, 1, 2, lr), N, W, C, torch.uint8, torch.device("cuda")),
-            ldist.BlockBuffer(ldist.BlockPlan(H, W, (2, 4), 5, 2, lr, lc), N, C, torch.uint8, torch.device("cuda"), lr, lc)]
+            ldist.BlockBuffer(ldist.BlockPlan(H, W, (3, 3), 4, 2, lr, lc), N, C, torch.uint8, torch.device("cuda"), lr, lc)]   # the centre block: 8 neighbours
     g = torch.Generator(device="cpu").manual_seed(3)
     for buf in bufs:
         assert len(buf.sends) == len(buf.recvs) and len(buf.sends) in (2, 8)

@@ -50,6 +50,11 @@ def main():
         d["s2 total"] = st[:, 10] - st[:, 7]
         d["finalise+geo"] = st[:, 11] - st[:, 10]
         d["stage3"] = st[:, 12] - st[:, 11]
+        blkt = st[:, 15] > 0                                # tiles that took the block tasks of stage 3
+        if blkt.any():
+            d["s3 tasks (block tiles)"] = np.where(blkt, st[:, 15] - st[:, 11], np.nan)
+            d["s3 ties+flush (block tiles)"] = np.where(blkt, st[:, 12] - st[:, 15], np.nan)
+            d["stage3 (other tiles)"] = np.where(~blkt, st[:, 12] - st[:, 11], np.nan)
         d["TOTAL"] = st[:, 12] - st[:, 0]
         rt = st[:, 14] - st[:, 13]                       # s_memrealtime ticks (100 MHz) over the same interval as TOTAL
         mhz = d["TOTAL"] / np.maximum(rt, 1) * 100.0
@@ -59,7 +64,7 @@ def main():
               % (kind, tiles, mhz.mean(), mhz.min(), mhz.max(), wall))
         tot = d["TOTAL"].mean()
         for k, v in d.items():
-            print("  %-14s %10.0f  %5.1f%%" % (k, v.mean(), 100 * v.mean() / tot))
+            print("  %-28s %10.0f  %5.1f%%" % (k, np.nanmean(v), 100 * np.nanmean(v) / tot))
 
 
 if __name__ == "__main__":
