@@ -776,11 +776,9 @@ warp_packed_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, int H
 // instructions per output value, same bytes (the tie guard re-evaluates anything within 1.5e-4 of a rounding tie in float64).
 template <typename TO, int KIND, bool PROD = false>
 __global__ void __launch_bounds__(256)
-warp_packed_px_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, int H, int W, WarpGeo g, float max_sigma,
-                      TO* __restrict__ out, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn) {
+warp_packed_px_kernel(const uint32_t* __restrict__ packed0, int64_t packed_sn, int n_frames, int H, int W, WarpGeo g, float max_sigma,
+                      TO* __restrict__ out0, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn) {
     constexpr int S = 2, C = 3;
-    packed += (int64_t)blockIdx.z * packed_sn;             // frame of the batch (one homography for all)
-    out += (int64_t)blockIdx.z * out_sn;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= g.oW) return;
@@ -824,6 +822,12 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, in
     const float ms255 = max_sigma * (1.0f / 255.0f);
 #pragma unroll
     for (int b = 0; b < S; ++b) { dxs[b] = dx[b] * gsc; dys[b] = dy[b] * gsc; }
+    // the frames of the batch share the homography: the float64 projection and the tap geometry above are paid once per
+    // output pixel, not once per frame (round 3: a fifth of this kernel's instructions went into repeating them)
+#pragma unroll 1
+    for (int fr = 0; fr < n_frames; ++fr) {
+    const uint32_t* __restrict__ packed = packed0 + (int64_t)fr * packed_sn;
+    TO* __restrict__ out = out0 + (int64_t)fr * out_sn;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         uint32_t d[S * S];
@@ -892,6 +896,7 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, in
         }
         Storer<TO>::put(dst, res);
     }
+    }
 }
 
 int launch_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, int W, int C, const WarpGeo& geo, int kind,
@@ -900,9 +905,9 @@ int launch_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, 
     if (n < 1 || n > 65535 || geo.oH > 65535) return LERF_EUNSUPPORTED;
     if (C == 3 && geo.S == 2 && (kind == LERF_KIND_GAUSS || kind == LERF_KIND_LINEAR) &&
         (out_dtype == LERF_U8 || out_dtype == LERF_F32)) {
-        dim3 blockp(256), gridp((geo.oW + 255) / 256, geo.oH, n);
+        dim3 blockp(256), gridp((geo.oW + 255) / 256, geo.oH, 1);
 #define LERF_WPX(TO, KIND, PROD)                                                                                      \
-    hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND, PROD>), gridp, blockp, 0, st, packed, packed_sn, H, W, geo, max_sigma, (TO*)out, \
+    hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND, PROD>), gridp, blockp, 0, st, packed, packed_sn, n, H, W, geo, max_sigma, (TO*)out, \
                        oy, ox, oc, out_sn)
         const bool prod = out_dtype == LERF_U8 && max_sigma <= s3::kNoShiftMaxSigma;     // production arithmetic + tie guard
         if (kind == LERF_KIND_GAUSS) {
