@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B/C... of several builds of the library on the same GPU box: tools/abn.sh "<bench args>" lib1.so lib2.so ...; three rounds
+args=$1; shift
+for i in 1 2 3; do
+  for l in "$@"; do
+    v=$(LERF_HIP_LIB=$PWD/$l python3 bench.py --steps 30 --no-cpu-baseline --no-other-input --sustained 0 $args 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
+    echo "$l $v"
+  done
+done
