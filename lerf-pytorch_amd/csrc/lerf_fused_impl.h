@@ -1769,53 +1769,65 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 const int h = t - g * ncg;
                 const int il0 = 2 * g, jl0 = 2 * h;
                 const int lr = g_lr[il0], lc = g_lc[jl0];
-                const float4 dxv = *reinterpret_cast<const float4*>(g_dr + il0 * 2);     // [row r][row tap b]
-                const float4 dyv = *reinterpret_cast<const float4*>(g_dc + jl0 * 2);     // [column q][column tap a]
-                const float dx[2][2] = {{dxv.x, dxv.y}, {dxv.z, dxv.w}};
-                const float dy[2][2] = {{dyv.x, dyv.y}, {dyv.z, dyv.w}};
+                // distances as PAIRS: DX[b] = (row 0, row 1) of row tap b, DY[a] = (column 0, column 1) of column tap a
+                s3::f2 DX[2], DY[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) { DX[b].x = g_dr[il0 * 2 + b]; DX[b].y = g_dr[il0 * 2 + 2 + b]; }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) { DY[a].x = g_dc[jl0 * 2 + a]; DY[a].y = g_dc[jl0 * 2 + 2 + a]; }
                 const uint32_t* dp = Dt + lr * D::HP + lc * CH;
                 uint8_t* ob = outt + il0 * D::OUT_PITCH + ophase + jl0 * CH;
                 float dist[4 * CH];                                  // [c][r][q]
                 float dmax = 0.0f;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    float v[SS2], k1[SS2], ty2[2][SS2], p0[2][SS2];
+                    // packed over the two COLUMNS q of the block (lane x = column 0, lane y = column 1); the scalars of a tap
+                    // (its value, m2rho, k1, k2) sit in the low halves of register pairs and are read through op_sel
+                    s3::f2 NUM[2], DEN[2];                           // [row r]
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
                             const uint32_t d = dp[b * D::HP + a * CH + c];
-                            v[a * 2 + b] = (float)(d >> 24);
-                            k1[a * 2 + b] = (float)((d >> 8) & 0xFFu);
-                            const float m2rho = s3::gauss_m2rho_u8((float)(d & 0xFFu));
-                            const float k2 = (float)((d >> 16) & 0xFFu);
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                const float tyv = s3::gauss_t_u8(k2, dy[q][a]);
-                                p0[q][a * 2 + b] = m2rho * tyv;
-                                ty2[q][a * 2 + b] = tyv * tyv;
+                            s3::f2 V, K1, K2, M2;
+                            V.x = V.y = (float)(d >> 24);                          // (both lanes: the weights' consumers below are plain vector code)
+                            K1.x = (float)((d >> 8) & 0xFFu);
+                            M2.x = s3::gauss_m2rho_u8((float)(d & 0xFFu));
+                            K2.x = (float)((d >> 16) & 0xFFu);
+                            const s3::f2 TYV = s3::pk_mul_blo(DY[a], K2);          // k2 * dy[q][a]
+                            const s3::f2 P0 = s3::pk_mul_blo(TYV, M2);             // m2rho * tyv
+                            const s3::f2 TY2 = s3::pk_mul(TYV, TYV);
+                            const s3::f2 TX = s3::pk_mul_blo(DX[b], K1);           // lanes = ROWS here: k1 * dx[r][b]
+                            // e[r][q] = fma(tx_r, p0_q, fma(tx_r, tx_r, ty2_q)), w = exp2(-e), num += w v, den += w
+                            const s3::f2 E0 = s3::pk_fma_ab<false>(TX, P0, s3::pk_fma_aa<false>(TX, TY2));
+                            const s3::f2 E1 = s3::pk_fma_ab<true>(TX, P0, s3::pk_fma_aa<true>(TX, TY2));
+                            s3::f2 W0, W1;
+                            W0.x = __builtin_amdgcn_exp2f(-E0.x); W0.y = __builtin_amdgcn_exp2f(-E0.y);
+                            W1.x = __builtin_amdgcn_exp2f(-E1.x); W1.y = __builtin_amdgcn_exp2f(-E1.y);
+                            // The consumers of the v_exp results are COMPILER-generated packed operations, not inline assembly: gfx950
+                            // needs a wait state between a transcendental instruction and a VALU read of its result, which the
+                            // compiler inserts for its own instructions only (an inline-asm consumer right behind v_exp read the stale
+                            // register: nondeterministic bytes).
+                            if (a == 0 && b == 0) {
+                                DEN[0] = W0; DEN[1] = W1;
+                                NUM[0] = W0 * V; NUM[1] = W1 * V;
+                            } else {
+                                NUM[0] = __builtin_elementwise_fma(W0, V, NUM[0]); NUM[1] = __builtin_elementwise_fma(W1, V, NUM[1]);
+                                DEN[0] = DEN[0] + W0; DEN[1] = DEN[1] + W1;
                             }
                         }
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        float tx[SS2];
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int b = 0; b < 2; ++b) tx[a * 2 + b] = s3::gauss_t_u8(k1[a * 2 + b], dx[r][b]);
+                    for (int r = 0; r < 2; ++r)
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
-                            float e[SS2];
-#pragma unroll
-                            for (int k = 0; k < SS2; ++k) e[k] = s3::gauss_form_cols(tx[k], ty2[q][k], p0[q][k]);
-                            const float xf = s3::finish<true, SS2, true, true, true>(e, v);
+                            const float den = q ? DEN[r].y : DEN[r].x, num = q ? NUM[r].y : NUM[r].x;
+                            const float xf = s3::finish_div(num, den);
                             const float rr = __builtin_rintf(xf);
                             const float ds = xf - rr;
                             dist[(c * 2 + r) * 2 + q] = ds;
                             dmax = __builtin_fmaxf(dmax, __builtin_fabsf(ds));
                             ob[r * D::OUT_PITCH + q * CH + c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(rr, 0u, 0u);
                         }
-                    }
                 }
                 if (dmax > 0.5f - s3::kTieEps && F.dis_r64 != nullptr) {
                     unsigned tiemask = 0;

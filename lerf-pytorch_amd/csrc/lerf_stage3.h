@@ -113,6 +113,14 @@ __device__ __forceinline__ float lin_factor(float alpha, float x, int cls) {
 // (launch_resize, fused_supported), whose arithmetic is the reference's own.
 constexpr float kNoShiftMaxSigma = 13.0f;
 
+// num / den of the uint8 paths: reciprocal + one Newton step instead of the IEEE division sequence (finish<.., FAST>)
+__device__ __forceinline__ float finish_div(float num, float den) {
+#pragma clang fp contract(off)
+    float r = __builtin_amdgcn_rcpf(den);
+    r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+    return num * r;
+}
+
 // normalised weighted sum over N taps; e[] are quadratic forms (GAUSS) or weights
 template <bool GAUSS, int N, bool FAST = false, bool SCALED = false, bool NOSHIFT = false>
 __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]) {
@@ -160,6 +168,51 @@ __device__ __forceinline__ float finish(const float (&e)[N], const float (&v)[N]
         return num * r;
     }
     return num / den;
+}
+
+// ---------------------------------------------------------------------------
+// Packed float32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per instruction, the same
+// results lane for lane as the scalar forms).  In the kernels' mixed instruction streams every VALU instruction costs one
+// 4-cycle pass (profiles/r03_issue_rates.txt), a packed one ~1.4 passes for two operations.  A scalar that both lanes use is
+// read through op_sel from the LOW or HIGH half of a register pair -- no copy into a pair of its own.
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+// (a.x * b.x, a.y * b.x)
+__device__ __forceinline__ f2 pk_mul_blo(f2 a, f2 b) {
+    f2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// (a.L * a.L + c.x, a.L * a.L + c.y) and (a.L * b.x + c.x, a.L * b.y + c.y) with L = the low (HI = false) or high half of a
+template <bool HI>
+__device__ __forceinline__ f2 pk_fma_aa(f2 a, f2 c) {
+    f2 d;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    return d;
+}
+template <bool HI>
+__device__ __forceinline__ f2 pk_fma_ab(f2 a, f2 b, f2 c) {
+    f2 d;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// (a.x * b.x + c.x, a.y * b.x + c.y)
+__device__ __forceinline__ f2 pk_fma_blo(f2 a, f2 b, f2 c) {
+    f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b) {
+    f2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
 // ---------------------------------------------------------------------------
