@@ -1632,12 +1632,64 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             unsigned tiebits = 0;                                 // bit r*4+u
 #pragma unroll
             for (int r = 0; r < GN; ++r) packed[r] = 0;
+            s3::f2 DXP[S];                                        // packed 4x4 path: (row 0, row 1) distances of row tap b
+            if constexpr (KIND == LERF_KIND_GAUSS && S == 4 && GS == 2) {
+#pragma unroll
+                for (int b = 0; b < S; ++b) { DXP[b].x = g_dr[il0 * S + b]; DXP[b].y = g_dr[(il0 + 1) * S + b]; }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int xc = min(max(b0 + u, 0), ncolc - 1);    // clamped; invalid bytes are not stored
                 const int jl = xc / CH;
                 const int c = xc - jl * CH;
                 const int lc = g_lc[jl];
+                if constexpr (KIND == LERF_KIND_GAUSS && S == 4 && GS == 2) {
+                    // The 4x4 support, two rows per group, in PACKED float32 over the two rows (lane x = row 0, lane y = row 1):
+                    // per tap and row PAIR one v_pk_mul (tx), two v_pk_fma (the form), one v_pk_add and one v_pk_fma (the sums)
+                    // instead of ten scalar operations; a tap's four scalars sit two to a register pair -- (p0, ty^2) and
+                    // (k1, value) -- and are read through op_sel.  Same operations in the same order: the same bytes.
+                    s3::f2 PT[SS], KV[SS];
+#pragma unroll
+                    for (int a = 0; a < S; ++a) {
+                        const float dy = g_dc[jl * S + a];
+#pragma unroll
+                        for (int b = 0; b < S; ++b) {
+                            const uint32_t d = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
+                            const float tyv = s3::gauss_t_u8((float)((d >> 16) & 0xFFu), dy);
+                            PT[a * S + b].x = s3::gauss_m2rho_u8((float)(d & 0xFFu)) * tyv;
+                            PT[a * S + b].y = tyv * tyv;
+                            KV[a * S + b].x = (float)((d >> 8) & 0xFFu);
+                            KV[a * S + b].y = (float)(d >> 24);
+                        }
+                    }
+                    s3::f2 NUM, DEN;
+#pragma unroll
+                    for (int a = 0; a < S; ++a)
+#pragma unroll
+                        for (int b = 0; b < S; ++b) {
+                            const int k = a * S + b;
+                            const s3::f2 TX = s3::pk_mul_blo(DXP[b], KV[k]);                       // k1 * dx[r][b]
+                            const s3::f2 E = s3::pk_fma_pb<false>(TX, PT[k], s3::pk_fma_ppb<true>(TX, PT[k]));   // fma(tx, p0, fma(tx, tx, ty2))
+                            s3::f2 W;
+                            W.x = __builtin_amdgcn_exp2f(-E.x);
+                            W.y = __builtin_amdgcn_exp2f(-E.y);
+                            if (k == 0) {
+                                DEN = W;
+                                NUM = s3::pk_mul_bhi_after_trans(W, KV[k]);
+                            } else {
+                                DEN = DEN + W;                                                  // (compiler-generated: see the block tasks)
+                                NUM = s3::pk_fma_bhi_after_trans(W, KV[k], NUM);
+                            }
+                        }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const float xf = s3::finish_div(r ? NUM.y : NUM.x, r ? DEN.y : DEN.x);
+                        bool tie;
+                        packed[r] = s3::pack_u8_tie(xf, u, packed[r], &tie);
+                        if (tie) tiebits |= 1u << (r * 4 + u);
+                    }
+                    continue;
+                }
                 // shared by the rows of the group: per tap (a = column offset major, numpy meshgrid 'xy' :95-98; b = row offset)
                 float p0[SS], k1[SS], ty[SS], v[SS];
 #pragma unroll

@@ -204,6 +204,34 @@ __device__ __forceinline__ f2 pk_fma_blo(f2 a, f2 b, f2 c) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// pairs a (two lanes) against the scalars packed in b: (a.x * a.x + b.H, a.y * a.y + b.H) and (a.x * b.H + c.x, a.y * b.H + c.y)
+template <bool HI>
+__device__ __forceinline__ f2 pk_fma_ppb(f2 a, f2 b) {
+    f2 d;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <bool HI>
+__device__ __forceinline__ f2 pk_fma_pb(f2 a, f2 b, f2 c) {
+    f2 d;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// the same with b's HIGH half, for operands that a transcendental instruction has just written: gfx950 needs one wait state
+// between v_exp / v_rcp and a VALU read of the result, which the compiler inserts for its own instructions only -- these
+// carry it themselves (s_nop 0)
+__device__ __forceinline__ f2 pk_mul_bhi_after_trans(f2 w, f2 b) {
+    f2 d;
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(w), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 pk_fma_bhi_after_trans(f2 w, f2 b, f2 c) {
+    f2 d;
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ f2 pk_mul(f2 a, f2 b) {
     f2 d;
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));

@@ -132,6 +132,20 @@ def test_tie_queue_full_falls_back_in_loop(torch, co, eng_g, eng_g4, eng_l, luts
     assert eng_g.sr_geometry((540, 960), 2).struct.tie_queue_cap == 0          # the engine's cached geometry is untouched
 
 
+def test_repeated_launches_give_the_same_bytes(torch, eng_g, eng_g4, eng_l):
+    """the same launch three times: a kernel that reads a register before its producer has finished (round 3: an inline-asm
+    consumer right behind v_exp_f32, which the compiler's hazard recogniser cannot see) gives the right bytes on a fresh box
+    and different ones afterwards"""
+    from lerf_pytorch_amd import ops
+    img = _frame("noise", 540, 960, 78)
+    x = torch.from_numpy(img).cuda()
+    for eng, scale in ((eng_g, 2), (eng_g4, 2), (eng_l, (1.5, 2.0)), (eng_g, 3)):
+        geo = eng.sr_geometry((540, 960), scale)
+        first = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma).clone()
+        for _ in range(2):
+            assert torch.equal(ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma), first)
+
+
 def test_config5_4k_to_8k_properties(torch, co, eng_g, luts_g):
     """2160x3840 -> 4320x7680: (a) the frame equals the float64 port byte for byte; (b) fused == unfused; (c) any
     interior crop with a 7-px halo reproduces the frame's bytes; (d) 8 strips with 7-row halos, ranks emulated one
