@@ -511,20 +511,36 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                      "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                     "binding_resource": "valu_issue (gather/VALU-bound path, HBM is the nominal roofline only: %.2f B per output pixel; DESIGN.md section 5)"
+                     "binding_resource": "lds_gather (the LUT gathers at the random-address rate of the LDS, see roofline_lds; then VALU issue. HBM is "
+                                         "the nominal roofline only: %.2f B per output pixel; DESIGN.md section 5)"
                                          % ((alg_bytes - LUT_BYTES[model]) / (B_local * out_px_local)),
                      "binding_resources_from_pmc": binding},
         # LR (input) pixels per second: what the LUT stages see -- the fair comparison between scale factors
         "lr_mpix_s": round(value * (H * W) / (oH * oW), 2),
     }
+    # The resource that binds (round 3): every LR pixel-channel costs 60 byte gathers (stage 1) + 60 gathers (stage 2: dword
+    # entries for LeRF-G, bytes for LeRF-L) from LUTs staged in LDS, the stage-2 ones also on the tile halo; a wave64 gather at
+    # random addresses takes 3.53 ns of a CU's LDS (32 lanes on 32 banks per cycle: 7.6 cycles, tools/ubench/lds_gather.hip,
+    # profiles/r03_lds_gather_and_clocks.txt), conflict-free it would take 0.9.  achieved = wave-gathers per second and CU.
+    if not args.unfused:
+        r3 = S // 2
+        halo = ((64 + 2 * r3) * (192 // C + 2 * r3) * C) / float(64 * 192)
+        wave_gathers = B_local * H * W * C * 60.0 * (1.0 + halo) / 64.0
+        lds_ns = 3.53
+        res["roofline_lds"] = {"bound": "lds_gather", "achieved": round(wave_gathers / (launch_ms * 1e-3) / 256 / 1e6, 2),
+                               "peak": round(1e3 / lds_ns, 2), "unit": "M wave-gathers/s per CU",
+                               "frac": round(wave_gathers * lds_ns * 1e-6 / 256 / launch_ms, 4),
+                               "wave_gathers_per_launch": int(wave_gathers),
+                               "note": "peak = random-address ds_read rate measured on this chip (3.53 ns per wave64 gather and CU)"}
+        res["roofline"]["bound_note"] = "nominal (contract): the binding resource is the LDS gather rate, see roofline_lds"
     if binding and "valu_instr_per_cu_cycle" in binding:
-        # the resource that binds (recorded PMC of these kernel sources): VALU wave-instructions issued per CU-cycle against the
-        # 2.0 a CU can issue (4 SIMDs x one full-rate wave64 instruction per 2 cycles; three quarters of this kernel's mix is
-        # the half-rate class, so its own ceiling is ~1.15: DESIGN.md section 5)
+        # the second resource (recorded PMC of these kernel sources): VALU wave-instructions issued per CU-cycle against the 2.0
+        # a CU can issue in runs of simple instructions; the kernels' mixed streams get one instruction per 4-cycle pass and
+        # SIMD = 1.0 per CU-cycle (profiles/r03_issue_rates.txt)
         res["roofline_valu"] = {"bound": "valu", "achieved": binding["valu_instr_per_cu_cycle"], "peak": 2.0,
                                 "unit": "wave-instr/CU-cycle", "frac": round(binding["valu_instr_per_cu_cycle"] / 2.0, 4),
                                 "source": tsrc}
-        res["roofline"]["bound_note"] = "nominal (contract): the binding resource is VALU issue, see roofline_valu"
+        res["roofline_valu"]["note"] = "one instruction per 4-cycle pass and SIMD is what the kernels' mixed streams reach (1.0 per CU-cycle): profiles/r03_issue_rates.txt"
     if sustained:
         res["sustained"] = {"seconds": round(sustained[1], 2), "steps": sustained[0],
                             "value": round(pix_per_step * sustained[0] / sustained[1] / 1e6, 2), "unit": "Mpix/s",

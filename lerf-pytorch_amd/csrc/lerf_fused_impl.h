@@ -1927,7 +1927,14 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 const int ch = i - row * nchunk;
                 if (ch >= full_lo && ch < full_hi) {
                     const v4u x = *reinterpret_cast<const v4u*>(outt + row * D::OUT_PITCH + ch * 16);
-                    __builtin_nontemporal_store(x, reinterpret_cast<v4u*>(gbase + row * rowpitch + ch * 16));
+                    uint8_t* dst = gbase + row * rowpitch + ch * 16;
+                    // streaming stores for the 64-byte lines this tile writes completely; the first and the last line of a row
+                    // are shared with the neighbouring tiles and go through the L2 (regular stores), which merges the two
+                    // tiles' halves into one line -- as streaming stores they were two partial-line writes each (+67 MB per step)
+                    const uintptr_t line = reinterpret_cast<uintptr_t>(dst) & ~(uintptr_t)63;
+                    const uintptr_t r0 = reinterpret_cast<uintptr_t>(gbase + row * rowpitch) + (uintptr_t)ophase;
+                    if (line >= r0 && line + 64 <= r0 + (uintptr_t)ncolc) __builtin_nontemporal_store(x, reinterpret_cast<v4u*>(dst));
+                    else *reinterpret_cast<v4u*>(dst) = x;
                 }
             }
             // the ragged chunks, two per row at most, in a loop of their own (a few waves take it once, instead of every
@@ -1945,7 +1952,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t w = x[k];
                     if (lo <= 4 * k && hi >= 4 * k + 4) {
-                        __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(dst + 4 * k));
+                        *reinterpret_cast<uint32_t*>(dst + 4 * k) = w;
                     } else {
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
