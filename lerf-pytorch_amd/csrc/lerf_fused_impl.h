@@ -128,7 +128,8 @@ struct Dims {
     // global address modulo 16
     static constexpr int OUT_ROWS = 2 * TH + 4, OUT_PITCH = up16(2 * TW * CH + 16 + 15);
     static constexpr int OFF_OUT = up16(OFF_TQ + TQ_CAP * 4);
-    static constexpr bool OUT_FITS = OFF_OUT + OUT_ROWS * OUT_PITCH <= OFF_X + PIECE_LDS;
+    static constexpr int OFF_CGRP = OFF_OUT + OUT_ROWS * OUT_PITCH;          // column-group table of the LeRF-L block tasks
+    static constexpr bool OUT_FITS = OFF_CGRP + (2 * TW + 16) * 4 <= OFF_X + PIECE_LDS;
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int LDS_BYTES = cmax(END1, cmax(END2, GEO_EARLY ? END3 : 0)) + 512;  // + small control block
     static constexpr int OFF_CTL = LDS_BYTES - 512;
@@ -1592,6 +1593,41 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 ctl[22] = uniform ? g0 : 0;
                 ctl[23] = 0;
             }
+            if constexpr (KIND == LERF_KIND_LINEAR && S == 2 && D::OUT_FITS) {
+                bool small = true;                               // no group of more than two rows (block tasks of LeRF-L)
+                for (int base = 0; base < ng; base += 64) {
+                    const int idx = base + lane;
+                    if (idx < ng && g_grp[idx + 1] - g_grp[idx] > 2) small = false;
+                }
+                const bool ok = __ballot(!small) == 0ull;
+                if (lane == 0) ctl[26] = ok ? 1 : 0;
+            }
+        } else if (wave == 1 && KIND == LERF_KIND_LINEAR && S == 2 && D::OUT_FITS) {
+            // LeRF-L block tasks: the columns in groups of at most two that share their taps (runs of equal left taps, every
+            // second column of a run starts a group); the table lies behind the output image, over the dead stage-2 areas
+            int* g_cgrp = reinterpret_cast<int*>(smem + D::OFF_CGRP);
+            constexpr int NCMAX = 2 * TW + 14;
+            int nc = 0;
+            for (int base = 0; base < ncol; base += 64) {
+                const int jl = base + lane;
+                bool start = false;
+                if (jl < ncol) {
+                    int back = 0;                                // columns of the same run to the left
+                    while (back < 16 && jl - back - 1 >= 0 && g_lc[jl - back - 1] == g_lc[jl]) ++back;
+                    start = (back & 1) == 0;
+                }
+                const unsigned long long m = __ballot(start);
+                if (start) {
+                    const int idx = nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (idx < NCMAX) g_cgrp[idx] = jl;
+                }
+                nc += __popcll(m);
+            }
+            if (lane == 0) {
+                if (nc <= NCMAX) g_cgrp[nc] = ncol;
+                ctl[25] = nc;
+                ctl[27] = (nc <= NCMAX) ? 1 : 0;
+            }
         } else if (wave == 1) {
             // the columns: do columns 2h and 2h + 1 share their taps for every h? (block tasks below)
             bool ok = (ncol & 1) == 0;
@@ -1913,6 +1949,117 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             }
             }
         };
+        // ---- LeRF-L block tasks (amplified-linear weights, 2 x 2 support): row groups and column groups of ONE or two
+        //      members (x1.5 gives groups of 1, 2, 1, 2 ..., x2 pairs; the frame edges singles), one task = the up to 2 x 2
+        //      outputs of a (row group, column group), all channels.  The dword-column tasks ran the general five-row form
+        //      here (a group's size is not uniform at x1.5) and evaluated every tap's row factor per output; the block forms
+        //      a tap's column factor once per column, its row factor once per row.  Weights as in lerf_stage3.h: the factor of
+        //      a distance x is max(1 - alpha |x|, 0) for |x| <= 1 and 0 outside -- alpha * x + 1 (x < 0) and 1 - alpha * x
+        //      (x >= 0) are the same float32 operations on |x| -- so the bytes are those of run_tasks.
+        constexpr bool BLKL = KIND == LERF_KIND_LINEAR && S == 2 && D::OUT_FITS;
+#ifndef LERF_NO_BLOCK_TASKS
+        const bool blkl = BLKL && __builtin_amdgcn_readfirstlane((rows_align && ctl[26] != 0 && ctl[27] != 0 && (rowpitch & 15) == 0 &&
+                                                                  nrow <= D::OUT_ROWS && ophase + ncolc <= D::OUT_PITCH) ? 1 : 0) != 0;
+#else
+        const bool blkl = false;
+#endif
+        auto run_blocks_lin = [&]() {
+            if constexpr (BLKL) {
+            const int* g_cgrp = reinterpret_cast<const int*>(smem + D::OFF_CGRP);
+            const int ncg = __builtin_amdgcn_readfirstlane(ctl[25]);
+            const int nblk = ngrp * ncg;
+            const unsigned magicc = (unsigned)((0x100000000ull + (unsigned)ncg - 1) / (unsigned)(ncg > 0 ? ncg : 1));
+            for (int t = tid; t < nblk; t += NT) {
+                const int g = (int)__umulhi((unsigned)t, magicc);
+                const int h = t - g * ncg;
+                const int il0 = g_grp[g], jl0 = g_cgrp[h];
+                const bool two_r = g_grp[g + 1] - il0 > 1, two_c = g_cgrp[h + 1] - jl0 > 1;
+                const int lr = g_lr[il0], lc = g_lc[jl0];
+                // |distance| and inside-the-support mask (1 / 0) of the two rows [r][row tap b] and the two columns [q][column
+                // tap a]; a single's second member reads its neighbour's entries (computed, never stored)
+                float ax[2][2], mx[2][2], ay[2][2], my[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float x = g_dr[(il0 + r) * 2 + b];
+                        ax[r][b] = __builtin_fabsf(x);
+                        mx[r][b] = s3::dist_class_f(x) != 0 ? 1.0f : 0.0f;
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const float y = g_dc[(jl0 + q) * 2 + a];
+                        ay[q][a] = __builtin_fabsf(y);
+                        my[q][a] = s3::dist_class_f(y) != 0 ? 1.0f : 0.0f;
+                    }
+                const uint32_t* dp = Dt + lr * D::HP + lc * CH;
+                uint8_t* ob = outt + il0 * D::OUT_PITCH + ophase + jl0 * CH;
+                float dist[4 * CH];                                  // [c][r][q]
+                float dmax = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    float v[4], fy[2][4], fx[2][4];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const uint32_t d = dp[b * D::HP + a * CH + c];
+                            v[a * 2 + b] = (float)(d >> 24);
+                            const float alpha = s3::lin_alpha_u8((float)(d & 0xFFu), ms255);
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) fy[q][a * 2 + b] = s3::lin_factor_abs(alpha, ay[q][a], my[q][a]);
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) fx[r][a * 2 + b] = s3::lin_factor_abs(alpha, ax[r][b], mx[r][b]);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            float e[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) e[k] = fx[r][k] * fy[q][k];
+                            const float xf = s3::finish<false, 4, true, true, true>(e, v);
+                            const float rr = __builtin_rintf(xf);
+                            const bool have = (r == 0 || two_r) && (q == 0 || two_c);
+                            const float ds = have ? xf - rr : 0.0f;
+                            dist[(c * 2 + r) * 2 + q] = ds;
+                            dmax = __builtin_fmaxf(dmax, __builtin_fabsf(ds));
+                            if (have) ob[r * D::OUT_PITCH + q * CH + c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(rr, 0u, 0u);
+                        }
+                }
+                if (dmax > 0.5f - s3::kTieEps && F.dis_r64 != nullptr) {
+                    unsigned tiemask = 0;
+#pragma unroll
+                    for (int q = 0; q < 4 * CH; ++q)
+                        if (__builtin_fabsf(dist[q]) > 0.5f - s3::kTieEps) tiemask |= 1u << q;
+#pragma unroll 1
+                    for (int q = 0; q < 4 * CH; ++q) {
+                        if (!((tiemask >> q) & 1u)) continue;
+                        const int c = q >> 2, r = (q >> 1) & 1, qq = q & 1;
+                        const int il = il0 + r, xc = (jl0 + qq) * CH + c;
+                        const int slot = atomicAdd(tq_count, 1);
+                        if (slot < P.tq_cap) {
+                            tq[slot] = ((uint32_t)il << 16) | (uint32_t)xc;
+                            continue;
+                        }
+                        uint32_t dd[4];
+                        double dx64[2], dy64[2];
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il) * 2 + b];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl0 + qq) * 2 + a];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) dd[a * 2 + b] = dp[b * D::HP + a * CH + c];
+                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<false, 2>(dd, dx64, dy64, P.max_sigma));
+                    }
+                }
+            }
+            }
+        };
         // the LDS image of the output block -> the frame: whole 16-byte chunks with streaming stores, the ragged ends of a
         // row (the neighbouring tiles' bytes share those chunks) dword by dword and byte by byte
         auto flush_blocks = [&]() {
@@ -1966,13 +2113,14 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
         // (max_sigma <= s3::kNoShiftMaxSigma here: the host sends larger values to the float64 direct kernel, lerf_fused.hip)
         if (blk) run_blocks();
+        else if (blkl) run_blocks_lin();
         else if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});
         else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{});
         else if (WIDE && gsame == 4) run_tasks(std::integral_constant<int, WIDE ? 4 : 0>{});
         else run_tasks(std::integral_constant<int, 0>{});
         // ---- tie pass: the queued outputs in float64, one per lane; each patches its byte behind the task loop's
         //      dword stores (drained and fenced by the barrier)
-        if (blk) {
+        if (blk || blkl) {
             // block tasks: the queued outputs are patched in the LDS image, which then leaves in one piece
             __syncthreads();
             LERF_STAMP(15);

@@ -104,6 +104,15 @@ __device__ __forceinline__ float lin_factor(float alpha, float x, int cls) {
     return f < 0.0f ? 0.0f : f;                                            // negative weights clipped (:240)
 }
 
+// the same factor from |x| and its inside-the-support mask (1 for |x| <= 1 -- both classes of dist_class_f --, 0 outside):
+// alpha * x + 1 for x < 0 and 1 - alpha * x for x >= 0 are both fl(1 - fl(alpha |x|)), so the result is lin_factor's, bit
+// for bit; callers that meet a distance many times (one row or column of a block of outputs) keep |x| and the mask
+__device__ __forceinline__ float lin_factor_abs(float alpha, float ax, float mask) {
+#pragma clang fp contract(off)
+    const float f = 1.0f - alpha * ax;
+    return (f < 0.0f ? 0.0f : f) * mask;
+}
+
 // The float32 production arithmetic of the uint8 paths (pre-scaled quadratic forms, unshifted exp2 sums, tie guard of
 // 1.5e-4) is sized for max_sigma <= kNoShiftMaxSigma: on an SR grid the nearest tap lies within half a pixel on both
 // axes, so its pre-scaled form is at most 0.5 log2(e) (0.25 + 0.25 + 0.5) max_sigma^2 = 0.7214 max_sigma^2 < 126 and
