@@ -24,8 +24,10 @@ NAMES = ["in+lut0", "s1:s", "copy", "s1:c", "copy", "s1:t", "bin+slots", "s2 cop
 
 
 def main():
-    eng = L.LerfEngine.shipped("lerf-g")
-    geo = eng.sr_geometry((H, W), 2)
+    model = os.environ.get("LERF_STAMPS_MODEL", "lerf-g")            # lerf-l: stage 2 + packing = stamps 6 -> 11 ("s2" rows are not set)
+    scale = tuple(float(v) for v in os.environ.get("LERF_STAMPS_SCALE", "2").split(","))
+    eng = L.LerfEngine.shipped(model)
+    geo = eng.sr_geometry((H, W), scale if len(scale) > 1 else scale[0])
     for kind in (sys.argv[1:] or ("noise", "natural", "constant")):
         if kind == "constant":
             x = torch.full((1, H, W, 3), 128, dtype=torch.uint8, device="cuda")
@@ -34,7 +36,7 @@ def main():
         tiles = ((H + 63) // 64) * ((W + 63) // 64)
         ws = torch.zeros(max(tiles * 16 * 8, 4 * H * W * 3), dtype=torch.uint8, device="cuda")
         for _ in range(2):
-            ops.sr_fused_u8(x, eng.luts, geo, "gauss", 10.0, workspace=ws)
+            ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma, workspace=ws)
         torch.cuda.synchronize()
         st = ws[:tiles * 16 * 8].view(torch.int64).reshape(tiles, 16).cpu().numpy().astype(np.float64)
         d = {}
@@ -49,6 +51,7 @@ def main():
         d["s2 lookups"] = st[:, 9]
         d["s2 total"] = st[:, 10] - st[:, 7]
         d["finalise+geo"] = st[:, 11] - st[:, 10]
+        d["stage 2 .. geometry (6 -> 11)"] = st[:, 11] - st[:, 6]
         d["stage3"] = st[:, 12] - st[:, 11]
         blkt = st[:, 15] > 0                                # tiles that took the block tasks of stage 3
         if blkt.any():
