@@ -1629,14 +1629,24 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 ctl[27] = (nc <= NCMAX) ? 1 : 0;
             }
         } else if (wave == 1) {
-            // the columns: do columns 2h and 2h + 1 share their taps for every h? (block tasks below)
-            bool ok = (ncol & 1) == 0;
-            for (int base = 0; base < ncol; base += 128) {
-                const int jl = base + 2 * lane;
-                if (jl + 1 < ncol && g_lc[jl + 1] != g_lc[jl]) ok = false;
+            // the columns (block tasks below): do they pair up as (2h, 2h + 1) -- code 1 -- or, behind a leading single (the
+            // frame's left edge), as (2h - 1, 2h) -- code 2?  A trailing single is fine either way.
+            bool ok0 = true, ok1 = true;
+            for (int base = 0; base < ncol; base += 64) {
+                const int jl = base + lane;
+                if (jl + 1 < ncol && g_lc[jl + 1] != g_lc[jl]) { if (jl & 1) ok1 = false; else ok0 = false; }
             }
-            const bool pairs = __ballot(!ok) == 0ull;
-            if (lane == 0) ctl[24] = pairs ? 1 : 0;
+            const bool p0 = __ballot(!ok0) == 0ull, p1 = __ballot(!ok1) == 0ull;
+            if (lane == 0) ctl[24] = p0 ? 1 : (p1 ? 2 : 0);
+        } else if (wave == 2 && KIND == LERF_KIND_GAUSS) {
+            // the rows, the same question on the rows' first taps
+            bool ok0 = true, ok1 = true;
+            for (int base = 0; base < nrow; base += 64) {
+                const int il = base + lane;
+                if (il + 1 < nrow && g_lr[il + 1] != g_lr[il]) { if (il & 1) ok1 = false; else ok0 = false; }
+            }
+            const bool p0 = __ballot(!ok0) == 0ull, p1 = __ballot(!ok1) == 0ull;
+            if (lane == 0) ctl[26] = p0 ? 1 : (p1 ? 2 : 0);
         }
         __syncthreads();
         const int ngrp = ctl[21];
@@ -1841,22 +1851,28 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         uint8_t* outt = smem + D::OFF_OUT;
         const int ophase = (int)(reinterpret_cast<uintptr_t>(seg0) & 15u);
 #ifndef LERF_NO_BLOCK_TASKS
-        const bool blk = BLK && __builtin_amdgcn_readfirstlane((gsame == 2 && ctl[24] != 0 && (rowpitch & 15) == 0 && nrow <= D::OUT_ROWS &&
-                                                                ophase + ncolc <= D::OUT_PITCH) ? 1 : 0) != 0;
+        const int rcode = __builtin_amdgcn_readfirstlane(ctl[26]), ccode = __builtin_amdgcn_readfirstlane(ctl[24]);
+        const bool blk = BLK && rows_align && rcode != 0 && ccode != 0 && (rowpitch & 15) == 0 && nrow <= D::OUT_ROWS &&
+                         ophase + ncolc <= D::OUT_PITCH;
+        // interior tiles: pairs from row 0 / column 0 on, even counts -- no validity tests; tiles at the frame's edges: a leading
+        // and / or trailing single row or column, handled as a pair whose other member is not stored
+        const bool blk_uni = blk && rcode == 1 && ccode == 1 && ((nrow | ncol) & 1) == 0;
 #else
-        const bool blk = false;
+        const bool blk = false, blk_uni = false;
 #endif
-        auto run_blocks = [&]() {
+        auto run_blocks = [&](auto uni_const) {
+            constexpr bool UNI = decltype(uni_const)::value;
             if constexpr (BLK) {
             constexpr int SS2 = 4;
-            const int ncg = ncol >> 1;
-            const int nblk = (nrow >> 1) * ncg;
+            const int rofs = UNI ? 0 : rcode - 1, cofs = UNI ? 0 : ccode - 1;
+            const int ncg = (ncol + cofs + 1) >> 1;
+            const int nblk = ((nrow + rofs + 1) >> 1) * ncg;
             const unsigned magicc = (unsigned)((0x100000000ull + (unsigned)ncg - 1) / (unsigned)(ncg > 0 ? ncg : 1));
             for (int t = tid; t < nblk; t += NT) {
                 const int g = (int)__umulhi((unsigned)t, magicc);
                 const int h = t - g * ncg;
-                const int il0 = 2 * g, jl0 = 2 * h;
-                const int lr = g_lr[il0], lc = g_lc[jl0];
+                const int il0 = 2 * g - rofs, jl0 = 2 * h - cofs;
+                const int lr = g_lr[UNI ? il0 : max(il0, 0)], lc = g_lc[UNI ? jl0 : max(jl0, 0)];
                 // distances as PAIRS: DX[b] = (row 0, row 1) of row tap b, DY[a] = (column 0, column 1) of column tap a
                 s3::f2 DX[2], DY[2];
 #pragma unroll
@@ -1912,9 +1928,10 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                             const float xf = s3::finish_div(num, den);
                             const float rr = __builtin_rintf(xf);
                             const float ds = xf - rr;
-                            dist[(c * 2 + r) * 2 + q] = ds;
-                            dmax = __builtin_fmaxf(dmax, __builtin_fabsf(ds));
-                            ob[r * D::OUT_PITCH + q * CH + c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(rr, 0u, 0u);
+                            const bool have = UNI || ((unsigned)(il0 + r) < (unsigned)nrow && (unsigned)(jl0 + q) < (unsigned)ncol);
+                            dist[(c * 2 + r) * 2 + q] = have ? ds : 0.0f;
+                            dmax = __builtin_fmaxf(dmax, __builtin_fabsf(dist[(c * 2 + r) * 2 + q]));
+                            if (have) ob[r * D::OUT_PITCH + q * CH + c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(rr, 0u, 0u);
                         }
                 }
                 if (dmax > 0.5f - s3::kTieEps && F.dis_r64 != nullptr) {
@@ -2112,7 +2129,8 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         // the group size per task
         constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
         // (max_sigma <= s3::kNoShiftMaxSigma here: the host sends larger values to the float64 direct kernel, lerf_fused.hip)
-        if (blk) run_blocks();
+        if (blk_uni) run_blocks(std::true_type{});
+        else if (blk) run_blocks(std::false_type{});
         else if (blkl) run_blocks_lin();
         else if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});
         else if (WIDE && gsame == 3) run_tasks(std::integral_constant<int, WIDE ? 3 : 0>{});
