@@ -32,6 +32,9 @@
 //   D    (hq0,hq1,hq2,feat) dwords      stage 3, overlays LUT (52 KB / 55 KB)
 //   GEO  tile geometry tables           stage 3 (9 KB; staged at kernel start for S=2)
 //   TQ   rounding-tie queue             stage 3 (8 KB, behind D)
+//   OUT  the tile's output block        stage 3, block tasks (2 x 2 outputs that share their taps: integer x2 LeRF-G, LeRF-L):
+//        assembled byte by byte (132 x 416 B behind TQ), ties patched in it, stored as whole 16-byte chunks
+//   CGRP column-group table             stage 3, LeRF-L block tasks (behind OUT)
 //
 // Stage 2 of LeRF-G keeps the whole 3-channel LUT entry in one dword, so one
 // simplex walk (index sort + 5 LDS gathers) serves all three hyper channels.
