@@ -86,11 +86,16 @@ constexpr int PIECE_LDS = PIECE_BLOCKS * 1024;                // what a piece oc
 
 // BIG = false: geometry tables for scale factors up to 4.9, staged at kernel start for the 2x2 support of RGB frames (the
 // headline layout).  BIG = true: up to x8.1, always staged late over the dead LUT area.
-template <int S, bool BIG = false>
+// NOHALO = true (the EMIT kernels): the hyper region is the tile itself -- the stage-3 ring of R3 pixels is looked up only by
+// the kernels that run stage 3 (the packed maps a warp reads hold every pixel once); the feat region keeps its size, so the
+// aligned-dword tile load stays.
+template <int S, bool BIG = false, bool NOHALO = false>
 struct Dims {
     static constexpr int R3 = S / 2;
-    static constexpr int HY = TH + 2 * R3, HX = TW + 2 * R3, HP = HX * CH, NH = HY * HP;   // hyper region
-    static constexpr int FY = HY + 2 * R2, FX = HX + 2 * R2, FP = FX * CH, NF = FY * FP;   // feat region
+    static constexpr int HR = NOHALO ? 0 : R3;                                             // ring of the hyper region around the tile
+    static constexpr int HY = TH + 2 * HR, HX = TW + 2 * HR, HP = HX * CH, NH = HY * HP;   // hyper region
+    static constexpr int FY = TH + 2 * R3 + 2 * R2, FX = TW + 2 * R3 + 2 * R2, FP = FX * CH, NF = FY * FP;   // feat region
+    static constexpr int HO = R2 + R3 - HR;                                                // the hyper region's origin inside the feat region
     // input region; its LDS pitch is a dword multiple with room for a 0..3 byte phase, so that interior tiles can be
     // fetched as aligned dwords (row r of the tile = global bytes from the 4-byte boundary below its first pixel)
     static constexpr int IY = FY + 2 * R1, IX = FX + 2 * R1, IPB = IX * CH, IP = (IPB + 3 + 3) / 4 * 4, NI = IY * IP;
@@ -921,7 +926,7 @@ __device__ __forceinline__ FrameView frame_view(const Params& P, const std::cond
 template <int S, int KIND, bool EMIT, bool FROM_FEAT = false, bool GEN = false>
 __global__ void __launch_bounds__(NT)
 sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
-    using D = Dims<S, GEN>;
+    using D = Dims<S, GEN, EMIT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -936,8 +941,8 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     uint8_t* __restrict__ outp = F.out;
 
     // region origins in frame coordinates
-    const int hy0 = ty0 - D::R3, hx0 = tx0 - D::R3;
-    const int fy0 = hy0 - R2, fx0 = hx0 - R2;
+    const int hy0 = ty0 - D::HR, hx0 = tx0 - D::HR;
+    const int fy0 = ty0 - D::R3 - R2, fx0 = tx0 - D::R3 - R2;
     const int iy0 = fy0 - R1, ix0 = fx0 - R1;
 
     uint8_t* Bt = smem + D::OFF_B;
@@ -1320,7 +1325,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             // as it is -- no second address computation per slot.
             const int p0 = tid * KH, ry0 = p0 / D::HP;
             uint32_t col = (uint32_t)(p0 - ry0 * D::HP);
-            uint32_t ap = (uint32_t)((ry0 + R2) * D::FP + R2 * CH) + col;
+            uint32_t ap = (uint32_t)((ry0 + D::HO) * D::FP + D::HO * CH) + col;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
                 const uint32_t q = k < 8 ? (qlo >> (4 * k)) & 0xFu : (qhi >> (4 * (k - 8))) & 0xFu;
@@ -1513,7 +1518,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 // feat-tile address -> hyper-region position: row (ry + R2) of pitch FP -> row ry of pitch HP, R2 pixels left
                 const uint32_t a = (k & 1) ? (slot2[k >> 1] >> 16) : (slot2[k >> 1] & 0xFFFFu);
                 const uint32_t row = a / (uint32_t)D::FP;
-                const uint32_t p = a - row * (uint32_t)(D::FP - D::HP) - (uint32_t)(R2 * D::HP + R2 * CH);
+                const uint32_t p = a - row * (uint32_t)(D::FP - D::HP) - (uint32_t)(D::HO * D::HP + D::HO * CH);
                 Dt[p] = h0 | (h1 << 8) | (h2 << 16) | ((uint32_t)Bt[a] << 24);
             }
         }
@@ -1536,7 +1541,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         uint32_t* eo = F.emit;
         const int rows = min(TH, H - ty0), cols3 = min(TW, W - tx0) * CH;
         for (int il = wave; il < rows; il += NW) {
-            const uint32_t* srow = Dt + (il + D::R3) * D::HP + D::R3 * CH;
+            const uint32_t* srow = Dt + (il + D::HR) * D::HP + D::HR * CH;
             uint32_t* drow = eo + ((int64_t)(ty0 + il) * W + tx0) * CH;
             for (int x = lane; x < cols3; x += 64) drow[x] = srow[x];
         }
@@ -2354,7 +2359,7 @@ inline size_t feat_slice_bytes(int H, int W) { return ((size_t)H * W * CH + 15) 
 
 template <int S, int KIND, bool EMIT, bool GEN>
 static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
-    using D = Dims<S, GEN>;
+    using D = Dims<S, GEN, EMIT>;
     using TableT = std::conditional_t<GEN, RaggedTable, NoTable>;
     const lerf_luts_t* L = a.luts;
     Params P{};
