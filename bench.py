@@ -523,7 +523,7 @@ def main():
     # random addresses takes 3.53 ns of a CU's LDS (32 lanes on 32 banks per cycle: 7.6 cycles, tools/ubench/lds_gather.hip,
     # profiles/r03_lds_gather_and_clocks.txt), conflict-free it would take 0.9.  achieved = wave-gathers per second and CU.
     if not args.unfused:
-        r3 = S // 2
+        r3 = 0 if cfg == 4 else S // 2              # the EMIT kernels of the warp path look up the tile itself, no stage-3 ring
         halo = ((64 + 2 * r3) * (192 // C + 2 * r3) * C) / float(64 * 192)
         wave_gathers = B_local * H * W * C * 60.0 * (1.0 + halo) / 64.0
         lds_ns = 3.53
