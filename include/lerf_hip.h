@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LERF_ABI_VERSION 4
+#define LERF_ABI_VERSION 5
 #define LERF_MAX_MODES 5          /* s, c, t, d, y  (resample/eval_lut_sr.py:12-18) */
 #define LERF_LUT_ENTRIES 83521    /* 17^4, interval = 4 (resample/eval_lut_sr.py:27-28) */
 #define LERF_MAX_SUPPORT 8
@@ -113,8 +113,15 @@ typedef struct {
     int roi_h, roi_w;        /* roi_w = 0: the whole frame.  A rank of a 2-D block partition passes its OWNED block here and the block
                               * plus halo as the frame: halo pixels then only ever serve as tile halos (255 instead of 288 tiles for a
                               * 1080x960 block of a 2160x3840 frame).  The output tables must list only outputs whose support starts
-                              * inside the region (the caller's slicing rule; lerf-pytorch_amd/dist.py BlockPlan) */
+                              * inside the region (the caller's slicing rule; lerf-pytorch_amd/dist.py BlockPlan).  With a workspace
+                              * the region takes the two-launch path too: stage 1 runs once per pixel over the region widened by
+                              * 3 + S/2 pixels (ABI 5; ABI 4 recomputed stage 1 on every tile's halo for regions) */
+    /* ---- ABI 5 (zero = the behaviour of ABI 4) */
+    int flags;               /* LERF_GEO_* bits, per call (the library reads no environment variables and keeps no state) */
 } lerf_sr_geo_t;
+#define LERF_GEO_FORCE_GENERAL 1   /* diagnostic: take the general tile-fused kernels where the specialised ones would serve (A/B runs) */
+#define LERF_GEO_INPUT_DEVICE 4    /* lerf_sr_fused_u8: the input frames are device memory / pinned host memory (read over PCIe from inside the */
+#define LERF_GEO_INPUT_HOST 8      /* kernel, once per pixel); neither bit: the library asks the runtime (one hipPointerGetAttributes per call) */
 
 /* Homography geometry (resize_right/resize_right2d_numpy.py:306-407): evaluated
  * per output pixel on the device in float64; pad_* come from lerf_warp_pads. */
@@ -257,11 +264,12 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
 int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind, double max_sigma);
 
 /* Frames of DIFFERENT sizes through ONE launch pair of the general tile-fused kernels (each workgroup finds its frame in a
- * descriptor table that travels in the kernel arguments; chunks of 16 frames per launch): what eltr.run does image by
- * image over a benchmark folder (resample/eval_lut_sr.py:489-512).  Every item carries its own geometry (same support S
- * and pad_mode for all; tie_queue_cap / roi of the first item apply).  `items` is a HOST array.  workspace: device scratch of
- * at least lerf_sr_ragged_workspace_bytes(items, n, C) bytes (required).  Configurations without a tile-fused kernel run
- * item by item through lerf_sr_fused_u8. */
+ * descriptor table that travels in the kernel arguments: 16 frames per launch pair, more frames = more launch pairs): what
+ * eltr.run does image by image over a benchmark folder (resample/eval_lut_sr.py:489-512).  Every item carries its own
+ * geometry; the support S, pad_mode, tie_queue_cap and flags must be the same for all items (LERF_EINVAL otherwise), an
+ * item with a region of interest sends the call item by item through lerf_sr_fused_u8, as does any configuration without
+ * a tile-fused kernel.  All frames, tables and the workspace live on ONE device (the caller's current one).  `items` is a
+ * HOST array.  workspace: device scratch of at least lerf_sr_ragged_workspace_bytes(items, n, C) bytes (required). */
 typedef struct {
     const uint8_t* img;      /* device, dense uint8 [H][W][C] */
     uint8_t* out;            /* device, dense uint8 [geo.out_h][geo.out_w][C] */

@@ -76,7 +76,11 @@ class SrGeo(C.Structure):
         ("pad_mode", C.c_int),
         ("tie_queue_cap", C.c_int),                                   # 0 = default, n > 0 = n entries, < 0 = no queue
         ("roi_y", C.c_int), ("roi_x", C.c_int), ("roi_h", C.c_int), ("roi_w", C.c_int),   # 0-sized = whole frame
+        ("flags", C.c_int),                                           # GEO_* bits (ABI 5)
     ]
+
+
+GEO_FORCE_GENERAL, GEO_INPUT_DEVICE, GEO_INPUT_HOST = 1, 4, 8
 
 
 class SrItem(C.Structure):          # lerf_sr_item_t: one frame of a ragged launch
@@ -180,7 +184,7 @@ def lib():
     L.lerf_srnet_to_lut.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:          # AttributeError here = the .so does not match include/lerf_hip.h
         getattr(L, name)
-    if L.lerf_abi_version() != 4:
+    if L.lerf_abi_version() != 5:
         raise LerfError("liblerf_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -262,6 +266,27 @@ def plane(t, sy, sx, sc, offset=0):
     return Plane(t.data_ptr() + offset * t.element_size(), _dt(t), int(sy), int(sx), int(sc))
 
 
-def current_stream():
+def current_stream(device=None):
+    """torch's current stream of `device` (default: the current device) as a hipStream_t"""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class on_device:
+    """`with on_device(t):` -- the tensor's device is the current one for the launches inside (the library resolves
+    per-device kernel attributes with hipGetDevice, and current_stream() then is the stream of THAT device); no-op for
+    host tensors (pinned frames of stream.StreamingSR run on the caller's current device)."""
+
+    def __init__(self, t):
+        import torch
+        self._g = torch.cuda.device(t.device) if getattr(t, "is_cuda", False) else None
+
+    def __enter__(self):
+        if self._g is not None:
+            self._g.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._g is not None:
+            return self._g.__exit__(*exc)
+        return False

@@ -380,7 +380,7 @@ static void fused_args_of(FusedArgs& f, int C, const lerf_luts_t* luts, const le
     f.dis_c64 = (geo->dis_r64 && geo->dis_c64) ? geo->dis_c64 : nullptr;
     f.kind = kind;
     f.roi_y = geo->roi_y; f.roi_x = geo->roi_x; f.roi_h = geo->roi_h; f.roi_w = geo->roi_w;
-    f.tq_cap = geo->tie_queue_cap; f.pad_mode = geo->pad_mode;
+    f.tq_cap = geo->tie_queue_cap; f.pad_mode = geo->pad_mode; f.flags = geo->flags;
 }
 
 int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind, double max_sigma) {
@@ -410,11 +410,16 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
     f.img = img; f.in_sn = in_sn; f.n = n;
     f.max_sigma = (float)max_sigma; f.out = out; f.out_sn = out_sn; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
     if (fused_supported(f)) {
-        if (workspace && !roi && workspace_bytes < fused_workspace_bytes(f)) return LERF_EINVAL;
+        if (workspace && workspace_bytes < fused_workspace_bytes(f)) return LERF_EINVAL;
         // frames in pinned host memory (read over PCIe from inside the kernel, lerf-pytorch_amd/stream.py) are fetched once per
         // tile into LDS; device frames let stage 1 read its neighbourhood pixels over the vector-memory path (L1 / L2 hits)
-        hipPointerAttribute_t pa;
-        f.host_input = hipPointerGetAttributes(&pa, img) == hipSuccess && pa.type == hipMemoryTypeHost;
+        // (LERF_GEO_INPUT_DEVICE / _HOST: the caller knows where its frames live and saves the runtime query per call)
+        if (geo->flags & (LERF_GEO_INPUT_DEVICE | LERF_GEO_INPUT_HOST)) {
+            f.host_input = (geo->flags & LERF_GEO_INPUT_HOST) != 0;
+        } else {
+            hipPointerAttribute_t pa;
+            f.host_input = hipPointerGetAttributes(&pa, img) == hipSuccess && pa.type == hipMemoryTypeHost;
+        }
         int rc = launch_sr_fused(f, as_stream(stream));
         return rc != LERF_OK ? rc : check_launch();
     }
@@ -463,6 +468,9 @@ int lerf_sr_fused_ragged_u8(const lerf_sr_item_t* items, int n, int C, const ler
         const lerf_sr_item_t& s = items[i];
         if (!s.img || !s.out || s.H < 1 || s.W < 1 || !s.geo.left_r || !s.geo.left_c || !s.geo.dis_r || !s.geo.dis_c) return LERF_EINVAL;
         if (s.geo.S != items[0].geo.S || s.geo.pad_mode != items[0].geo.pad_mode) return LERF_EINVAL;
+        // per-call knobs of the launch: one value for all items (the first item's would silently win otherwise)
+        if (s.geo.tie_queue_cap != items[0].geo.tie_queue_cap || s.geo.flags != items[0].geo.flags) return LERF_EINVAL;
+        // (the float64 tables -- the tie guard -- are honoured frame by frame: FrameDesc.dis_r64)
         all = all && lerf_sr_fused_supported(C, luts, &s.geo, s.H, s.W, kind, max_sigma) && s.geo.roi_h == 0;
     }
     if (!all) {                       // some item has no tile-fused kernel: item by item (same results)

@@ -7,7 +7,6 @@
 // Reference path being replaced: eltr._worker, resample/eval_lut_sr.py:541-665
 // (FourSimplexInterpFaster :24-470 x 24 passes, SteeringGaussianResize2dNumpy /
 // AmplifiedLinearResize2dNumpy, resize_right/resize_right2d_numpy.py:142-282).
-#include <stdlib.h>
 #define LERF_FUSED_NS fused
 #define LERF_FUSED_CH 3
 #include "lerf_fused_impl.h"
@@ -28,8 +27,7 @@ static bool luts_packable(const lerf_luts_t* L) {
 static bool fused_fast(const FusedArgs& a) {
     const lerf_luts_t* L = a.luts;
     if (a.C != 3 || a.items != nullptr) return false;
-    static const bool force_general = getenv("LERF_FORCE_GENERAL") != nullptr;     // diagnostic: A/B of the two kernel families
-    if (force_general) return false;
+    if (a.flags & LERF_GEO_FORCE_GENERAL) return false;                             // diagnostic: A/B of the two kernel families
     if (L->n_modes1 != 3 || L->n_modes2 != 3 || memcmp(L->modes1, "sct", 3) != 0 || memcmp(L->modes2, "sct", 3) != 0) return false;
     return (int64_t)a.oH <= 4 * (int64_t)a.H + 8 && (int64_t)a.oW <= 4 * (int64_t)a.W + 8;      // geometry staging
 }

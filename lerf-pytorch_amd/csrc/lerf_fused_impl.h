@@ -2230,7 +2230,9 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     int bid = xcd_order((int)blockIdx.x, (int)gridDim.x);
     const FrameView F = frame_view<GEN>(P, T, bid);
     const int tyi = bid / F.tiles_x, txi = bid - tyi * F.tiles_x;
-    const int fy0 = tyi * TH, fx0 = txi * TW;
+    // (P.ty_org, P.tx_org) = origin of the stage-1 region: (0, 0) for whole frames, the region of interest widened by the
+    // reach of stages 2 + 3 for a rank's block (launch_fused_t)
+    const int fy0 = P.ty_org + tyi * TH, fx0 = P.tx_org + txi * TW;
     const int iy0 = fy0 - R1, ix0 = fx0 - R1;
     const int H = F.H, W = F.W;
     const uint8_t* __restrict__ img = F.img;
@@ -2406,7 +2408,7 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
             }
     };
     set_s1off(P, 0);
-    bool two = a.workspace != nullptr && !roi;
+    bool two = a.workspace != nullptr;
 #ifdef LERF_STAMPS
     two = false;                 // the diagnostic build keeps the single launch: its stamps live in the workspace
 #endif
@@ -2465,7 +2467,21 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
         P.feat_sn = (int64_t)feat_slice_bytes(a.H, a.W);
         Params Pa = P;
         set_s1off(Pa, 1);
-        hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(NT), DimsA::LDS_BYTES, st, Pa, T);
+        int64_t blocks1 = blocks;
+        if (roi) {
+            // region of interest: stage 1 over the region widened by the reach of stages 2 + 3 (whole 64 x 64 blocks from an
+            // origin on a 4-pixel boundary, so that the feat rows keep their aligned dword stores; a block that reaches past
+            // the widened region computes valid stage-1 values nobody reads)
+            const int reach = R2 + D::R3;
+            const int y0 = a.roi_y - reach > 0 ? a.roi_y - reach : 0, x0 = a.roi_x - reach > 0 ? (a.roi_x - reach) & ~3 : 0;
+            const int y1 = a.roi_y + a.roi_h + reach < a.H ? a.roi_y + a.roi_h + reach : a.H;
+            const int x1 = a.roi_x + a.roi_w + reach < a.W ? a.roi_x + a.roi_w + reach : a.W;
+            Pa.ty_org = y0; Pa.tx_org = x0;
+            Pa.tiles_y = (y1 - y0 + TH - 1) / TH; Pa.tiles_x = (x1 - x0 + TW - 1) / TW;
+            blocks1 = (int64_t)a.n * Pa.tiles_y * Pa.tiles_x;
+            if (blocks1 > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
+        }
+        hipLaunchKernelGGL(ka, dim3((unsigned)blocks1), dim3(NT), DimsA::LDS_BYTES, st, Pa, T);
         hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(NT), D::LDS_BYTES, st, P, T);
         return LERF_OK;
     }

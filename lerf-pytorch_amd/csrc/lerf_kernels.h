@@ -73,6 +73,7 @@ struct FusedArgs {
     int tq_cap;                           // lerf_sr_geo_t.tie_queue_cap
     int pad_mode;                         // LERF_PAD_* of the image operand
     bool host_input;                      // img is (pinned) host memory: the kernels must not re-read pixels from it
+    int flags;                            // lerf_sr_geo_t.flags (LERF_GEO_*)
     const FusedItem* items; int n_items;  // ragged launch (general kernels): frames of different sizes; img/out/H/W/... above unused
 };
 bool fused_supported(const FusedArgs& a);          // some tile-fused kernel covers the configuration

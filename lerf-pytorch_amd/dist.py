@@ -36,6 +36,9 @@ class StripPlan:
             raise ValueError("fewer rows than ranks")
         self.H, self.world, self.rank, self.S = int(H), int(world), int(rank), int(support)
         self.halo = halo_rows(self.S)
+        if world > 1 and H // world < self.halo:
+            # a strip's halo rows must all belong to its two NEIGHBOURS: thinner strips would need rows of ranks further away
+            raise ValueError("strips thinner than the halo (%d rows) are not supported: %d rows over %d ranks" % (self.halo, H, world))
         self.y0 = rank * H // world                 # owned LR rows [y0, y1)
         self.y1 = (rank + 1) * H // world
         self.ylo = max(self.y0 - self.halo, 0)      # rows held locally after the exchange
@@ -120,13 +123,23 @@ class StripBuffer:
             return self.ext
         if (p.H // p.world) < p.halo:
             raise ValueError("strips thinner than the halo (%d rows) are not supported" % p.halo)
+        self.finish(self.post(group))
+        return self.ext
+
+    def post(self, group=None):
+        """pack + post the transfers of this buffer; returns the work handles for finish()"""
+        import torch.distributed as dist
         self._copy(self.sends, self.send_buf, True)
         ops_ = []
         for peer, _, off, nb in self.sends:
             ops_.append(dist.P2POp(dist.isend, self.send_buf[off:off + nb], peer, group))
         for peer, _, off, nb in self.recvs:
             ops_.append(dist.P2POp(dist.irecv, self.recv_buf[off:off + nb], peer, group))
-        for w in dist.batch_isend_irecv(ops_):
+        return dist.batch_isend_irecv(ops_) if ops_ else []
+
+    def finish(self, works):
+        """wait for the transfers of post() (RCCL: the compute stream waits, not the host) and unpack the halo"""
+        for w in works:
             w.wait()
         self._copy(self.recvs, self.recv_buf, False)
         return self.ext
@@ -233,6 +246,12 @@ class BlockPlan:
         self.H, self.W, self.grid, self.world, self.rank, self.S = int(H), int(W), (gy, gx), world, int(rank), int(support)
         self.ry, self.rx = rank // gx, rank % gx
         self.halo = halo_rows(self.S)
+        # the halo of a block must lie inside its 8 ADJACENT blocks (BlockBuffer exchanges with those only): every block at
+        # least `halo` pixels high (if the grid has more than one row) and wide (more than one column).  Smaller blocks would
+        # need pixels of ranks further away, which nobody sends -- the kernel would read uninitialised halo bytes.
+        if (gy > 1 and H // gy < self.halo) or (gx > 1 and W // gx < self.halo):
+            raise ValueError("blocks smaller than the halo (%d pixels) are not supported: %d x %d pixels over a %d x %d grid"
+                             % (self.halo, H, W, gy, gx))
         self.y0, self.y1 = self.ry * H // gy, (self.ry + 1) * H // gy            # owned LR rows / columns
         self.x0, self.x1 = self.rx * W // gx, (self.rx + 1) * W // gx
         self.ylo, self.yhi = max(self.y0 - self.halo, 0), min(self.y1 + self.halo, H)
@@ -277,16 +296,40 @@ class BlockPlan:
             return None
         return ya, xa, yb - ya, xb - xa
 
-    def check_support(self, left_r, left_c):
-        """every source pixel of every owned output pixel is held locally"""
+    def needed_rect(self, left_r, left_c):
+        """global rectangle (y, x, h, w) of the source pixels the owned output pixels depend on, or None"""
         lr = np.asarray(left_r)[self.i0:self.i1]
         lc = np.asarray(left_c)[self.j0:self.j1]
         if len(lr) == 0 or len(lc) == 0:
-            return True
+            return None
         r12 = STAGE1_RADIUS + STAGE2_RADIUS
-        ok_r = max(lr.min() - r12, 0) >= self.ylo and min(lr.max() + self.S - 1 + r12, self.H - 1) < self.yhi
-        ok_c = max(lc.min() - r12, 0) >= self.xlo and min(lc.max() + self.S - 1 + r12, self.W - 1) < self.xhi
-        return bool(ok_r and ok_c)
+        ya, yb = max(int(lr.min()) - r12, 0), min(int(lr.max()) + self.S - 1 + r12, self.H - 1) + 1
+        xa, xb = max(int(lc.min()) - r12, 0), min(int(lc.max()) + self.S - 1 + r12, self.W - 1) + 1
+        return ya, xa, yb - ya, xb - xa
+
+    def check_support(self, left_r, left_c):
+        """every source pixel of every owned output pixel is held locally AND filled: it belongs to the owned block or to
+        the part of an adjacent block that the halo exchange delivers (pixels of blocks further away are never sent)"""
+        need = self.needed_rect(left_r, left_c)
+        if need is None:
+            return True
+        ya, xa, h, w = need
+        if ya < self.ylo or xa < self.xlo or ya + h > self.yhi or xa + w > self.xhi:
+            return False
+        have = np.zeros((h, w), dtype=bool)
+
+        def mark(y0, x0, y1, x1):
+            y0, x0, y1, x1 = max(y0, ya), max(x0, xa), min(y1, ya + h), min(x1, xa + w)
+            if y0 < y1 and x0 < x1:
+                have[y0 - ya:y1 - ya, x0 - xa:x1 - xa] = True
+
+        mark(self.y0, self.x0, self.y1, self.x1)
+        for peer, _, _ in self.neighbours():
+            other = BlockPlan(self.H, self.W, self.grid, peer, self.S, np.zeros(1), np.zeros(1))
+            inc = self._overlap(other)
+            if inc is not None:
+                mark(inc[0], inc[1], inc[0] + inc[2], inc[1] + inc[3])
+        return bool(have.all())
 
 
 class BlockBuffer:
@@ -344,13 +387,23 @@ class BlockBuffer:
         import torch.distributed as dist
         if self.plan.world == 1:
             return self.ext
+        self.finish(self.post(group))
+        return self.ext
+
+    def post(self, group=None):
+        """pack + post the transfers of this buffer; returns the work handles for finish()"""
+        import torch.distributed as dist
         self._copy(self.sends, self.send_buf, True)
         ops_ = []
         for peer, _, off, nb in self.sends:
             ops_.append(dist.P2POp(dist.isend, self.send_buf[off:off + nb], peer, group))
         for peer, _, off, nb in self.recvs:
             ops_.append(dist.P2POp(dist.irecv, self.recv_buf[off:off + nb], peer, group))
-        for w in dist.batch_isend_irecv(ops_):
+        return dist.batch_isend_irecv(ops_) if ops_ else []
+
+    def finish(self, works):
+        """wait for the transfers of post() (RCCL: the compute stream waits, not the host) and unpack the halo"""
+        for w in works:
             w.wait()
         self._copy(self.recvs, self.recv_buf, False)
         return self.ext
@@ -362,11 +415,41 @@ def block_geometry(geo, plan: BlockPlan):
     return geo.block_slice(plan.ylo, lh, plan.i0, plan.i1, plan.xlo, lw, plan.j0, plan.j1, roi=plan.roi)
 
 
-def sr_block(engine, ext, plan: BlockPlan, geo, out=None):
-    """This rank's output rectangle [i0, i1) x [j0, j1) from its extended block.  ONE launch (no stage-1 workspace pass):
-    a block is sized to fill the chip once, and a second launch would only add its tail."""
+def sr_block(engine, ext, plan: BlockPlan, geo, out=None, workspace="auto"):
+    """This rank's output rectangle [i0, i1) x [j0, j1) from its extended block(s) [N, lh, lw, C].
+    workspace="auto": ONE frame -> one launch (stage 1 recomputed on the tile halos: a block is sized to fill the chip once,
+    a second launch would only add its tail); a BATCH of frames -> the two-launch path over the region of interest
+    (stage 1 once per pixel over the owned block widened by 3 + S/2 pixels, then stages 2+3 over the owned block):
+    8 frames of a 1080 x 960 block are 8 x 272 + 8 x 255 workgroups instead of 8 x 255 with 27 % more stage-1 work each.
+    workspace=False / None / a tensor: as ops.sr_fused_u8."""
     from . import ops
-    return ops.sr_fused_u8(ext, engine.luts, block_geometry(geo, plan), engine.kind, engine.max_sigma, out=out, workspace=False)
+    if isinstance(workspace, str):
+        workspace = None if (ext.dim() == 4 and ext.shape[0] > 1) else False
+    return ops.sr_fused_u8(ext, engine.luts, block_geometry(geo, plan), engine.kind, engine.max_sigma, out=out, workspace=workspace)
+
+
+def sr_batch_pipelined(engine, buffers, plan, geo, outs=None, group=None, compute=None):
+    """Halo exchange of part k + 1 of a batch under the kernels of part k.  `buffers`: BlockBuffer / StripBuffer objects
+    (one per part of the batch, e.g. two halves of 4 frames), already filled through `.own`.  All parts are packed and their
+    transfers posted first (RCCL runs them on its own stream; `wait()` only makes the compute stream wait for one part), then
+    every part is unpacked and computed as soon as ITS halo has arrived.  Returns the list of outputs.
+    compute(ext, out) defaults to sr_block / sr_strip on `plan`."""
+    import torch.distributed as dist
+    if compute is None:
+        if isinstance(plan, BlockPlan):
+            compute = lambda ext, out: sr_block(engine, ext, plan, geo, out=out)
+        else:
+            compute = lambda ext, out: sr_strip(engine, ext, plan, geo, out=out)
+    outs = list(outs) if outs is not None else [None] * len(buffers)
+    pending = []
+    for b in buffers:
+        pending.append(b.post(group) if plan.world > 1 else None)
+    res = []
+    for b, works, o in zip(buffers, pending, outs):
+        if works is not None:
+            b.finish(works)
+        res.append(compute(b.ext, o))
+    return res
 
 
 def gather_blocks(out_block, rects, out_hw, group=None):
@@ -402,6 +485,8 @@ def sr_frame_blocks(engine, own_block, H, W, scale, grid=None, group=None, gathe
     geo = engine.sr_geometry((H, W), scale)
     lr, lc = geo.host["left_r"], geo.host["left_c"]
     plan = BlockPlan(H, W, grid, rank, engine.support, lr, lc)
+    if not plan.check_support(lr, lc):
+        raise ValueError("the halo exchange of this block grid does not cover the pixels rank %d needs" % rank)
     buf = BlockBuffer(plan, 1, own_block.shape[-1], own_block.dtype, own_block.device, lr, lc)
     buf.own.copy_(own_block.unsqueeze(0))
     out = sr_block(engine, buf.exchange(group), plan, geo)[0]

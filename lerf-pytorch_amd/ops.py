@@ -66,6 +66,7 @@ class SrGeometry:
         g.pad_mode = getattr(self, "pad_mode", 0)
         g.tie_queue_cap = int(getattr(self, "tie_queue_cap", 0))
         g.roi_y, g.roi_x, g.roi_h, g.roi_w = getattr(self, "roi", (0, 0, 0, 0))
+        g.flags = int(getattr(self, "flags", 0))
         for k in ("left_r", "dis_r", "left_c", "dis_c", "dis_r64", "dis_c64"):
             setattr(g, k, self.t[k].data_ptr())
         self.struct = g
@@ -79,16 +80,33 @@ class SrGeometry:
         g._upload()
         return g
 
+    def with_flags(self, flags):
+        """a copy of this geometry with lerf_sr_geo_t.flags = `flags` (_lib.GEO_*: diagnostic A/B of the kernel families)"""
+        g = object.__new__(SrGeometry)
+        g.__dict__.update(self.__dict__)
+        g.flags = int(flags)
+        g._upload()
+        return g
+
+    def _check_partition_pad(self):
+        # a slice pads at the LOCAL frame borders: wrap padding would wrap inside the strip / block, and the far side of
+        # the frame lives on another rank.  constant / edge / reflect / symmetric only reach pixels next to the global border,
+        # which a slice that touches that border holds itself.
+        if self.pad_mode == _lib.PAD_MODES["wrap"]:
+            raise ValueError("strip / block partitions do not support pad_mode 'wrap' (the far side of the frame is on another rank)")
+
     def row_slice(self, lr_row0, lr_rows, out_row0, out_row1):
         """Geometry of a horizontal strip: the LR rows [lr_row0, lr_row0 + lr_rows) held locally
         (owned rows plus halo) produce the global output rows [out_row0, out_row1).  The row tables
         are the global ones, rebased to the strip -- the kernels never see the strip as a frame of
         its own, so non-integer scales partition exactly like integer ones."""
+        self._check_partition_pad()
         g = object.__new__(SrGeometry)
         g.in_hw = (int(lr_rows), self.in_hw[1])
         g.out_hw = (int(out_row1 - out_row0), self.out_hw[1])
         g.scales, g.S, g.device, g.pad_vec = self.scales, self.S, self.device, self.pad_vec
         g.pad_mode = self.pad_mode
+        g.flags = int(getattr(self, "flags", 0))
         h = self.host
         g.host = dict(left_r=(h["left_r"][out_row0:out_row1] - lr_row0).astype(np.int32),
                       dis_r=h["dis_r"][out_row0:out_row1], dis_r32=h["dis_r32"][out_row0:out_row1],
@@ -212,9 +230,10 @@ def stages_packed(img_u8, luts, workspace=None):
         workspace = fused_workspace(H, W, Cn, N, img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device()))
     elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
         raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
-    _lib.check(_lib.lib().lerf_stages_packed_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(),
-                                                packed.data_ptr(), packed.stride(0), workspace.data_ptr(), workspace.numel(),
-                                                _lib.current_stream()), "lerf_stages_packed_u8")
+    with _lib.on_device(packed):
+        _lib.check(_lib.lib().lerf_stages_packed_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(),
+                                                    packed.data_ptr(), packed.stride(0), workspace.data_ptr(), workspace.numel(),
+                                                    _lib.current_stream()), "lerf_stages_packed_u8")
     return packed[0] if squeeze else packed
 
 
@@ -227,8 +246,8 @@ def stages_packed_ragged(imgs_u8, luts, workspace=None):
     xs = [x.contiguous() for x in imgs_u8]
     Cn = xs[0].shape[-1]
     for x in xs:
-        if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[-1] != Cn or not x.is_cuda:
-            raise ValueError("ragged stages take uint8 [H,W,C] device tensors with one channel count")
+        if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[-1] != Cn or not x.is_cuda or x.device != xs[0].device:
+            raise ValueError("ragged stages take uint8 [H,W,C] tensors of ONE device with one channel count")
     outs = [torch.empty(tuple(x.shape), dtype=torch.int32, device=x.device) for x in xs]
     items = (_lib.StageItem * len(xs))()
     for it, x, o in zip(items, xs, outs):
@@ -238,8 +257,9 @@ def stages_packed_ragged(imgs_u8, luts, workspace=None):
         workspace = _cached_workspace(need, xs[0].device)
     elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
         raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
-    _lib.check(_lib.lib().lerf_stages_packed_ragged_u8(items, len(xs), Cn, luts.ref(), workspace.data_ptr(), workspace.numel(),
-                                                       _lib.current_stream()), "lerf_stages_packed_ragged_u8")
+    with _lib.on_device(xs[0]):
+        _lib.check(_lib.lib().lerf_stages_packed_ragged_u8(items, len(xs), Cn, luts.ref(), workspace.data_ptr(), workspace.numel(),
+                                                           _lib.current_stream()), "lerf_stages_packed_ragged_u8")
     return outs
 
 
@@ -374,6 +394,7 @@ def warp_planar(feat, hypers, geo: WarpGeometry, kind="gauss", max_sigma=10.0, o
 
 # --------------------------------------------------------------------------- fused SR
 _WS = {}
+_WS_MAX = 8
 
 
 def _cached_workspace(need, device):
@@ -382,11 +403,17 @@ def _cached_workspace(need, device):
     of racing for this one."""
     torch = _torch()
     need = max(int(need), 1)
-    key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
-    ws = _WS.get(key)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    # the stream the launch will use: every launch below runs inside `_lib.on_device(tensor)` and passes
+    # _lib.current_stream() of that device -- the same call that forms this key
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    ws = _WS.pop(key, None)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
-        _WS[key] = ws
+    _WS[key] = ws                      # most recently used last
+    while len(_WS) > _WS_MAX:          # streams come and go (stream handles are recycled): keep the cache bounded
+        _WS.pop(next(iter(_WS)))
     return ws
 
 
@@ -449,9 +476,13 @@ def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out
         elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
             raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
         ws_ptr, ws_n = workspace.data_ptr(), workspace.numel()
-    _lib.check(_lib.lib().lerf_sr_fused_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(), geo.ref(),
-                                           KINDS[kind], float(max_sigma), o4.data_ptr(), o4.stride(0),
-                                           ws_ptr, ws_n, _lib.current_stream()), "lerf_sr_fused_u8")
+    # where the frames live travels with the call (no hipPointerGetAttributes per launch)
+    gs = _lib.SrGeo.from_buffer_copy(geo.struct)
+    gs.flags |= _lib.GEO_INPUT_DEVICE if img.is_cuda else _lib.GEO_INPUT_HOST
+    with _lib.on_device(o4):
+        _lib.check(_lib.lib().lerf_sr_fused_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(), C.byref(gs),
+                                               KINDS[kind], float(max_sigma), o4.data_ptr(), o4.stride(0),
+                                               ws_ptr, ws_n, _lib.current_stream()), "lerf_sr_fused_u8")
     return o4[0] if squeeze else o4
 
 
@@ -471,8 +502,10 @@ def sr_fused_ragged_u8(imgs_u8, luts, geos, kind="gauss", max_sigma=10.0, worksp
     xs = [x.contiguous() for x in imgs_u8]
     Cn = xs[0].shape[-1]
     for x, g in zip(xs, geos):
-        if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[-1] != Cn or not x.is_cuda:
-            raise ValueError("ragged SR takes uint8 [H,W,C] device tensors with one channel count")
+        if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[-1] != Cn or not x.is_cuda or x.device != xs[0].device:
+            raise ValueError("ragged SR takes uint8 [H,W,C] tensors of ONE device with one channel count")
+        if g.device != xs[0].device and (g.device.index is not None or xs[0].device.index != torch.cuda.current_device()):
+            raise ValueError("the geometry tables live on another device than the frames")
         if tuple(x.shape[:2]) != g.in_hw:
             raise ValueError("geometry was built for another input size")
     outs = [torch.empty((g.out_hw[0], g.out_hw[1], Cn), dtype=torch.uint8, device=x.device) for x, g in zip(xs, geos)]
@@ -484,9 +517,10 @@ def sr_fused_ragged_u8(imgs_u8, luts, geos, kind="gauss", max_sigma=10.0, worksp
         workspace = _cached_workspace(need, xs[0].device)
     elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
         raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
-    _lib.check(_lib.lib().lerf_sr_fused_ragged_u8(items, len(xs), Cn, luts.ref(), KINDS[kind], float(max_sigma),
-                                                  workspace.data_ptr(), workspace.numel(), _lib.current_stream()),
-               "lerf_sr_fused_ragged_u8")
+    with _lib.on_device(xs[0]):
+        _lib.check(_lib.lib().lerf_sr_fused_ragged_u8(items, len(xs), Cn, luts.ref(), KINDS[kind], float(max_sigma),
+                                                      workspace.data_ptr(), workspace.numel(), _lib.current_stream()),
+                   "lerf_sr_fused_ragged_u8")
     return outs
 
 
@@ -504,5 +538,6 @@ def rect_copy(frames_u8, staging_u8, rects, to_staging):
         a.y, a.x, a.h, a.w, a.off = int(y), int(x), int(h), int(w), int(off)
         if off + N * h * w * Cn > staging_u8.numel():
             raise ValueError("staging buffer too small")
-    _lib.check(_lib.lib().lerf_rect_copy_u8(frames_u8.data_ptr(), N, fh, fw, Cn, staging_u8.data_ptr(), arr, len(rects),
-                                            1 if to_staging else 0, _lib.current_stream()), "lerf_rect_copy_u8")
+    with _lib.on_device(frames_u8):
+        _lib.check(_lib.lib().lerf_rect_copy_u8(frames_u8.data_ptr(), N, fh, fw, Cn, staging_u8.data_ptr(), arr, len(rects),
+                                                1 if to_staging else 0, _lib.current_stream()), "lerf_rect_copy_u8")

@@ -47,6 +47,28 @@ def test_block_grid_and_single_round_of_tiles(oracle):
         assert -(-rh // 64) * -(-rw // 64) == 255     # one round of workgroups on 256 CUs (strips: 300)
 
 
+@pytest.mark.parametrize("H,W,grid", [(24, 24, (2, 4)), (40, 40, (1, 8)), (13, 200, (2, 2))])
+def test_blocks_smaller_than_the_halo_are_refused(oracle, H, W, grid):
+    """a block narrower / lower than the 7-pixel halo needs pixels of a NON-adjacent rank, which the
+    8-neighbour exchange never delivers -- the plan must refuse instead of letting the kernel read uninitialised halo"""
+    lr, _, _, _ = oracle.sr_axis_tables(H, 2 * H, 2.0, 2)
+    lc, _, _, _ = oracle.sr_axis_tables(W, 2 * W, 2.0, 2)
+    with pytest.raises(ValueError, match="smaller than the halo"):
+        ldist.BlockPlan(H, W, grid, 0, 2, lr, lc)
+
+
+def test_check_support_sees_uncovered_halo_pixels(oracle):
+    """check_support verifies COVERAGE (owned block + what the adjacent blocks send), not just the local extent"""
+    H, W, grid = 64, 64, (2, 2)
+    lr, _, _, _ = oracle.sr_axis_tables(H, 2 * H, 2.0, 2)
+    lc, _, _, _ = oracle.sr_axis_tables(W, 2 * W, 2.0, 2)
+    p = ldist.BlockPlan(H, W, grid, 0, 2, lr, lc)
+    assert p.check_support(lr, lc)
+    q = ldist.BlockPlan(H, W, grid, 0, 2, lr, lc)
+    q.neighbours = lambda: [n for n in ldist.BlockPlan.neighbours(q) if n[1] == 0 or n[2] == 0]      # drop the corner peer
+    assert not q.check_support(lr, lc)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -76,6 +98,14 @@ def _worker(rank, world, grid, port, H, W, scale, tmp):
         ext = buf.exchange()
         ok = ok and ext.data_ptr() == buf.ext.data_ptr()
         ok = ok and np.array_equal(ext[1].numpy(), img[plan.ylo:plan.yhi, plan.xlo:plan.xhi])
+    # two parts of a batch, the exchange of part 2 posted before part 1 is consumed (dist.sr_batch_pipelined)
+    parts = [ldist.BlockBuffer(plan, 1, 3, torch.uint8, None, lr, lc) for _ in range(2)]
+    for k, b in enumerate(parts):
+        b.ext.zero_()
+        b.own.copy_(((own.to(torch.int32) + k) % 256).to(torch.uint8).unsqueeze(0))
+    got = ldist.sr_batch_pipelined(None, parts, plan, None, compute=lambda e, o: e.clone())
+    for k, g in enumerate(got):
+        ok = ok and np.array_equal(g[0].numpy(), ((img[plan.ylo:plan.yhi, plan.xlo:plan.xhi].astype(np.int32) + k) % 256).astype(np.uint8))
     # per-block compute with the checker: LUT stages on the local frame alone (wrong only in the outer ring of an
     # artificial border, which stage 3 of the owned outputs never reads), stage 3 with the GLOBAL geometry
     luts = O.load_luts(os.path.join(ASSETS, "lerf-g"))

@@ -34,6 +34,13 @@ def test_plan_covers_rows_and_support(oracle, H, world, S, scale):
     assert all(outs[i][1] == outs[i + 1][0] for i in range(world - 1))
 
 
+def test_strips_thinner_than_the_halo_are_refused(oracle):
+    left, _, _, _ = oracle.sr_axis_tables(20, 40, 2.0, 2)
+    with pytest.raises(ValueError, match="thinner than the halo"):
+        ldist.StripPlan(20, 4, 1, 2, left)
+    ldist.StripPlan(20, 1, 0, 2, left)          # a world of one has no halo to exchange
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -208,6 +208,79 @@ def test_blocks_emulated_equal_full_frame(torch, H, W, scale, grid, S):
     assert torch.equal(out, full)
 
 
+@pytest.mark.parametrize("H,W,scale,grid,S,model", [(200, 260, 2, (2, 4), 2, "lerf-g"), (150, 131, 1.5, (2, 2), 2, "lerf-g"),
+                                                    (140, 150, 3, (2, 3), 4, "lerf-g"), (97, 128, 2.4, (1, 2), 2, "lerf-g"),
+                                                    (300, 280, 2, (2, 2), 2, "lerf-l"), (280, 304, (1.5, 2.0), (2, 2), 2, "lerf-l")])
+def test_blocks_batched_two_launch_roi_equal_full_frame(torch, H, W, scale, grid, S, model):
+    """round 4: a BATCH of blocks takes the two-launch path over the region of interest -- stage 1 once per pixel over the
+    owned block widened by 3 + S/2 pixels, stages 2+3 over the owned block -- rank by rank on one GPU, stitched == the full
+    frames bit for bit; the workspace starts out poisoned (nothing outside the stage-1 region may be read for an owned output)"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import dist as ldist, ops
+    eng = L.LerfEngine.shipped(model, support=S)
+    N = 3
+    x = torch.from_numpy(np.random.default_rng(H * W).integers(0, 256, (N, H, W, 3), dtype=np.uint8)).cuda()
+    geo = eng.sr_geometry((H, W), scale)
+    full = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma)
+    lr, lc = geo.host["left_r"], geo.host["left_c"]
+    out = torch.zeros_like(full)
+    for r in range(grid[0] * grid[1]):
+        p = ldist.BlockPlan(H, W, grid, r, S, lr, lc)
+        ext = x[:, p.ylo:p.yhi, p.xlo:p.xhi].contiguous()
+        lh, lw = p.local_hw
+        ws = torch.full((int(_ws_bytes(lh, lw, 3, N)),), 0xA5 if r % 2 else 0x00, dtype=torch.uint8, device="cuda")
+        i0, i1, j0, j1 = p.out_rect()
+        got = ldist.sr_block(eng, ext, p, geo, workspace=ws)
+        assert torch.equal(got, ldist.sr_block(eng, ext, p, geo, workspace=False))     # two launches == one launch
+        out[:, i0:i1, j0:j1] = got
+    assert torch.equal(out, full)
+
+
+def _ws_bytes(H, W, C, N):
+    from lerf_pytorch_amd import _lib
+    return _lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, N)
+
+
+def test_ragged_launch_of_more_than_64_frames_and_its_argument_checks(torch, oracle):
+    """the outer loop of the ragged API (64 items per FusedArgs, 16 per launch pair); items that disagree on the per-call
+    knobs (tie_queue_cap, flags) are refused instead of silently taking the first item's"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import ops
+    eng = L.LerfEngine.shipped("lerf-g")
+    rng = np.random.default_rng(70)
+    shapes = [(8 + (3 * i) % 23, 10 + (5 * i) % 31) for i in range(70)]
+    imgs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).cuda() for h, w in shapes]
+    geos = {}
+    for h, w in shapes:
+        geos.setdefault((h, w), eng.sr_geometry((h, w), 2))
+    outs = ops.sr_fused_ragged_u8(imgs, eng.luts, [geos[s] for s in shapes], eng.kind, eng.max_sigma)
+    for i in (0, 15, 16, 63, 64, 69):
+        assert torch.equal(outs[i], eng.sr(imgs[i], 2))
+    gl = [geos[s] for s in shapes[:3]]
+    with pytest.raises(ValueError):
+        ops.sr_fused_ragged_u8(imgs[:3], eng.luts, [gl[0], gl[1].with_tie_queue_cap(8), gl[2]], eng.kind, eng.max_sigma)
+    with pytest.raises(ValueError):
+        ops.sr_fused_ragged_u8(imgs[:3], eng.luts, [gl[0], gl[1], gl[2].with_flags(1)], eng.kind, eng.max_sigma)
+
+
+def test_force_general_flag_and_partition_pad_guard(torch):
+    """lerf_sr_geo_t.flags replaces the LERF_FORCE_GENERAL environment variable of round 3 (the ABI reads no environment):
+    the general kernels give the specialised kernels' bytes; strips / blocks refuse wrap padding"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import _lib, ops
+    eng = L.LerfEngine.shipped("lerf-g")
+    x = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (2, 150, 210, 3), dtype=np.uint8)).cuda()
+    geo = eng.sr_geometry((150, 210), 2)
+    a = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma)
+    b = ops.sr_fused_u8(x, eng.luts, geo.with_flags(_lib.GEO_FORCE_GENERAL), eng.kind, eng.max_sigma)
+    assert torch.equal(a, b)
+    gw = ops.SrGeometry((150, 210), 2, support=2, pad_mode=_lib.PAD_MODES["wrap"])
+    with pytest.raises(ValueError, match="wrap"):
+        gw.row_slice(0, 80, 0, 150)
+    with pytest.raises(ValueError, match="wrap"):
+        gw.block_slice(0, 80, 0, 150, 0, 100, 0, 190)
+
+
 def test_rect_copy_round_trip(torch):
     from lerf_pytorch_amd import ops
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -241,7 +314,7 @@ def test_batched_packed_warp_equals_frame_by_frame(torch):
             assert torch.equal(torch.nan_to_num(a[b].float()), torch.nan_to_num(one.float()))
 
 
-def test_abi4_argument_checks(torch):
+def test_abi_argument_checks(torch):
     import ctypes as C
     import lerf_pytorch_amd as L
     from lerf_pytorch_amd import _lib, ops
