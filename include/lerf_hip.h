@@ -354,6 +354,12 @@ int lerf_resize_bwd_f32(const float* feat, const float* h0, const float* h1, con
 size_t lerf_srnet_weight_floats(int outC);
 int lerf_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut, float* y, void* stream);
 
+/* ---- calibration (bench.py roofline_lds): `workgroups` x 1024 threads, each wave issuing 10 x `iters` ds_read_b32 gathers
+ * into a 134-KB LDS table -- pattern 0: random addresses (the rate a data-dependent LUT gather gets), pattern 1:
+ * conflict-free.  The caller times the launch (one workgroup per CU: wave-gathers per CU = 160 x iters) and owns `sink`
+ * (4 bytes of device memory, practically never written).  Not part of the reference's path: a ruler for it. */
+int lerf_ubench_lds_gather(int pattern, int iters, int workgroups, uint32_t* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

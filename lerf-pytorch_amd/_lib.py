@@ -45,7 +45,7 @@ EXPORTS = [
     "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed", "lerf_rect_copy_u8",
     "lerf_metric_y_sse_u8", "lerf_metric_ssim_y_u8", "lerf_metric_masked_sse_u8",
     "lerf_swf2lut_interp_f32", "lerf_swf2lut_interp_bwd_f32", "lerf_resize_bwd_f32",
-    "lerf_srnet_weight_floats", "lerf_srnet_to_lut",
+    "lerf_srnet_weight_floats", "lerf_srnet_to_lut", "lerf_ubench_lds_gather",
 ]
 
 
@@ -182,6 +182,7 @@ def lib():
     L.lerf_srnet_weight_floats.restype = C.c_size_t
     L.lerf_srnet_weight_floats.argtypes = [C.c_int]
     L.lerf_srnet_to_lut.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lerf_ubench_lds_gather.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     for name in EXPORTS:          # AttributeError here = the .so does not match include/lerf_hip.h
         getattr(L, name)
     if L.lerf_abi_version() != 5:

@@ -360,6 +360,12 @@ int lerf_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut,
     return rc != LERF_OK ? rc : check_launch();
 }
 
+int lerf_ubench_lds_gather(int pattern, int iters, int workgroups, uint32_t* sink, void* stream) {
+    if ((pattern != 0 && pattern != 1) || iters < 1 || workgroups < 1 || !sink) return LERF_EINVAL;
+    int rc = launch_ubench_lds_gather(pattern, iters, workgroups, sink, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
 static size_t general_workspace_bytes(int H, int W, int C, int n) { return (size_t)n * H * W * C * 4; }
 
 size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {

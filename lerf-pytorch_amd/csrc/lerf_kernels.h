@@ -94,6 +94,9 @@ int launch_stages_fused_c4(const FusedArgs& a, hipStream_t st);
 size_t srnet_weight_floats(int outC);
 int launch_srnet_to_lut(const float* weights, int outC, int interval, int8_t* lut, float* y, hipStream_t st);
 
+// lerf_ubench.hip
+int launch_ubench_lds_gather(int pattern, int iters, int blocks, uint32_t* sink, hipStream_t st);
+
 int launch_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, hipStream_t st);
 int launch_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, int W, int C, const WarpGeo& geo, int kind,
                        float max_sigma, void* out, int out_dtype, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn, hipStream_t st);

@@ -23,15 +23,19 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
         raise ValueError("interval must be 1..7 (q = 2**interval, L = 2**(8-interval)+1, :27-28)")
     dy, dx = _lib.mode_offsets(mode, 0)            # ValueError("Mode x not implemented.")
     torch = _lib.require_gpu()
+    from .. import lazy
+    if isinstance(img_in, lazy.DeviceArray):           # a result of an earlier call, still in HBM (lazy.py)
+        img_in, lazy_out = img_in.t, True
+    else:
+        lazy_out = False
     as_numpy = not isinstance(img_in, torch.Tensor)
     if as_numpy:
-        img = torch.from_numpy(np.ascontiguousarray(np.asarray(img_in))).cuda()
-        lut = torch.from_numpy(np.ascontiguousarray(np.asarray(weight))).cuda()
+        img = _upload_image(torch, np.asarray(img_in))
+        lut = _device_lut(torch, weight, oC, img.device)
     else:
-        img, lut = img_in, weight.to(img_in.device)
+        img = img_in
+        lut = _device_lut(torch, weight, oC, img.device)
     img = img.round().clamp(0, 255).to(torch.uint8) if img.dtype != torch.uint8 else img
-    lut = lut.reshape(-1, oC)
-    lut = lut.round().to(torch.int8) if lut.dtype != torch.int8 else lut
     pad = mode_pad_dict[mode]
     if img.shape[1] < h + pad or img.shape[2] < w + pad:
         raise ValueError("img_in must be padded by {} pixels for mode {}".format(pad, mode))
@@ -39,4 +43,40 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
     Cn = img.shape[0]
     out = num.reshape(Cn * oC, h, w)
     out = torch.rot90(out, int(rot), [1, 2]).to(torch.float64) / float(2 ** interval)
+    if lazy_out or (as_numpy and lazy.enabled()):
+        return lazy.DeviceArray(out)                   # numpy-shaped, device-backed: the caller's += / clip / round stay in HBM
     return out.cpu().numpy() if as_numpy else out
+
+
+def _upload_image(torch, a):
+    """[C, H, W] numpy image -> device.  The call sites hand over `np.pad(...).transpose((2, 0, 1))` (:551-553): a
+    transposed VIEW of a contiguous HWC array -- that buffer is uploaded as it lies (no host-side gather) and viewed as
+    [C, H, W] on the device."""
+    from .. import lazy
+    if a.ndim == 3 and not a.flags.c_contiguous and a.transpose(1, 2, 0).flags.c_contiguous:
+        return lazy.upload(a.transpose(1, 2, 0)).permute(2, 0, 1)
+    return lazy.upload(np.ascontiguousarray(a))
+
+
+# device copies of the LUT arrays the caller passes again and again (9 per model, 24 calls per image): keyed by the
+# host buffer, checked against a strided sample of its values so that an array mutated in place is uploaded afresh
+_LUTS = {}
+
+
+def _device_lut(torch, weight, oC, device):
+    if isinstance(weight, torch.Tensor):
+        lut = weight.to(device).reshape(-1, oC)
+        return lut.round().to(torch.int8) if lut.dtype != torch.int8 else lut
+    w = np.asarray(weight)
+    key = (w.__array_interface__["data"][0], w.shape, w.dtype.str, int(oC), str(device))
+    flat = w.reshape(-1)
+    sample = flat[::max(1, flat.size // 257)].copy()
+    hit = _LUTS.get(key)
+    if hit is not None and hit[0].shape == sample.shape and np.array_equal(hit[0], sample):
+        return hit[1]
+    lut = torch.from_numpy(np.ascontiguousarray(w)).to(device).reshape(-1, oC)
+    lut = lut.round().to(torch.int8) if lut.dtype != torch.int8 else lut
+    if len(_LUTS) >= 32:
+        _LUTS.pop(next(iter(_LUTS)))
+    _LUTS[key] = (sample, lut, w)                       # `w` keeps the buffer (and with it the key) alive
+    return lut

@@ -16,8 +16,21 @@ from .. import _lib, ops
 
 
 def _to_dev(a):
+    """numpy array -> float32 device tensor; a lazy.DeviceArray (a result that never left the device) is used in place"""
     torch = _lib.require_gpu()
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).cuda()
+    from .. import lazy
+    if isinstance(a, lazy.DeviceArray):
+        return a.t.to(torch.float32)
+    return lazy.upload(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+
+
+def _result(out, inputs):
+    """float64 device result -> what the caller gets: a device-backed array when the inputs were device-backed (or lazy
+    results are enabled), else the numpy array of the reference's contract"""
+    from .. import lazy
+    if lazy.enabled() or any(isinstance(a, lazy.DeviceArray) for a in inputs):
+        return lazy.DeviceArray(out)
+    return out.cpu().numpy()
 
 
 class Resize2dNumpy(object):
@@ -92,7 +105,7 @@ class Resize2dNumpy(object):
             raise ValueError("input shape {} does not match set_shape({})".format(list(x.shape), self.in_shape))
         hs = [_to_dev(h) for h in hypers]
         out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f64")
-        return out.cpu().numpy()
+        return _result(out, [input] + list(hypers))
 
 
 class SteeringGaussianResize2dNumpy(Resize2dNumpy):
@@ -141,7 +154,7 @@ class Warp2dNumpy(object):
         if list(x.shape) != list(self.in_shape):
             raise ValueError("input shape {} does not match set_shape({})".format(list(x.shape), self.in_shape))
         hs = [_to_dev(h) for h in hypers]
-        return ops.warp_planar(x, hs, self.geo, kind, max_sigma, out="f64").cpu().numpy()
+        return _result(ops.warp_planar(x, hs, self.geo, kind, max_sigma, out="f64"), [input] + list(hypers))
 
 
 class NearestWarp2dNumpy(Warp2dNumpy):

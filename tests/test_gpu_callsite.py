@@ -1,0 +1,111 @@
+"""The unchanged-call-site path: the reference's _worker protocol (tools/callsite_driver.py:
+24 FourSimplexInterpFaster calls + set_shape + resize, numpy calls in between, resample/eval_lut_sr.py:541-665) driven
+against the mirrored names.  The bytes must be the reference's own (g5 md5s of its Set5 outputs), with the device-backed
+lazy arrays (lerf_pytorch_amd.lazy) and with plain numpy results alike; and DeviceArray must answer the numpy operations
+of the call sites exactly as numpy does."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import ASSETS, DATA, GOLDEN
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "GPU tests need an MI355X"
+    return t
+
+
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("lazy_on", [True, False])
+@pytest.mark.parametrize("model,scale", [("lerf-g", 2), ("lerf-g", 3), ("lerf-l", 2), ("lerf-l", 4)])
+def test_worker_protocol_gives_the_reference_bytes(torch, oracle, model, scale, lazy_on):
+    import callsite_driver as cd
+    from lerf_pytorch_amd import lazy
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["sr"]
+    linear = model == "lerf-l"
+    luts = cd.float_luts(oracle.load_luts(os.path.join(ASSETS, model), linear=linear))
+    interp, pads, resizer = cd.mirror_api(linear=linear)
+    lazy.set_enabled(lazy_on)
+    try:
+        for n in ("baby", "butterfly", "woman"):
+            lr = np.array(Image.open(os.path.join(DATA, "LR_bicubic/rrLR_X%.2f_%.2f" % (scale, scale), n + ".png"))).astype(np.float32)
+            out = cd.worker_sr(interp, pads, resizer, luts, lr, (scale, scale), out_c=1 if linear else 3, linear=linear)
+            assert isinstance(out, lazy.DeviceArray) == lazy_on
+            o8 = np.asarray(out)
+            assert o8.dtype == np.uint8 and list(o8.shape) == ref["%s/x%d/%s" % (model, scale, n)]["shape"]
+            assert _md5(o8) == ref["%s/x%d/%s" % (model, scale, n)]["md5_out"]
+            assert np.array_equal(np.array(Image.fromarray(out)), o8)            # PIL takes it through __array_interface__
+    finally:
+        lazy.set_enabled(True)
+
+
+def test_device_array_answers_like_numpy(torch):
+    """every operation the call sites apply between the library calls, DeviceArray against the same numpy expression"""
+    from lerf_pytorch_amd import lazy
+    rng = np.random.default_rng(0)
+    a64 = rng.integers(-2032, 2033, (9, 37, 41)).astype(np.float64) / 16.0
+    b64 = rng.integers(-2032, 2033, (9, 37, 41)).astype(np.float64) / 16.0
+    A, B = lazy.asdevice(a64), lazy.asdevice(b64)
+    eq = lambda d, n: isinstance(d, lazy.DeviceArray) and d.dtype == n.dtype and d.shape == n.shape and np.array_equal(np.asarray(d), n)
+    p_d, p_n = 0, 0
+    p_d += A
+    p_n += a64
+    p_d += B
+    p_n = p_n + b64
+    assert eq(p_d, p_n)
+    for avg, bias in ((3, 0), (12, 127)):
+        d = np.round(np.clip((p_d / avg) + bias, 0, 255)).astype(np.float32).transpose((1, 2, 0))
+        n = np.round(np.clip((p_n / avg) + bias, 0, 255)).astype(np.float32).transpose((1, 2, 0))
+        assert eq(d, n)
+        assert eq(d / float(255), n / float(255))
+        for r in range(4):
+            dr, nr = np.rot90(d, r), np.rot90(n, r)
+            assert eq(dr, nr)
+            assert eq(np.pad(dr, ((0, 3), (0, 3), (0, 0)), mode="edge").transpose((2, 0, 1)),
+                      np.pad(nr, ((0, 3), (0, 3), (0, 0)), mode="edge").transpose((2, 0, 1)))
+    idx = list(range(1, 10, 3))
+    assert eq(A[idx, :, :], a64[idx, :, :])
+    assert eq(np.clip(np.round(A).transpose((1, 2, 0)), 0, 255).astype(np.uint8), np.clip(np.round(a64).transpose((1, 2, 0)), 0, 255).astype(np.uint8))
+    # ties round to even, like np.round
+    t = np.array([0.5, 1.5, 2.5, -0.5, 254.5, 255.5])
+    assert eq(np.round(lazy.asdevice(t)), np.round(t))
+    # everything else happens on the host copy, with numpy's own result
+    assert float(A.max()) == a64.max() and np.allclose(np.mean(A), a64.mean()) and np.array_equal(np.abs(A), np.abs(a64))
+    assert np.array_equal(np.dot(A[0], np.ones(41)), np.dot(a64[0], np.ones(41)))
+
+
+def test_interp_accepts_device_arrays_and_caches_luts(torch, oracle):
+    """a lazy result fed back as img_in (stage 2 of the call sites) == the numpy route; a LUT array mutated in place is
+    uploaded afresh"""
+    from lerf_pytorch_amd import lazy
+    from lerf_pytorch_amd.resample.eval_lut_sr import FourSimplexInterpFaster
+    luts = oracle.load_luts(os.path.join(ASSETS, "lerf-g"))
+    w = luts["s2_cr1"].astype(np.float32)
+    img = np.random.default_rng(3).integers(0, 256, (3, 30 + 3, 44 + 3)).astype(np.float32)
+    lazy.set_enabled(False)
+    try:
+        want = FourSimplexInterpFaster(w, img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
+    finally:
+        lazy.set_enabled(True)
+    assert isinstance(want, np.ndarray)
+    got = FourSimplexInterpFaster(w, lazy.asdevice(img), 30, 44, 4, 1, upscale=1, mode="c", oC=3)
+    assert isinstance(got, lazy.DeviceArray) and np.array_equal(np.asarray(got), want)
+    assert np.array_equal(np.asarray(FourSimplexInterpFaster(w, img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)), want)
+    w[::7] = 5.0                                          # same buffer, new values: the cached device copy must not be used
+    changed = FourSimplexInterpFaster(w, img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
+    fresh = FourSimplexInterpFaster(w.copy(), img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)     # another buffer: no cache hit possible
+    assert np.array_equal(np.asarray(changed), np.asarray(fresh)) and not np.array_equal(np.asarray(changed), want)

@@ -74,3 +74,33 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): ops.sr_fused_u8(ext, eng.luts, lgw, "gauss", 10.0, out=o)
 torch.cuda.synchronize()
 print("block 5 without the region of interest (tiles over block + halo: 18 x 16 = 288, two launches): %.3f ms" % ((time.perf_counter() - t) / 10 * 1e3))
+
+# ---- round 4: the 8 frames of a bench step as 2 x 4 blocks, one rank's blocks in ONE launch pair over the region of interest
+#      (stage 1 once per pixel over block + 4 px: 8 x 272 workgroups, stages 2+3 over the owned block: 8 x 255) against the
+#      single-launch form (stage 1 recomputed on every tile's halo) and against 1/8 of the whole-frame batch
+full8 = 8 * dt / B
+tb2, tb1 = [], []
+stitched = torch.zeros((8, 4320, 7680, 3), dtype=torch.uint8, device="cuda")
+for r in range(8):
+    plan = ldist.BlockPlan(2160, 3840, (2, 4), r, 2, lr_, lc_)
+    ext8 = x8[:, plan.ylo:plan.yhi, plan.xlo:plan.xhi].contiguous()
+    lg = ldist.block_geometry(geo, plan)
+    o2 = ops.sr_fused_u8(ext8, eng.luts, lg, "gauss", 10.0)                       # workspace from the cache: two launches
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): ops.sr_fused_u8(ext8, eng.luts, lg, "gauss", 10.0, out=o2)
+    torch.cuda.synchronize(); tb2.append((time.perf_counter() - t) / 5)
+    if r in (0, 5):
+        o1 = ops.sr_fused_u8(ext8, eng.luts, lg, "gauss", 10.0, workspace=False)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(5): ops.sr_fused_u8(ext8, eng.luts, lg, "gauss", 10.0, out=o1, workspace=False)
+        torch.cuda.synchronize(); tb1.append((time.perf_counter() - t) / 5)
+        assert torch.equal(o1, o2)
+    i0, i1, j0, j1 = plan.out_rect()
+    stitched[:, i0:i1, j0:j1] = o2
+whole8 = torch.empty((8, 4320, 7680, 3), dtype=torch.uint8, device="cuda")
+for h in range(2): ops.sr_fused_u8(x8[4 * h:4 * h + 4], eng.luts, geo, "gauss", 10.0, out=whole8[4 * h:4 * h + 4])
+print("per-rank ms (two-launch ROI, 8 frames):", " ".join("%.3f" % (t * 1e3) for t in tb2))
+print("8 frames x 8 blocks (two-launch ROI) stitched == whole frames:", bool(torch.equal(stitched, whole8)))
+print("8 frames, one rank's BLOCKS, two launches over the region of interest: %.3f ms max, %.3f ms mean (single launch, stage 1 per tile halo: %.3f ms) "
+      "vs 1/8 of the whole-frame batch %.3f ms -> strong-scaling efficiency of the compute part %.0f %% (single launch %.0f %%; strips %.0f %%)"
+      % (max(tb2) * 1e3, np.mean(tb2) * 1e3, max(tb1) * 1e3, full8 / 8 * 1e3, 100 * full8 / 8 / max(tb2), 100 * full8 / 8 / max(tb1), 100 * full8 / 8 / d8))

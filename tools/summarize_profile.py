@@ -99,17 +99,31 @@ out += ["", "one step (both launches):",
            tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]))]
 open(os.path.join(dst, label + "_pmc_summary.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
-if "--no-json" not in sys.argv and bench["config"]["baseline_config"] == 2 and not extra_args:
+if "--no-json" not in sys.argv:
     import bench as B
-    json.dump({"frames": bench["config"]["frames_per_step_per_gpu"], "input": bench["config"]["input"], "bytes_per_launch": int(2 * fetch + write),
-               "valu_instr_per_cu_cycle": round(tot["SQ_INSTS_VALU"] / cu, 3),
-               "valu_busy": round(tot["SQ_ACTIVE_INST_VALU"] * 4 / tot["SQ_WAVE_CYCLES"], 3),
-               "lds_array_busy": round(tot["SQ_LDS_IDX_ACTIVE"] / cu, 3),
-               "lds_bank_conflict_share": round(tot["SQ_LDS_BANK_CONFLICT"] / max(tot["SQ_LDS_IDX_ACTIVE"], 1.0), 3),
-               "l2_hit_rate": round(tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 4),
-               "kernel_trace_avg_us": round(step_us, 1), "fetch_size_bytes_raw": int(fetch), "write_size_bytes": int(write),
-               "kernel_src_sha16": B.kernel_source_sha(),
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) x 1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per "
-                       "128-B streaming request; the 1-B/lane input-tile reads are uncalibrated, so this is an upper bound)",
-               "source": "profiles/%s_pmc_summary.txt" % label},
-              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    cfgd = bench["config"]
+    cfg = cfgd["baseline_config"]
+    S = 4 if "S=4" in cfgd["workload"] else 2
+    key = B.traffic_key(cfg, S, cfgd.get("channels", 3), cfgd.get("scale", [2.0, 2.0]), cfgd["frames_per_step_per_gpu"], cfgd["input"])
+    path = os.path.join(dst, "hbm_traffic.json")
+    try:
+        allj = json.load(open(path))
+        if "entries" not in allj:
+            allj = {"entries": {}}
+    except (OSError, ValueError):
+        allj = {"entries": {}}
+    allj["note"] = ("one entry per profiled workload (key = bench.traffic_key); bench.py attaches an entry to `roofline.traffic` only when its "
+                    "kernel_src_sha16 equals the sha of the kernel sources being run")
+    allj["entries"][key] = {
+        "frames": cfgd["frames_per_step_per_gpu"], "input": cfgd["input"], "bytes_per_launch": int(2 * fetch + write),
+        "valu_instr_per_cu_cycle": round(tot["SQ_INSTS_VALU"] / cu, 3),
+        "valu_busy": round(tot["SQ_ACTIVE_INST_VALU"] * 4 / tot["SQ_WAVE_CYCLES"], 3),
+        "lds_array_busy": round(tot["SQ_LDS_IDX_ACTIVE"] / cu, 3),
+        "lds_bank_conflict_share": round(tot["SQ_LDS_BANK_CONFLICT"] / max(tot["SQ_LDS_IDX_ACTIVE"], 1.0), 3),
+        "l2_hit_rate": round(tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 4),
+        "kernel_trace_avg_us": round(step_us, 1), "fetch_size_bytes_raw": int(fetch), "write_size_bytes": int(write),
+        "kernel_src_sha16": B.kernel_source_sha(),
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) x 1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per "
+                "128-B streaming request; the 1-B/lane input-tile reads are uncalibrated, so this is an upper bound)",
+        "source": "profiles/%s_pmc_summary.txt" % label}
+    json.dump(allj, open(path, "w"), indent=1)
