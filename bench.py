@@ -735,7 +735,16 @@ def run_callsite(args):
                       "bytes_equal_engine_path": bool(np.array_equal(out, want))}
         return dt
 
+    # what the CALLER itself spends in numpy before the library sees a pixel: the 12 rot90 + edge pad + transpose of stage 1 on
+    # its host image (stage 2's run on the library's lazy result); no drop-in can take that away from an unchanged call site
+    t0 = time.perf_counter()
+    for m in "sct":
+        for r in range(4):
+            rot = np.rot90(img, r)
+            np.pad(rot, ((0, pads[m]), (0, pads[m]), (0, 0)), mode="edge").transpose((2, 0, 1))
+    t_caller = time.perf_counter() - t0
     t_lazy = run("lazy_device_arrays", True, False, max(3, args.steps // 5))
+    legs["lazy_device_arrays"]["of_which_caller_numpy_ms"] = round(t_caller * 1e3, 2)
     run("lazy_plus_asdevice_line", True, True, max(3, args.steps // 5))
     t_naive = run("naive_numpy_round_trips", False, False, 2)
     t_eng = []

@@ -203,15 +203,23 @@ class DeviceArray(object):
     def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
     def __rmul__(self, o): return self._bin(o, lambda a, b: a * b, True)
 
-    def __truediv__(self, o):
+    # Division by a host scalar: torch multiplies by the reciprocal when the divisor is a CPU scalar (one rounding more than
+    # numpy's IEEE division: (N / 16) / 3 at N = 48 k + 24 must be exactly k + 0.5 for the round-half-even that follows).
+    # The scalar therefore travels as a 0-dim DEVICE tensor of the array's dtype: a true division.
+    def _div(self, o, reflected):
         torch = _torch()
         t = self.t if self.t.is_floating_point() else self.t.to(torch.float64)    # numpy: int / x -> float64
-        return DeviceArray(t)._bin(o, lambda a, b: a / b)
+        if isinstance(o, (np.generic,)) or (isinstance(o, np.ndarray) and o.ndim == 0):
+            o = o.item()
+        if isinstance(o, (int, float, bool)):
+            o = DeviceArray(torch.full((), float(o), dtype=t.dtype, device=t.device))
+        return DeviceArray(t)._bin(o, lambda a, b: torch.true_divide(a, b), reflected)
+
+    def __truediv__(self, o):
+        return self._div(o, False)
 
     def __rtruediv__(self, o):
-        torch = _torch()
-        t = self.t if self.t.is_floating_point() else self.t.to(torch.float64)
-        return DeviceArray(t)._bin(o, lambda a, b: a / b, True)
+        return self._div(o, True)
 
     def __neg__(self): return DeviceArray(-self.t)
 

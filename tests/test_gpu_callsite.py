@@ -80,6 +80,11 @@ def test_device_array_answers_like_numpy(torch):
     idx = list(range(1, 10, 3))
     assert eq(A[idx, :, :], a64[idx, :, :])
     assert eq(np.clip(np.round(A).transpose((1, 2, 0)), 0, 255).astype(np.uint8), np.clip(np.round(a64).transpose((1, 2, 0)), 0, 255).astype(np.uint8))
+    # IEEE division, not a multiplication by the reciprocal: N / 48 at the ties of the round that follows, x / 255 in float32
+    n = (np.arange(0, 4000, dtype=np.float64) * 24.0 - 24000.0) / 16.0
+    assert eq(np.round(lazy.asdevice(n) / 3), np.round(n / 3)) and eq(lazy.asdevice(n) / 12 + 127, n / 12 + 127)
+    q = np.arange(256, dtype=np.float32)
+    assert eq(lazy.asdevice(q) / float(255), q / float(255)) and eq(lazy.asdevice(q) / np.float32(255), q / np.float32(255))
     # ties round to even, like np.round
     t = np.array([0.5, 1.5, 2.5, -0.5, 254.5, 255.5])
     assert eq(np.round(lazy.asdevice(t)), np.round(t))
