@@ -717,6 +717,28 @@ def run_callsite(args):
     want = eng.sr(frame, 2)
     legs = {}
 
+    # time spent INSIDE the library (the 24 + 2 mirrored calls and the final materialisation, host clock incl. the device waits they
+    # contain) against the caller's own numpy between them: with a host image the caller's 12 np.rot90 + np.pad(edge) of stage 1
+    # (25 ms each on a fresh 25-MB array) are its own and no drop-in can take them away
+    inside = [0.0]
+
+    def timed_call(f):
+        def g(*a, **k):
+            t = time.perf_counter()
+            try:
+                return f(*a, **k)
+            finally:
+                inside[0] += time.perf_counter() - t
+        return g
+
+    class TimedResizer(object):
+        def __init__(self, r):
+            self.r = r
+            self.set_shape = timed_call(r.set_shape)
+            self.resize = timed_call(r.resize)
+
+    interp_t, resizer_t = timed_call(interp), TimedResizer(resizer)
+
     def run(name, enabled, first, reps):
         lazy.set_enabled(enabled)
         try:
@@ -724,29 +746,23 @@ def run_callsite(args):
             for k in range(reps + 1):
                 if k == 1:
                     torch.cuda.synchronize()
+                    inside[0] = 0.0
                     t0 = time.perf_counter()
-                x = lazy.asdevice(img) if first else img
-                out = np.asarray(cd.worker_sr(interp, pads, resizer, luts, x, (2.0, 2.0)))
+                x = timed_call(lazy.asdevice)(img) if first else img
+                res = cd.worker_sr(interp_t, pads, resizer_t, luts, x, (2.0, 2.0))
+                out = timed_call(np.asarray)(res)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
         finally:
             lazy.set_enabled(True)
         legs[name] = {"ms_per_frame": round(dt * 1e3, 2), "mpix_s": round(out.shape[0] * out.shape[1] / dt / 1e6, 2),
+                      "inside_library_ms": round(inside[0] / reps * 1e3, 2), "callers_own_numpy_ms": round((dt - inside[0] / reps) * 1e3, 2),
                       "bytes_equal_engine_path": bool(np.array_equal(out, want))}
-        return dt
+        return dt, inside[0] / reps
 
-    # what the CALLER itself spends in numpy before the library sees a pixel: the 12 rot90 + edge pad + transpose of stage 1 on
-    # its host image (stage 2's run on the library's lazy result); no drop-in can take that away from an unchanged call site
-    t0 = time.perf_counter()
-    for m in "sct":
-        for r in range(4):
-            rot = np.rot90(img, r)
-            np.pad(rot, ((0, pads[m]), (0, pads[m]), (0, 0)), mode="edge").transpose((2, 0, 1))
-    t_caller = time.perf_counter() - t0
-    t_lazy = run("lazy_device_arrays", True, False, max(3, args.steps // 5))
-    legs["lazy_device_arrays"]["of_which_caller_numpy_ms"] = round(t_caller * 1e3, 2)
-    run("lazy_plus_asdevice_line", True, True, max(3, args.steps // 5))
-    t_naive = run("naive_numpy_round_trips", False, False, 2)
+    t_lazy, in_lazy = run("lazy_device_arrays", True, False, max(3, args.steps // 5))
+    t_dev, _ = run("lazy_plus_asdevice_line", True, True, max(3, args.steps // 5))
+    t_naive, in_naive = run("naive_numpy_round_trips", False, False, 2)
     t_eng = []
     for k in range(6):
         torch.cuda.synchronize()
@@ -761,6 +777,8 @@ def run_callsite(args):
                                   "24 FourSimplexInterpFaster calls + set_shape + resize + the caller's numpy calls; host float32 HWC in, host uint8 HWC out",
                       "baseline_config": 2, "path": "callsite (tools/callsite_driver.py against lerf_pytorch_amd mirrors)", "input": args.input or "noise"},
            "legs": legs, "speedup_lazy_over_naive": round(t_naive / t_lazy, 1),
+           "speedup_inside_library_lazy_over_naive": round(in_naive / max(in_lazy, 1e-9), 1),
+           "speedup_lazy_plus_one_line_over_naive": round(t_naive / t_dev, 1),
            "reference_numpy_same_frame_s": 692.0,
            "note": "direct kernels (lut_interp_kernel x 24, resize_kernel float64), not the tile-fused path: each call is one LUT pass as the "
                    "caller asked for it; reference numpy on the build container: 692 s for this frame size (SURVEY.md section 6)"}

@@ -120,6 +120,7 @@ typedef struct {
     int flags;               /* LERF_GEO_* bits, per call (the library reads no environment variables and keeps no state) */
 } lerf_sr_geo_t;
 #define LERF_GEO_FORCE_GENERAL 1   /* diagnostic: take the general tile-fused kernels where the specialised ones would serve (A/B runs) */
+#define LERF_GEO_SINGLE_LAUNCH 2   /* diagnostic: the single-launch kernel although a workspace is passed (the stamped build keeps its stamps there) */
 #define LERF_GEO_INPUT_DEVICE 4    /* lerf_sr_fused_u8: the input frames are device memory / pinned host memory (read over PCIe from inside the */
 #define LERF_GEO_INPUT_HOST 8      /* kernel, once per pixel); neither bit: the library asks the runtime (one hipPointerGetAttributes per call) */
 

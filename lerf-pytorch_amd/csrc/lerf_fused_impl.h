@@ -2239,6 +2239,7 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + D::IY <= H && ix0 + D::IX <= W;
     const int Hc = interior ? -1 : H, Wc = W;
     uint8_t* Ft = smem + D::OFF_F;
+    LERF_STAMP(0);
 
 #ifndef LERF_S1_LDS_PIXELS
     // interior tiles of the specialised kernel: pixel reads on the vector-memory path (byte_phase_vmem), no input tile in LDS
@@ -2313,6 +2314,7 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         }
     }
     }
+    LERF_STAMP(1);
     // the block's rows to P.feat
     uint8_t* __restrict__ fdst = F.feat;
     const int rows = min(TH, H - fy0), cols3 = min(TW, W - fx0) * CH;
@@ -2331,6 +2333,10 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             fdst[((int64_t)(fy0 + r) * W + fx0) * CH + c3] = Ft[r * D::FP + c3];
         }
     }
+#ifdef LERF_STAMPS
+    __syncthreads();
+    LERF_STAMP(2);
+#endif
 }
 
 #undef LERF_S1_LOAD
@@ -2408,9 +2414,18 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
             }
     };
     set_s1off(P, 0);
-    bool two = a.workspace != nullptr;
+    bool two = a.workspace != nullptr && !(a.flags & LERF_GEO_SINGLE_LAUNCH);
 #ifdef LERF_STAMPS
-    two = false;                 // the diagnostic build keeps the single launch: its stamps live in the workspace
+    // diagnostic build: the stamps live at the START of the workspace -- [n x tiles x 16] of the stages-2+3 (or single) launch,
+    // then [n x stage-1 blocks x 16] of s1_kernel, then (two launches) the stage-1 output.  A workspace too small for
+    // all three keeps the single launch (tools/stamps.py sizes it).
+    size_t stamp_bytes = 0;
+    {
+        const size_t per = 16 * sizeof(unsigned long long);
+        const size_t nb = (size_t)a.n * P.tiles_y * P.tiles_x;
+        stamp_bytes = ((2 * nb + nb / 4 + 64) * per + 255) & ~(size_t)255;   // both areas (the stage-1 grid of a region is a little larger)
+        two = two && a.items == nullptr && !EMIT && a.workspace_bytes >= stamp_bytes + (size_t)a.n * feat_slice_bytes(a.H, a.W);
+    }
 #endif
     auto ka = s1_kernel<GEN>;
     auto kb = sr_fused_kernel<S, KIND, EMIT, true, GEN>;
@@ -2464,8 +2479,14 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     // recomputation, then stages 2+3 from it
     if (two) {
         P.feat = (uint8_t*)a.workspace;
+#ifdef LERF_STAMPS
+        P.feat += stamp_bytes;
+#endif
         P.feat_sn = (int64_t)feat_slice_bytes(a.H, a.W);
         Params Pa = P;
+#ifdef LERF_STAMPS
+        Pa.stamps = P.stamps + (size_t)blocks * 16;
+#endif
         set_s1off(Pa, 1);
         int64_t blocks1 = blocks;
         if (roi) {
