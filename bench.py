@@ -406,7 +406,7 @@ def main():
             lgeo = ldist.block_geometry(geo, plan)
             buf = ldist.BlockBuffer(plan, B_local, C, torch.uint8, torch.device("cuda"), lr_, lc_)
             buf.own.copy_(torch.from_numpy(np.ascontiguousarray(host[:, plan.y0:plan.y1, plan.x0:plan.x1])).cuda())
-            out = torch.empty((B_local, plan.i1 - plan.i0, plan.j1 - plan.j0, C), dtype=torch.uint8, device="cuda")
+            out = ldist.block_output(plan, B_local, C, torch.device("cuda"))       # rows padded to 16 bytes (a view)
 
             buf_px = buf.ext.shape[1] * buf.ext.shape[2]
 

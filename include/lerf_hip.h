@@ -118,6 +118,9 @@ typedef struct {
                               * 3 + S/2 pixels (ABI 5; ABI 4 recomputed stage 1 on every tile's halo for regions) */
     /* ---- ABI 5 (zero = the behaviour of ABI 4) */
     int flags;               /* LERF_GEO_* bits, per call (the library reads no environment variables and keeps no state) */
+    int out_row_pitch;       /* lerf_sr_fused_u8: BYTES between output rows; 0 = dense rows of out_w * C bytes.  >= out_w * C.  A rank of
+                              * a block partition owns 1919 or 1921 output columns at x2: with rows padded to a multiple of 16 bytes its
+                              * tiles keep the aligned store paths (dense 5757-byte rows cost +13 % per launch) */
 } lerf_sr_geo_t;
 #define LERF_GEO_FORCE_GENERAL 1   /* diagnostic: take the general tile-fused kernels where the specialised ones would serve (A/B runs) */
 #define LERF_GEO_SINGLE_LAUNCH 2   /* diagnostic: the single-launch kernel although a workspace is passed (the stamped build keeps its stamps there) */

@@ -77,6 +77,7 @@ class SrGeo(C.Structure):
         ("tie_queue_cap", C.c_int),                                   # 0 = default, n > 0 = n entries, < 0 = no queue
         ("roi_y", C.c_int), ("roi_x", C.c_int), ("roi_h", C.c_int), ("roi_w", C.c_int),   # 0-sized = whole frame
         ("flags", C.c_int),                                           # GEO_* bits (ABI 5)
+        ("out_row_pitch", C.c_int),                                   # bytes between output rows of lerf_sr_fused_u8, 0 = dense
     ]
 
 

@@ -386,7 +386,7 @@ static void fused_args_of(FusedArgs& f, int C, const lerf_luts_t* luts, const le
     f.dis_c64 = (geo->dis_r64 && geo->dis_c64) ? geo->dis_c64 : nullptr;
     f.kind = kind;
     f.roi_y = geo->roi_y; f.roi_x = geo->roi_x; f.roi_h = geo->roi_h; f.roi_w = geo->roi_w;
-    f.tq_cap = geo->tie_queue_cap; f.pad_mode = geo->pad_mode; f.flags = geo->flags;
+    f.tq_cap = geo->tie_queue_cap; f.pad_mode = geo->pad_mode; f.flags = geo->flags; f.out_pitch = geo->out_row_pitch;
 }
 
 int lerf_sr_fused_supported(int C, const lerf_luts_t* luts, const lerf_sr_geo_t* geo, int H, int W, int kind, double max_sigma) {
@@ -409,6 +409,7 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
     if (kind != LERF_KIND_GAUSS && kind != LERF_KIND_LINEAR) return LERF_EUNSUPPORTED;
     if ((kind == LERF_KIND_GAUSS) != (luts->oC == 3)) return LERF_EINVAL;
     if (geo->pad_mode < LERF_PAD_CONSTANT || geo->pad_mode > LERF_PAD_WRAP) return LERF_EINVAL;
+    if (geo->out_row_pitch != 0 && (int64_t)geo->out_row_pitch < (int64_t)geo->out_w * C) return LERF_EINVAL;
     const bool roi = geo->roi_h > 0 && geo->roi_w > 0;
     if (roi && (geo->roi_y < 0 || geo->roi_x < 0 || geo->roi_y + geo->roi_h > H || geo->roi_x + geo->roi_w > W)) return LERF_EINVAL;
     FusedArgs f{};
@@ -445,7 +446,7 @@ int lerf_sr_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int
         for (int k = 0; k < 3; ++k)
             hp[k] = lerf_plane_t{ws + (size_t)H * W * C + (k < oC ? k : 0), LERF_U8, (int64_t)W * C * oC,
                                  (int64_t)C * oC, oC};
-        lerf_mplane_t o{out + b * out_sn, LERF_U8, (int64_t)geo->out_w * C, C, 1};
+        lerf_mplane_t o{out + b * out_sn, LERF_U8, geo->out_row_pitch ? (int64_t)geo->out_row_pitch : (int64_t)geo->out_w * C, C, 1};
         rc = lerf_resize(&fin, hp, H, W, C, geo, kind, max_sigma, &o, stream);
         if (rc != LERF_OK) return rc;
     }
@@ -475,7 +476,7 @@ int lerf_sr_fused_ragged_u8(const lerf_sr_item_t* items, int n, int C, const ler
         if (!s.img || !s.out || s.H < 1 || s.W < 1 || !s.geo.left_r || !s.geo.left_c || !s.geo.dis_r || !s.geo.dis_c) return LERF_EINVAL;
         if (s.geo.S != items[0].geo.S || s.geo.pad_mode != items[0].geo.pad_mode) return LERF_EINVAL;
         // per-call knobs of the launch: one value for all items (the first item's would silently win otherwise)
-        if (s.geo.tie_queue_cap != items[0].geo.tie_queue_cap || s.geo.flags != items[0].geo.flags) return LERF_EINVAL;
+        if (s.geo.tie_queue_cap != items[0].geo.tie_queue_cap || s.geo.flags != items[0].geo.flags || s.geo.out_row_pitch != 0) return LERF_EINVAL;
         // (the float64 tables -- the tie guard -- are honoured frame by frame: FrameDesc.dis_r64)
         all = all && lerf_sr_fused_supported(C, luts, &s.geo, s.H, s.W, kind, max_sigma) && s.geo.roi_h == 0;
     }

@@ -177,6 +177,7 @@ struct Params {
     int tq_cap;                      // stage-3 tie queue entries in use (<= Dims::TQ_CAP; lerf_sr_geo_t.tie_queue_cap)
     int pad_mode;                    // LERF_PAD_* of the image operand of stage 3 at the true frame borders
     int host_input;                  // the input frames live in (pinned) HOST memory: read every pixel once (LDS tile), never 39 times
+    int out_pitch;                   // bytes per output row (lerf_sr_geo_t.out_row_pitch; 0 = dense rows of oW * CH bytes)
 };
 
 #ifdef LERF_STAMPS
@@ -1568,8 +1569,10 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         constexpr int GMAX = S == 2 ? 5 : 3;                      // rows per group (larger runs are split)
         int* g_grp = reinterpret_cast<int*>(g_dc + D::GEO_COLS * S);
         const int ncolc = ncol * CH;
-        const int64_t rowpitch = (int64_t)F.oW * CH;
-        uint8_t* seg0 = outp + ((int64_t)i0 * F.oW + j0) * CH;
+        // bytes per output row: dense, or the caller's pitch (a rank's block of 1919 / 1921 output columns lives in rows padded to a
+        // 16-byte multiple so that its tiles keep the dword-column / block tasks -- dense, every row was a group of its own)
+        const int64_t rowpitch = P.out_pitch > 0 ? (int64_t)P.out_pitch : (int64_t)F.oW * CH;      // (ragged launches: always dense)
+        uint8_t* seg0 = outp + (int64_t)i0 * rowpitch + (int64_t)j0 * CH;
         const bool rows_align = (rowpitch & 3) == 0;              // dword columns line up across the rows of a group
         // dword columns per row: when every row of the block starts on a 4-byte boundary (a0 == 0 below) the block needs
         // no slack column, and a 384-byte tile row is exactly 96 dwords = whole 128-byte lines per wave store
@@ -2374,6 +2377,7 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
     P.tq_cap = a.tq_cap == 0 ? D::TQ_CAP : (a.tq_cap < 0 ? 0 : (a.tq_cap > D::TQ_CAP ? D::TQ_CAP : a.tq_cap));
     P.pad_mode = a.pad_mode;
     P.host_input = a.host_input ? 1 : 0;
+    P.out_pitch = a.out_pitch;
     P.img = a.img; P.in_sn = a.in_sn; P.out = a.out; P.out_sn = a.out_sn;
     P.H = a.H; P.W = a.W; P.oH = a.oH; P.oW = a.oW;
     const bool roi = a.roi_h > 0 && a.roi_w > 0;

@@ -74,6 +74,7 @@ struct FusedArgs {
     int pad_mode;                         // LERF_PAD_* of the image operand
     bool host_input;                      // img is (pinned) host memory: the kernels must not re-read pixels from it
     int flags;                            // lerf_sr_geo_t.flags (LERF_GEO_*)
+    int out_pitch;                        // lerf_sr_geo_t.out_row_pitch (bytes; 0 = dense)
     const FusedItem* items; int n_items;  // ragged launch (general kernels): frames of different sizes; img/out/H/W/... above unused
 };
 bool fused_supported(const FusedArgs& a);          // some tile-fused kernel covers the configuration

@@ -425,7 +425,25 @@ def sr_block(engine, ext, plan: BlockPlan, geo, out=None, workspace="auto"):
     from . import ops
     if isinstance(workspace, str):
         workspace = None if (ext.dim() == 4 and ext.shape[0] > 1) else False
+    if out is None:
+        out = block_output(plan, ext.shape[0] if ext.dim() == 4 else 1, ext.shape[-1], ext.device)
+        if ext.dim() == 3:
+            out = out[0]
     return ops.sr_fused_u8(ext, engine.luts, block_geometry(geo, plan), engine.kind, engine.max_sigma, out=out, workspace=workspace)
+
+
+def block_output(plan: BlockPlan, N, C, device):
+    """Output tensor [N, i1-i0, j1-j0, C] of a rank's block as a VIEW of rows padded to a multiple of 16 bytes.  The blocks at
+    the frame's left / right edge own 1919 / 1921 output columns at x2 (the half-pixel shift of the grid): dense rows of 5757
+    bytes start at every phase of a dword, and the kernel then stores row by row, byte by byte (+13 % per launch, measured);
+    the pitched rows keep its 16-byte store path (lerf_sr_geo_t.out_row_pitch)."""
+    import torch
+    h, w = plan.i1 - plan.i0, plan.j1 - plan.j0
+    wp = -(-(w * C) // 16) * 16
+    if wp % C:                                     # the padded pitch must still be a whole number of pixels for a [.., w, C] view
+        wp = -(-(w * C) // (16 * C)) * (16 * C)
+    buf = torch.empty((N, h, wp // C, C), dtype=torch.uint8, device=device)
+    return buf[:, :, :w]
 
 
 def sr_batch_pipelined(engine, buffers, plan, geo, outs=None, group=None, compute=None):

@@ -428,16 +428,21 @@ def _gpu_visible(t):
     return t.is_cuda or t.is_pinned()
 
 
-def _check_out_u8(out, shape, device, what):
+def _check_out_u8(out, shape, device, what, pitched=False):
+    """frames may be strided (dim 0); each frame is dense HWC -- or, with pitched=True, HWC rows at a pitch >= W * C bytes
+    (a view [:, :, :W] of a wider tensor: lerf_sr_geo_t.out_row_pitch)"""
     torch = _torch()
     if not isinstance(out, torch.Tensor) or out.dtype != torch.uint8 or tuple(out.shape) != tuple(shape):
         raise ValueError("%s must be a uint8 tensor of shape %s" % (what, tuple(shape)))
     if not _gpu_visible(out):
         raise ValueError("%s must live in device memory or pinned host memory" % what)
     exp = 1
-    for d in range(out.dim() - 1, 0, -1):               # frames may be strided (dim 0); each frame is dense HWC
+    for d in range(out.dim() - 1, 0, -1):
         if out.shape[d] != 1 and out.stride(d) != exp:
-            raise ValueError("%s: every frame must be contiguous [H,W,C]" % what)
+            if pitched and d == out.dim() - 3 and out.stride(d) > exp:
+                exp = out.stride(d)                     # the row pitch
+            else:
+                raise ValueError("%s: every frame must be contiguous [H,W,C]%s" % (what, " (rows may be pitched)" if pitched else ""))
         exp *= out.shape[d]
 
 
@@ -466,7 +471,7 @@ def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out
         o4 = torch.empty(oshape, dtype=torch.uint8, device=dev)
     else:
         o4 = out.unsqueeze(0) if (squeeze and out.dim() == 3) else out
-        _check_out_u8(o4, oshape, img.device, "out")
+        _check_out_u8(o4, oshape, img.device, "out", pitched=True)
     need = int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N))
     if workspace is False:
         ws_ptr, ws_n = None, 0
@@ -479,6 +484,8 @@ def sr_fused_u8(img_u8, luts, geo: SrGeometry, kind="gauss", max_sigma=10.0, out
     # where the frames live travels with the call (no hipPointerGetAttributes per launch)
     gs = _lib.SrGeo.from_buffer_copy(geo.struct)
     gs.flags |= _lib.GEO_INPUT_DEVICE if img.is_cuda else _lib.GEO_INPUT_HOST
+    if o4.shape[1] > 1 and o4.stride(1) != oshape[2] * Cn:
+        gs.out_row_pitch = int(o4.stride(1))         # rows of a wider tensor (dist.sr_block pads a block's rows to 16 bytes)
     with _lib.on_device(o4):
         _lib.check(_lib.lib().lerf_sr_fused_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(), C.byref(gs),
                                                KINDS[kind], float(max_sigma), o4.data_ptr(), o4.stride(0),

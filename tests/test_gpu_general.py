@@ -263,6 +263,25 @@ def test_ragged_launch_of_more_than_64_frames_and_its_argument_checks(torch, ora
         ops.sr_fused_ragged_u8(imgs[:3], eng.luts, [gl[0], gl[1], gl[2].with_flags(1)], eng.kind, eng.max_sigma)
 
 
+def test_pitched_output_rows(torch):
+    """lerf_sr_geo_t.out_row_pitch: the output as a [:, :, :w] view of wider rows -- same bytes, nothing written past the w-th pixel
+    of a row; specialised, general and fallback kernels"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import ops
+    for model, S, shape, scale in (("lerf-g", 2, (2, 70, 131, 3), 2), ("lerf-l", 2, (1, 66, 90, 3), (1.5, 2.0)), ("lerf-g", 4, (1, 40, 77, 3), 3),
+                                   ("lerf-g", 2, (1, 50, 60, 1), 2)):
+        eng = L.LerfEngine.shipped(model, support=S)
+        x = torch.from_numpy(np.random.default_rng(shape[2]).integers(0, 256, shape, dtype=np.uint8)).cuda()
+        geo = eng.sr_geometry(shape[1:3], scale)
+        dense = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma)
+        oh, ow = geo.out_hw
+        wide = torch.full((shape[0], oh, ow + 21, shape[3]), 0x5A, dtype=torch.uint8, device="cuda")
+        got = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma, out=wide[:, :, :ow])
+        assert torch.equal(got, dense) and bool((wide[:, :, ow:] == 0x5A).all())
+        one = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma, out=wide[:, :, :ow], workspace=False)
+        assert torch.equal(one, dense) and bool((wide[:, :, ow:] == 0x5A).all())
+
+
 def test_force_general_flag_and_partition_pad_guard(torch):
     """lerf_sr_geo_t.flags replaces the LERF_FORCE_GENERAL environment variable of round 3 (the ABI reads no environment):
     the general kernels give the specialised kernels' bytes; strips / blocks refuse wrap padding"""

@@ -25,23 +25,23 @@ H, W = 1080, 1920
 
 
 def classes(ty, tx):
-    """tile class of every tile of the (ty x tx) grid: 0 interior, 1 frame edge (first row / column, last column), 2 last tile row"""
+    """tile class of every tile of the (ty x tx) grid: 0 interior, 1 first tile row, 3 first column, 4 last column, 2 last tile row"""
     c = np.zeros((ty, tx), np.int32)
     c[0, :] = 1
-    c[:, 0] = 1
-    c[:, -1] = 1
+    c[:, 0] = 3
+    c[:, -1] = 4
     c[-1, :] = 2
     return c.reshape(-1)
 
 
 def report(kind, d, cls, mhz, wall, title):
-    names = {0: "interior", 1: "frame edge", 2: "last tile row (56 of 64 rows)"}
+    names = {0: "interior", 1: "top row", 3: "left column", 4: "right column", 2: "last row (56/64)"}
     print("== %s, %s: cycles per tile (s_memtime ticks, stamped on wave 0).  Shader clock during the tiles: %.0f MHz mean (%.0f .. %.0f); "
           "launch = %.1f us by the 100 MHz counter" % (kind, title, mhz.mean(), mhz.min(), mhz.max(), wall))
-    sel = [("all %d tiles" % len(cls), np.ones(len(cls), bool))] + [("%s (%d)" % (names[k], (cls == k).sum()), cls == k) for k in (0, 1, 2)]
-    print("  %-30s" % "" + "".join("%26s" % n for n, _ in sel))
+    sel = [("all %d tiles" % len(cls), np.ones(len(cls), bool))] + [("%s (%d)" % (names[k], (cls == k).sum()), cls == k) for k in (0, 1, 3, 4, 2)]
+    print("  %-30s" % "" + "".join("%20s" % n for n, _ in sel))
     for k, v in d.items():
-        print("  %-30s" % k + "".join("%26.0f" % (np.nanmean(v[m]) if m.any() and not np.isnan(v[m]).all() else float("nan")) for _, m in sel))
+        print("  %-30s" % k + "".join("%20.0f" % (np.nanmean(v[m]) if m.any() and not np.isnan(v[m]).all() else float("nan")) for _, m in sel))
 
 
 def main():
