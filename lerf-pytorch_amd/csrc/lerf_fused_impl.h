@@ -1671,7 +1671,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         constexpr int GS = decltype(gs_const)::value;          // rows per group, 0 = read it per group
         constexpr int GN = GS > 0 ? GS : GMAX;
         for (int t = tid; t < ntask; t += NT) {
-            const int g = (int)__umulhi((unsigned)t, magic);
+            const int g = ndw == 1 ? t : (int)__umulhi((unsigned)t, magic);      // (ceil(2^32 / 1) does not fit the 32-bit magic)
             const int dw = t - g * ndw;
             const int il0 = g_grp[g];
             const int gs = GS > 0 ? GS : g_grp[g + 1] - il0;
@@ -1880,7 +1880,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             const int nblk = ((nrow + rofs + 1) >> 1) * ncg;
             const unsigned magicc = (unsigned)((0x100000000ull + (unsigned)ncg - 1) / (unsigned)(ncg > 0 ? ncg : 1));
             for (int t = tid; t < nblk; t += NT) {
-                const int g = (int)__umulhi((unsigned)t, magicc);
+                const int g = ncg == 1 ? t : (int)__umulhi((unsigned)t, magicc);
                 const int h = t - g * ncg;
                 const int il0 = 2 * g - rofs, jl0 = 2 * h - cofs;
                 const int lr = g_lr[UNI ? il0 : max(il0, 0)], lc = g_lc[UNI ? jl0 : max(jl0, 0)];
@@ -1998,7 +1998,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             const int nblk = ngrp * ncg;
             const unsigned magicc = (unsigned)((0x100000000ull + (unsigned)ncg - 1) / (unsigned)(ncg > 0 ? ncg : 1));
             for (int t = tid; t < nblk; t += NT) {
-                const int g = (int)__umulhi((unsigned)t, magicc);
+                const int g = ncg == 1 ? t : (int)__umulhi((unsigned)t, magicc);
                 const int h = t - g * ncg;
                 const int il0 = g_grp[g], jl0 = g_cgrp[h];
                 const bool two_r = g_grp[g + 1] - il0 > 1, two_c = g_cgrp[h + 1] - jl0 > 1;
@@ -2098,7 +2098,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             const int total = nrow * nchunk;
             const int full_lo = ophase == 0 ? 0 : 1, full_hi = ((ophase + ncolc) & 15) == 0 ? nchunk : nchunk - 1;   // whole chunks of a row
             for (int i = tid; i < total; i += NT) {
-                const int row = (int)__umulhi((unsigned)i, magicf);
+                const int row = nchunk == 1 ? i : (int)__umulhi((unsigned)i, magicf);
                 const int ch = i - row * nchunk;
                 if (ch >= full_lo && ch < full_hi) {
                     const v4u x = *reinterpret_cast<const v4u*>(outt + row * D::OUT_PITCH + ch * 16);

@@ -268,8 +268,11 @@ def test_pitched_output_rows(torch):
     of a row; specialised, general and fallback kernels"""
     import lerf_pytorch_amd as L
     from lerf_pytorch_amd import ops
+    # (70 x 65 and 66 x 129: a last tile column of ONE LR pixel -- a single column pair / a one-chunk row of the block tasks,
+    #  whose index divisions by 1 overflowed their 32-bit magic before round 4; reachable only with pitched rows)
     for model, S, shape, scale in (("lerf-g", 2, (2, 70, 131, 3), 2), ("lerf-l", 2, (1, 66, 90, 3), (1.5, 2.0)), ("lerf-g", 4, (1, 40, 77, 3), 3),
-                                   ("lerf-g", 2, (1, 50, 60, 1), 2)):
+                                   ("lerf-g", 2, (1, 50, 60, 1), 2), ("lerf-g", 2, (2, 70, 65, 3), 2), ("lerf-l", 2, (1, 66, 129, 3), 2),
+                                   ("lerf-g", 2, (1, 65, 64, 3), 2)):
         eng = L.LerfEngine.shipped(model, support=S)
         x = torch.from_numpy(np.random.default_rng(shape[2]).integers(0, 256, shape, dtype=np.uint8)).cuda()
         geo = eng.sr_geometry(shape[1:3], scale)
