@@ -222,6 +222,41 @@ class DeviceArray(object):
         return self._div(o, True)
 
     def __neg__(self): return DeviceArray(-self.t)
+    def __abs__(self): return DeviceArray(self.t.abs())
+
+    # comparisons on the device (boolean arrays, like numpy's); a comparison torch cannot form falls back to the host copy
+    def _cmp(self, o, op, hop):
+        r = self._bin(o, op)
+        return hop(self.numpy(), _host(o)) if r is NotImplemented else r
+
+    def __eq__(self, o): return self._cmp(o, lambda a, b: a == b, lambda a, b: a == b)
+    def __ne__(self, o): return self._cmp(o, lambda a, b: a != b, lambda a, b: a != b)
+    def __lt__(self, o): return self._cmp(o, lambda a, b: a < b, lambda a, b: a < b)
+    def __le__(self, o): return self._cmp(o, lambda a, b: a <= b, lambda a, b: a <= b)
+    def __gt__(self, o): return self._cmp(o, lambda a, b: a > b, lambda a, b: a > b)
+    def __ge__(self, o): return self._cmp(o, lambda a, b: a >= b, lambda a, b: a >= b)
+    __hash__ = None
+
+    def __bool__(self):
+        return bool(self.numpy())
+
+    def __float__(self):
+        return float(self.numpy())
+
+    def __int__(self):
+        return int(self.numpy())
+
+    # the rest of the operator table: numpy's own result on the host copy
+    def __pow__(self, o): return self.numpy() ** _host(o)
+    def __rpow__(self, o): return _host(o) ** self.numpy()
+    def __mod__(self, o): return self.numpy() % _host(o)
+    def __floordiv__(self, o): return self.numpy() // _host(o)
+    def __and__(self, o): return self.numpy() & _host(o)
+    def __or__(self, o): return self.numpy() | _host(o)
+    def __xor__(self, o): return self.numpy() ^ _host(o)
+    def __invert__(self): return ~self.numpy()
+    def __matmul__(self, o): return self.numpy() @ _host(o)
+    def __iter__(self): return iter(self.numpy())
 
     # ---- numpy protocol: the handful of functions of the call sites run on the device, everything else on the host copy
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
