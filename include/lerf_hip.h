@@ -124,6 +124,11 @@ typedef struct {
 } lerf_sr_geo_t;
 #define LERF_GEO_FORCE_GENERAL 1   /* diagnostic: take the general tile-fused kernels where the specialised ones would serve (A/B runs) */
 #define LERF_GEO_SINGLE_LAUNCH 2   /* diagnostic: the single-launch kernel although a workspace is passed (the stamped build keeps its stamps there) */
+#define LERF_GEO_X2_TABLES 16      /* the caller vouches that the tables are lerf_sr_axis_tables(scale = 2) on both axes (or row / column slices of
+                                    * them): output rows and columns pair up on their taps, the distances have period 2.  Read only by the
+                                    * round-4 experiment build (-DLERF_PERSIST_EXPERIMENT: a persistent kernel that defers stage 3 into the next
+                                    * tile's LUT-piece copies; byte-exact, slower -- DESIGN.md); the product library ignores it */
+#define LERF_GEO_NO_PERSIST 32     /* experiment build only: never take that kernel (A/B runs) */
 #define LERF_GEO_INPUT_DEVICE 4    /* lerf_sr_fused_u8: the input frames are device memory / pinned host memory (read over PCIe from inside the */
 #define LERF_GEO_INPUT_HOST 8      /* kernel, once per pixel); neither bit: the library asks the runtime (one hipPointerGetAttributes per call) */
 

@@ -81,7 +81,7 @@ class SrGeo(C.Structure):
     ]
 
 
-GEO_FORCE_GENERAL, GEO_SINGLE_LAUNCH, GEO_INPUT_DEVICE, GEO_INPUT_HOST = 1, 2, 4, 8
+GEO_FORCE_GENERAL, GEO_SINGLE_LAUNCH, GEO_INPUT_DEVICE, GEO_INPUT_HOST, GEO_X2_TABLES, GEO_NO_PERSIST = 1, 2, 4, 8, 16, 32
 
 
 class SrItem(C.Structure):          # lerf_sr_item_t: one frame of a ragged launch

@@ -53,6 +53,11 @@ class SrGeometry:
             dr32, dc32 = dr64.astype(np.float32), dc64.astype(np.float32)
         self.pad_vec = ((0, 0), pr, pc)                                     # :129
         self.host = dict(left_r=lr, dis_r=dr64, dis_r32=dr32, left_c=lc, dis_c=dc64, dis_c32=dc32)
+        # exact x2 tables of lerf_sr_axis_tables on both axes: rows / columns pair up on their taps, distances have period 2 --
+        # lets lerf_sr_fused_u8 take the persistent kernel (LERF_GEO_X2_TABLES; slices of these tables keep the property)
+        if sh == 2.0 and sw == 2.0 and arithmetic == "f64" and float(dis_scale) == 1.0 and self.S == 2 \
+                and self.out_hw == (2 * H, 2 * W):
+            self.flags = _lib.GEO_X2_TABLES
         self._upload()
 
     def _upload(self):
@@ -81,10 +86,10 @@ class SrGeometry:
         return g
 
     def with_flags(self, flags):
-        """a copy of this geometry with lerf_sr_geo_t.flags = `flags` (_lib.GEO_*: diagnostic A/B of the kernel families)"""
+        """a copy of this geometry with `flags` added to lerf_sr_geo_t.flags (_lib.GEO_*: diagnostic A/B of the kernel families)"""
         g = object.__new__(SrGeometry)
         g.__dict__.update(self.__dict__)
-        g.flags = int(flags)
+        g.flags = int(getattr(self, "flags", 0)) | int(flags)
         g._upload()
         return g
 

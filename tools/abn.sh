@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B/C... of several builds of the library on the same GPU box: tools/abn.sh "<bench args>" lib1.so lib2.so ...; three rounds
+# A/B/C... of several builds of the library on one GPU box: tools/abn.sh "<bench args>" lib1.so lib2.so ... ; three alternating rounds
 args=$1; shift
 for i in 1 2 3; do
   for l in "$@"; do
-    v=$(LERF_HIP_LIB=$PWD/$l python3 bench.py --steps 30 --no-cpu-baseline --no-other-input --sustained 0 $args 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
+    v=$(LERF_HIP_LIB=$PWD/$l python3 bench.py --steps 30 --no-cpu-baseline --no-other-input --sustained 0 $args 2>/dev/null | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'])")
     echo "$l $v"
   done
 done

@@ -53,17 +53,18 @@ def main():
     eng = L.LerfEngine.shipped(model, support=S)
     geo = eng.sr_geometry((H, W), scale if len(scale) > 1 else scale[0])
     ty, tx = (H + 63) // 64, (W + 63) // 64
-    tiles = ty * tx
-    cls = classes(ty, tx)
+    nfr = int(os.environ.get("LERF_STAMPS_FRAMES", "1"))          # >= 2 frames of 1080p: the persistent kernel takes the launch
+    tiles = ty * tx * nfr
+    cls = np.tile(classes(ty, tx), nfr)
     for kind in (args or ("noise", "natural")):
         if kind == "constant":
-            x = torch.full((1, H, W, 3), 128, dtype=torch.uint8, device="cuda")
+            x = torch.full((nfr, H, W, 3), 128, dtype=torch.uint8, device="cuda")
         else:
-            x = torch.from_numpy(bench.synth_frames(kind, 1, 7, H, W)).cuda()
+            x = torch.from_numpy(bench.synth_frames(kind, nfr, 7, H, W)).cuda()
         stamp_bytes = ((2 * tiles + tiles // 4 + 64) * 128 + 255) & ~255
-        feat_bytes = (H * W * 3 + 15) // 16 * 16
-        need = int(L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, 3, 1))
-        ws = torch.zeros(max(need, stamp_bytes + feat_bytes), dtype=torch.uint8, device="cuda")
+        feat_bytes = nfr * ((H * W * 3 + 15) // 16 * 16)
+        need = int(L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, 3, nfr))
+        ws = torch.zeros(need + stamp_bytes + 4096, dtype=torch.uint8, device="cuda")
         g = geo.with_flags(L._lib.GEO_SINGLE_LAUNCH) if single else geo
         for _ in range(2):
             ops.sr_fused_u8(x, eng.luts, g, eng.kind, eng.max_sigma, workspace=ws)
