@@ -480,7 +480,10 @@ int lerf_sr_fused_ragged_u8(const lerf_sr_item_t* items, int n, int C, const ler
         if (!s.img || !s.out || s.H < 1 || s.W < 1 || !s.geo.left_r || !s.geo.left_c || !s.geo.dis_r || !s.geo.dis_c) return LERF_EINVAL;
         if (s.geo.S != items[0].geo.S || s.geo.pad_mode != items[0].geo.pad_mode) return LERF_EINVAL;
         // per-call knobs of the launch: one value for all items (the first item's would silently win otherwise)
-        if (s.geo.tie_queue_cap != items[0].geo.tie_queue_cap || s.geo.flags != items[0].geo.flags || s.geo.out_row_pitch != 0) return LERF_EINVAL;
+        // (LERF_GEO_X2_TABLES / _INPUT_* describe an item; FORCE_GENERAL / SINGLE_LAUNCH steer the launch)
+        if (s.geo.tie_queue_cap != items[0].geo.tie_queue_cap || s.geo.out_row_pitch != 0 ||
+            ((s.geo.flags ^ items[0].geo.flags) & (LERF_GEO_FORCE_GENERAL | LERF_GEO_SINGLE_LAUNCH)) != 0)
+            return LERF_EINVAL;
         // (the float64 tables -- the tie guard -- are honoured frame by frame: FrameDesc.dis_r64)
         all = all && lerf_sr_fused_supported(C, luts, &s.geo, s.H, s.W, kind, max_sigma) && s.geo.roi_h == 0;
     }

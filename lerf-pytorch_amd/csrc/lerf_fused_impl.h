@@ -1889,7 +1889,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         //      per output), and a tile is exactly 4 tasks per thread.  The bytes are assembled in an LDS image of the tile's
         //      output block (ties are patched there) and leave as whole 16-byte chunks.  Same arithmetic, operation for
         //      operation, as run_tasks: the outputs are bit-identical.
-        constexpr bool BLK = KIND == LERF_KIND_GAUSS && S == 2 && D::OUT_FITS;
+        constexpr bool BLK = KIND == LERF_KIND_GAUSS && (S == 2 || S == 4) && D::OUT_FITS;      // (round 4: the 4 x 4 support too)
         uint8_t* outt = smem + D::OFF_OUT;
         const int ophase = (int)(reinterpret_cast<uintptr_t>(seg0) & 15u);
 #ifndef LERF_NO_BLOCK_TASKS
@@ -1905,7 +1905,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         auto run_blocks = [&](auto uni_const) {
             constexpr bool UNI = decltype(uni_const)::value;
             if constexpr (BLK) {
-            constexpr int SS2 = 4;
+            constexpr int SS2 = S * S;
             const int rofs = UNI ? 0 : rcode - 1, cofs = UNI ? 0 : ccode - 1;
             const int ncg = (ncol + cofs + 1) >> 1;
             const int nblk = ((nrow + rofs + 1) >> 1) * ncg;
@@ -1916,11 +1916,11 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 const int il0 = 2 * g - rofs, jl0 = 2 * h - cofs;
                 const int lr = g_lr[UNI ? il0 : max(il0, 0)], lc = g_lc[UNI ? jl0 : max(jl0, 0)];
                 // distances as PAIRS: DX[b] = (row 0, row 1) of row tap b, DY[a] = (column 0, column 1) of column tap a
-                s3::f2 DX[2], DY[2];
+                s3::f2 DX[S], DY[S];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) { DX[b].x = g_dr[il0 * 2 + b]; DX[b].y = g_dr[il0 * 2 + 2 + b]; }
+                for (int b = 0; b < S; ++b) { DX[b].x = g_dr[il0 * S + b]; DX[b].y = g_dr[il0 * S + S + b]; }
 #pragma unroll
-                for (int a = 0; a < 2; ++a) { DY[a].x = g_dc[jl0 * 2 + a]; DY[a].y = g_dc[jl0 * 2 + 2 + a]; }
+                for (int a = 0; a < S; ++a) { DY[a].x = g_dc[jl0 * S + a]; DY[a].y = g_dc[jl0 * S + S + a]; }
                 const uint32_t* dp = Dt + lr * D::HP + lc * CH;
                 uint8_t* ob = outt + il0 * D::OUT_PITCH + ophase + jl0 * CH;
                 float dist[4 * CH];                                  // [c][r][q]
@@ -1931,9 +1931,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                     // (its value, m2rho, k1, k2) sit in the low halves of register pairs and are read through op_sel
                     s3::f2 NUM[2], DEN[2];                           // [row r]
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                    for (int a = 0; a < S; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
+                        for (int b = 0; b < S; ++b) {
                             const uint32_t d = dp[b * D::HP + a * CH + c];
                             s3::f2 V, K1, K2, M2;
                             V.x = V.y = (float)(d >> 24);                          // (both lanes: the weights' consumers below are plain vector code)
@@ -1993,16 +1993,16 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                         }
                         // queue full: evaluated on the spot (float64, the reference's own dtype chain), patched behind the store above
                         uint32_t dd[SS2];
-                        double dx64[2], dy64[2];
+                        double dx64[S], dy64[S];
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il) * 2 + b];
+                        for (int b = 0; b < S; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il) * S + b];
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl0 + qq) * 2 + a];
+                        for (int a = 0; a < S; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl0 + qq) * S + a];
 #pragma unroll
-                        for (int a = 0; a < 2; ++a)
+                        for (int a = 0; a < S; ++a)
 #pragma unroll
-                            for (int b = 0; b < 2; ++b) dd[a * 2 + b] = dp[b * D::HP + a * CH + c];
-                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<true, 2>(dd, dx64, dy64, P.max_sigma));
+                            for (int b = 0; b < S; ++b) dd[a * S + b] = dp[b * D::HP + a * CH + c];
+                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<true, S>(dd, dx64, dy64, P.max_sigma));
                     }
                 }
             }
