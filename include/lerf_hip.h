@@ -129,6 +129,9 @@ typedef struct {
                                     * round-4 experiment build (-DLERF_PERSIST_EXPERIMENT: a persistent kernel that defers stage 3 into the next
                                     * tile's LUT-piece copies; byte-exact, slower -- DESIGN.md); the product library ignores it */
 #define LERF_GEO_NO_PERSIST 32     /* experiment build only: never take that kernel (A/B runs) */
+#define LERF_GEO_TILE_ROWS_64 64    /* force the tile height of the RGB tile-fused kernels (default: 64 rows, 32 / 16 for launches too small to */
+#define LERF_GEO_TILE_ROWS_32 128   /* fill the chip with 64-row tiles -- a 256 x 256 frame runs as 64 tiles of 16 rows); tests and A/B runs */
+#define LERF_GEO_TILE_ROWS_16 256
 #define LERF_GEO_INPUT_DEVICE 4    /* lerf_sr_fused_u8: the input frames are device memory / pinned host memory (read over PCIe from inside the */
 #define LERF_GEO_INPUT_HOST 8      /* kernel, once per pixel); neither bit: the library asks the runtime (one hipPointerGetAttributes per call) */
 

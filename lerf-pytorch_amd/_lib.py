@@ -82,6 +82,7 @@ class SrGeo(C.Structure):
 
 
 GEO_FORCE_GENERAL, GEO_SINGLE_LAUNCH, GEO_INPUT_DEVICE, GEO_INPUT_HOST, GEO_X2_TABLES, GEO_NO_PERSIST = 1, 2, 4, 8, 16, 32
+GEO_TILE_ROWS_64, GEO_TILE_ROWS_32, GEO_TILE_ROWS_16 = 64, 128, 256
 
 
 class SrItem(C.Structure):          # lerf_sr_item_t: one frame of a ragged launch

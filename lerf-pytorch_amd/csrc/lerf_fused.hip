@@ -65,10 +65,36 @@ size_t fused_workspace_bytes(const FusedArgs& a) {
     return (size_t)a.n * (((size_t)a.H * a.W * a.C + 15) / 16 * 16);
 }
 
+// Tile rows of an RGB launch: 64 unless the launch is too small to fill the chip with 64-row tiles -- then 32 or 16 rows (general
+// kernels), whichever first gives every CU something to do.  A 256 x 256 frame: 16 tiles of 64 rows on 256 CUs (0.158 ms) ->
+// 64 tiles of 16 rows.  Larger launches stay on 64 rows: a tile's fixed costs make the small tiles slower per pixel.
+// LERF_GEO_TILE_ROWS_* force a height (tests, A/B).
+static int tile_rows_for(const FusedArgs& a) {
+    if (a.flags & LERF_GEO_TILE_ROWS_64) return 64;
+    if (a.flags & LERF_GEO_TILE_ROWS_32) return 32;
+    if (a.flags & LERF_GEO_TILE_ROWS_16) return 16;
+    auto tiles = [&](int th) {
+        int64_t t = 0;
+        if (a.items != nullptr) {
+            for (int i = 0; i < a.n_items; ++i) t += (int64_t)((a.items[i].H + th - 1) / th) * ((a.items[i].W + 63) / 64);
+            return t;
+        }
+        const bool roi = a.roi_h > 0 && a.roi_w > 0;
+        return (int64_t)a.n * (((roi ? a.roi_h : a.H) + th - 1) / th) * (((roi ? a.roi_w : a.W) + 63) / 64);
+    };
+    constexpr int64_t kEnough = 192;                 // three quarters of the 256 CUs busy: the larger tile wins from here on
+    if (tiles(64) >= kEnough) return 64;
+    if (tiles(32) >= kEnough) return 32;
+    return tiles(32) >= 96 ? 32 : 16;               // (very small launches: the most workgroups)
+}
+
 int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
     if (a.C == 1) return launch_sr_fused_c1(a, st);
     if (a.C == 4) return launch_sr_fused_c4(a, st);
     if (a.C != 3) return LERF_EUNSUPPORTED;
+    const int th = tile_rows_for(a);
+    if (th == 32) return launch_sr_fused_h32(a, st);
+    if (th == 16) return launch_sr_fused_h16(a, st);
     return fused_fast(a) ? fused::launch_sr<false>(a, st) : launch_sr_fused_g3(a, st);
 }
 
@@ -83,6 +109,9 @@ int launch_stages_fused(const FusedArgs& a, hipStream_t st) {
     if (a.C == 1) return launch_stages_fused_c1(a, st);
     if (a.C == 4) return launch_stages_fused_c4(a, st);
     if (a.C != 3) return LERF_EUNSUPPORTED;
+    const int th = tile_rows_for(a);
+    if (th == 32) return launch_stages_fused_h32(a, st);
+    if (th == 16) return launch_stages_fused_h16(a, st);
     return fused_fast(a) ? fused::launch_stages<false>(a, st) : launch_stages_fused_g3(a, st);
 }
 

@@ -1,7 +1,7 @@
 // Implementation of the tile-fused kernels, included once per channel count: the including translation unit defines
 //   LERF_FUSED_NS   namespace of this instance (fused = RGB, fused_c1 = single channel, fused_c4 = four channels)
 //   LERF_FUSED_CH   channels per pixel; the LR tile is 64 rows x (192 / CH) pixels, 192 pixel-channels per tile row
-//   LERF_FUSED_FAST 1: also instantiate the specialised (modes "sct"/"sct", scale <= 4.9) kernels -- RGB only
+//   LERF_FUSED_TH   tile rows (default 64)
 // (a plain C++ namespace-parametrised include: everything in here is gfx950 code, there is no second platform).
 //
 // Tile-fused uint8 SR path for MI355X (gfx950): stage-1 LUTs -> stage-2 LUTs -> spatially-varying resampling per
@@ -57,7 +57,10 @@ constexpr int NT = 1024;           // threads per workgroup
 constexpr int NW = NT / 64;        // waves
 constexpr int CH = LERF_FUSED_CH;  // channels per pixel of this instance
 static_assert(CH == 1 || CH == 3 || CH == 4, "192 pixel-channels per tile row");
-constexpr int TH = 64, TW = 192 / CH;   // LR tile: 64 rows x 192 pixel-channels (64x64 RGB pixels, 64x192 grey, 64x48 RGBA):
+#ifndef LERF_FUSED_TH
+#define LERF_FUSED_TH 64           // tile rows: 64 = the throughput tile; the 32- and 16-row instances (lerf_fused_h32 / _h16.hip) serve launches
+#endif                             // too small to fill the chip with 64-row tiles (a 256 x 256 frame: 16 / 32 / 64 workgroups)
+constexpr int TH = LERF_FUSED_TH, TW = 192 / CH;   // LR tile: TH rows x 192 pixel-channels (64x64 RGB pixels, 64x192 grey, 64x48 RGBA):
                                    // the same number of stage-2 positions, registers and LDS bytes for every channel count
 constexpr int R1 = 3, R2 = 3;      // stage radii: the reach of the widest sampling patterns (c, t: 3 px; s 1, d 2, y 2)
 constexpr int MAXM = 4;            // modes per stage the 16-bit sums can hold (4 rotations x 4 modes x 16 x 255 < 2^16)

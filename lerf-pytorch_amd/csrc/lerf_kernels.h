@@ -87,6 +87,10 @@ int launch_stages_fused(const FusedArgs& a, hipStream_t st);
 // the general kernels (any patterns, scale <= 8, ragged frames) per channel count, one translation unit each
 int launch_sr_fused_g3(const FusedArgs& a, hipStream_t st);
 int launch_stages_fused_g3(const FusedArgs& a, hipStream_t st);
+int launch_sr_fused_h32(const FusedArgs& a, hipStream_t st);      // RGB, 32- and 16-row tiles (small launches)
+int launch_stages_fused_h32(const FusedArgs& a, hipStream_t st);
+int launch_sr_fused_h16(const FusedArgs& a, hipStream_t st);
+int launch_stages_fused_h16(const FusedArgs& a, hipStream_t st);
 int launch_sr_fused_c1(const FusedArgs& a, hipStream_t st);
 int launch_stages_fused_c1(const FusedArgs& a, hipStream_t st);
 int launch_sr_fused_c4(const FusedArgs& a, hipStream_t st);

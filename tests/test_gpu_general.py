@@ -389,3 +389,29 @@ def test_halo_buffers_pack_and_unpack_on_the_device(torch, oracle):
         for _, (y, x, h, w), off, nb in buf.recvs:
             assert torch.equal(buf.ext[:, y:y + h, x:x + w], buf.recv_buf[off:off + nb].view(N, h, w, C))
         assert torch.equal(buf.own, before)                    # the halo writes never touch the owned pixels
+
+
+@pytest.mark.parametrize("model,S,scale,shapes", [("lerf-g", 2, 2, [(256, 256), (40, 56), (97, 131)]), ("lerf-g", 4, 2, [(70, 90)]),
+                                                  ("lerf-l", 2, (1.5, 2.0), [(130, 67)]), ("lerf-g", 2, 3, [(33, 200)])])
+def test_tile_rows_give_the_same_bytes(torch, model, S, scale, shapes):
+    """round 4: the 32- and 16-row tile instances (small launches) against the 64-row tiles, fused SR, packed stages and a
+    ragged launch; the default rule picks small tiles for a launch that cannot fill the chip"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import _lib, ops
+    eng = L.LerfEngine.shipped(model, support=S)
+    rng = np.random.default_rng(len(shapes) + S)
+    xs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).cuda() for h, w in shapes]
+    geos = [eng.sr_geometry(x.shape[:2], scale) for x in xs]
+    for x, g in zip(xs, geos):
+        want = ops.sr_fused_u8(x, eng.luts, g.with_flags(_lib.GEO_TILE_ROWS_64), eng.kind, eng.max_sigma)
+        assert torch.equal(want, eng.sr(x, scale, fused=False))
+        for fl in (_lib.GEO_TILE_ROWS_32, _lib.GEO_TILE_ROWS_16, 0):
+            assert torch.equal(ops.sr_fused_u8(x, eng.luts, g.with_flags(fl), eng.kind, eng.max_sigma), want)
+            assert torch.equal(ops.sr_fused_u8(x, eng.luts, g.with_flags(fl), eng.kind, eng.max_sigma, workspace=False), want)
+    want = [ops.sr_fused_u8(x, eng.luts, g.with_flags(_lib.GEO_TILE_ROWS_64), eng.kind, eng.max_sigma) for x, g in zip(xs, geos)]
+    for fl in (_lib.GEO_TILE_ROWS_32, _lib.GEO_TILE_ROWS_16, 0):
+        got = ops.sr_fused_ragged_u8(xs, eng.luts, [g.with_flags(fl) for g in geos], eng.kind, eng.max_sigma)
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+    feat, hq = eng.stages(xs[0])
+    f2, h2 = ops.lut_stages(xs[0], eng.luts)
+    assert torch.equal(torch.as_tensor(feat).cuda(), f2) and torch.equal(torch.as_tensor(hq).cuda(), h2)     # small launch: small tiles by default

@@ -50,3 +50,33 @@ o = torch.empty((512, 512, 3), dtype=torch.uint8, device="cuda")
 ta = timeit(lambda: ops.sr_fused_u8(tile, eng.luts, geo, "gauss", 10.0, out=o), 200)
 tb = timeit(lambda: ops.sr_fused_u8(tile, eng.luts, geo, "gauss", 10.0, out=o, workspace=False), 200)
 print("config-1 tile 256x256 -> 512x512 (16 tiles on 256 CUs): two launches %.4f ms, one launch %.4f ms per call (host-timed, back to back)" % (ta * 1e3, tb * 1e3))
+
+# ---- round 4: tile rows.  64-row tiles are the throughput tile; launches too small to fill the chip take 32- or 16-row tiles
+#      (lerf_fused.hip tile_rows_for); LERF_GEO_TILE_ROWS_* force a height
+from lerf_pytorch_amd import _lib
+ref = ops.sr_fused_u8(tile, eng.luts, geo.with_flags(_lib.GEO_TILE_ROWS_64), "gauss", 10.0)
+for nm, fl in (("64 rows (16 tiles)", _lib.GEO_TILE_ROWS_64), ("32 rows (32 tiles)", _lib.GEO_TILE_ROWS_32), ("16 rows (64 tiles)", _lib.GEO_TILE_ROWS_16), ("default", 0)):
+    g = geo.with_flags(fl)
+    same = torch.equal(ops.sr_fused_u8(tile, eng.luts, g, "gauss", 10.0), ref)
+    t2 = timeit(lambda: ops.sr_fused_u8(tile, eng.luts, g, "gauss", 10.0, out=o), 200)
+    t1 = timeit(lambda: ops.sr_fused_u8(tile, eng.luts, g, "gauss", 10.0, out=o, workspace=False), 200)
+    print("config-1 tile 256x256 -> 512x512, tiles of %-18s: two launches %.4f ms, one launch %.4f ms; bytes == 64-row tiles: %s" % (nm, t2 * 1e3, t1 * 1e3, same))
+for model in ("lerf-g",):
+    eng = L.LerfEngine.shipped(model)
+    jobs = [(s, n) for s in (2, 3, 4) for n in NAMES]
+    xs = [torch.from_numpy(np.array(Image.open(os.path.join(DATA, "LR_bicubic/rrLR_X%.2f_%.2f" % (s, s), n + ".png")))).cuda() for s, n in jobs]
+    geos0 = [eng.sr_geometry(x.shape[:2], (float(s), float(s))) for x, (s, _) in zip(xs, jobs)]
+    base = None
+    for nm, fl in (("64", _lib.GEO_TILE_ROWS_64), ("32", _lib.GEO_TILE_ROWS_32), ("16", _lib.GEO_TILE_ROWS_16), ("default", 0)):
+        geos = [g.with_flags(fl) for g in geos0]
+        outs = ops.sr_fused_ragged_u8(xs, eng.luts, geos, eng.kind, eng.max_sigma)
+        base = base or outs
+        same = all(torch.equal(p, q) for p, q in zip(outs, base))
+        t = timeit(lambda: ops.sr_fused_ragged_u8(xs, eng.luts, geos, eng.kind, eng.max_sigma))
+        print("%s Set5 ragged launch, tile rows %-7s: %.3f ms; bytes == 64-row tiles: %s" % (model, nm, t * 1e3, same))
+    for k, (x, g0) in enumerate(list(zip(xs, geos0))[:5]):
+        ts = []
+        for fl in (_lib.GEO_TILE_ROWS_64, 0):
+            g = g0.with_flags(fl)
+            ts.append(timeit(lambda: ops.sr_fused_u8(x, eng.luts, g, eng.kind, eng.max_sigma), 100))
+        print("   %s x2 LR %dx%d alone: 64-row tiles %.4f ms, default rule %.4f ms" % (NAMES[k], x.shape[1], x.shape[0], ts[0] * 1e3, ts[1] * 1e3))
