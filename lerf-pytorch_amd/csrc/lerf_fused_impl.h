@@ -1570,6 +1570,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 
     if (EMIT) {
         __syncthreads();
+#ifdef LERF_DBG_NOEMIT
+        if (P.pad_mode != 77) return;          // timing experiment only: the stages kernel without its packed-map stores
+#endif
         uint32_t* eo = F.emit;
         const int rows = min(TH, H - ty0), cols3 = min(TW, W - tx0) * CH;
         for (int il = wave; il < rows; il += NW) {

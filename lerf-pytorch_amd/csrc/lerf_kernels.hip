@@ -833,6 +833,10 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed0, int64_t packed_sn, i
         uint32_t d[S * S];
 #pragma unroll
         for (int t = 0; t < S * S; ++t) d[t] = packed[pos[t] + c];
+#ifdef LERF_DBG_WARP_NOLOAD          // timing experiment only (wrong results): the kernel without its tap loads = what a tile-fused warp could save at most
+#pragma unroll
+        for (int t = 0; t < S * S; ++t) d[t] = (uint32_t)(pos[t] + c) * 2654435761u + (uint32_t)fr;
+#endif
         if constexpr (PROD) {
             float e[S * S], v[S * S];
 #pragma unroll
