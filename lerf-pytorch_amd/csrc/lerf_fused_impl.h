@@ -112,7 +112,13 @@ struct Dims {
     static constexpr int END1 = OFF_ACC + up16(NF * 2);
     // stage 2, LeRF-G: one piece.  The position lists and the wave x bin count table only live between the binning and the
     // first piece store (the first piece waits in registers) and overlay the piece.
-    static constexpr int MAXR = (NH + NBIN * 63 + NT - 1) / NT;   // slot rounds: every bin padded to whole waves (14)
+    // positions that are looked up: the hyper region without its last row and column (never read by an owned output, see the binning)
+#ifndef LERF_FULL_RING
+    static constexpr int NHL = HR > 0 ? (HY - 1) * (HX - 1) * CH : NH;
+#else
+    static constexpr int NHL = NH;
+#endif
+    static constexpr int MAXR = (NHL + NBIN * 63 + NT - 1) / NT;  // slot rounds: every bin padded to whole waves (13 for S = 2, 14 for S = 4)
     static constexpr int OFF_LST = OFF_X;
     static constexpr int OFF_TAB = OFF_LST + MAXR * NT * 2;       // [wave][4 bins] counts
     static_assert(OFF_TAB + NW * 4 * 4 <= OFF_X + PIECE_LDS, "binning scratch fits under the piece");
@@ -1247,6 +1253,16 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 if (p < D::NH) {
                     bool in = true;
                     const int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, &in);
+#ifndef LERF_FULL_RING
+                    // The last row and the last column of the hyper region are never read by an owned output: a tile owns the
+                    // outputs whose first tap lies in [t0 - S/2, t0 + T - S/2), so their taps end at t0 + T + S/2 - 2, one short of
+                    // the region's end (the frame's own trailing outputs reach it -- as out-of-frame positions, which fill_outside()
+                    // supplies).  Not looked up: 3 % of the positions (66 x 66 -> 65 x 65), 13 slot rounds instead of 14.
+                    if (D::HR > 0) {
+                        const int ry = p / D::HP, r3 = p - ry * D::HP;
+                        if (ry == D::HY - 1 || r3 >= (D::HX - 1) * CH) in = false;
+                    }
+#endif
                     if (in) q = bin_of_level((uint32_t)Bt[a] >> 4);
                 }
                 if (k < 8) qlo |= q << (4 * k); else qhi |= q << (4 * (k - 8));

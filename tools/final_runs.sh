@@ -18,3 +18,7 @@ python tools/probe_warp.py > gpurun_out/$tag/warp_split.txt 2>&1
 python tools/eval_set5.py > gpurun_out/$tag/set5_table.txt 2>&1
 bash tools/prof_all.sh > gpurun_out/$tag/prof_all.log 2>&1
 ls gpurun_out/$tag
+# direct kernels behind the unchanged call sites (FourSimplexInterpFaster x 24, resize): kernel trace of bench.py --path callsite
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag/callsite_trace -o k -- python3 $GRAFT_REPO_ROOT/bench.py --path callsite --steps 5 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
