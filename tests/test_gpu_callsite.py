@@ -53,6 +53,32 @@ def test_worker_protocol_gives_the_reference_bytes(torch, oracle, model, scale, 
         lazy.set_enabled(True)
 
 
+@pytest.mark.parametrize("lazy_on", [True, False])
+@pytest.mark.parametrize("model,p", [("lerf-g", "isc"), ("lerf-l", "osc")])
+def test_warp_worker_protocol_gives_the_reference_bytes(torch, oracle, model, p, lazy_on):
+    """the warp harness' call sequence (resample/eval_lut_warp.py:100-233) against the mirrors: masked output md5 and mask md5 of
+    the reference's own Set5 runs"""
+    import callsite_driver as cd
+    from lerf_pytorch_amd import lazy
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["warp"]
+    linear = model == "lerf-l"
+    luts = cd.float_luts(oracle.load_luts(os.path.join(ASSETS, model), linear=linear))
+    interp, pads, warper, nn = cd.mirror_warp_api(linear=linear)
+    lazy.set_enabled(lazy_on)
+    try:
+        for n in ("bird", "head"):
+            r = ref["%s/%s/%s" % (model, p, n)]
+            lr = np.array(Image.open(os.path.join(DATA, p, n + ".png"))).astype(np.float32)
+            gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+            out8, mask = cd.worker_warp(interp, pads, warper, nn, luts, lr, np.array(r["matrix"]), gt.shape[:2],
+                                        out_c=1 if linear else 3, linear=linear)
+            o8, mk = np.asarray(out8), np.asarray(mask)
+            assert int(mk.sum()) == r["mask_sum"] and _md5(mk.astype(np.uint8)) == r["md5_mask"]
+            assert _md5(o8 * mk) == r["md5_out_masked"]
+    finally:
+        lazy.set_enabled(True)
+
+
 def test_device_array_answers_like_numpy(torch):
     """every operation the call sites apply between the library calls, DeviceArray against the same numpy expression"""
     from lerf_pytorch_amd import lazy

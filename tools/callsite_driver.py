@@ -47,6 +47,42 @@ def worker_sr(interp, pads, resizer, luts, img_lr_hwc_f32, scale_hw, modes="sct"
     return np.clip(np.round(out).transpose((1, 2, 0)), 0, norm).astype(np.uint8)
 
 
+def worker_warp(interp, pads, warper, nn_warper, luts, img_lr_hwc_f32, matrix, gt_hw, modes="sct", modes2="sct", out_c=3, linear=False,
+                interval=4, norm=255, border=4):
+    """float32 HWC image in -> (uint8 HWC image, boolean HWC validity mask), by the call sequence of the warp harness
+    (resample/eval_lut_warp.py:100-233): the LUT stages as in worker_sr, then set_shape(matrix) / warp on both resamplers --
+    the learned one on (feat, hyper), the nearest one on a white image with a `border`-pixel black frame (:197-204, 229)."""
+    s1 = lut_ensemble(interp, pads, luts, img_lr_hwc_f32, 1, modes, 1, interval, lambda r: "r0")
+    feat = np.round(np.clip(s1 / len(modes) + 0, 0, norm)).astype(np.float32).transpose((1, 2, 0))
+    s2 = lut_ensemble(interp, pads, luts, feat, 2, modes2, out_c, interval, lambda r: "r%d" % (r & 1))
+    hyper = np.round(np.clip(s2 / (len(modes2) * 4) + norm // 2, 0, norm)).astype(np.float32) / float(norm)
+    chw = feat.transpose((2, 0, 1))
+    out_shape = (chw.shape[0], gt_hw[0], gt_hw[1])
+    warper.set_shape(chw.shape, matrix, out_shape)
+    white = np.zeros(chw.shape, dtype=np.float32)
+    h, w = white.shape[-2:]
+    white[:, border:h - border, border:w - border] = 255
+    nn_warper.set_shape(chw.shape, matrix, out_shape)
+    mask_out = nn_warper.warp(white)
+    if linear:
+        out = warper.warp(chw, hyper)
+    else:
+        n = hyper.shape[0]
+        out = warper.warp(chw, hyper[list(range(0, n, 3)), :, :], hyper[list(range(1, n + 1, 3)), :, :], hyper[list(range(2, n + 2, 3)), :, :])
+    out8 = np.clip(np.round(out).transpose((1, 2, 0)), 0, norm).astype(np.uint8)
+    mask = np.array(mask_out.transpose((1, 2, 0)) == 255)
+    return out8, mask
+
+
+def mirror_warp_api(linear=False, support=2, max_sigma=10):
+    """(interp, pads, learned warper, nearest warper) of the MI355X package (eval_lut_warp.py:37-44 constructs them)"""
+    from lerf_pytorch_amd.resample.eval_lut_sr import FourSimplexInterpFaster, mode_pad_dict
+    from lerf_pytorch_amd.resize_right.resize_right2d_numpy import (AmplifiedLinearWarp2dNumpy, NearestWarp2dNumpy,
+                                                                   SteeringGaussianWarp2dNumpy)
+    w = AmplifiedLinearWarp2dNumpy() if linear else SteeringGaussianWarp2dNumpy(support_sz=support, max_sigma=max_sigma)
+    return FourSimplexInterpFaster, mode_pad_dict, w, NearestWarp2dNumpy()
+
+
 def mirror_api(linear=False, support=2, max_sigma=10):
     """(interp, pads, resizer) of the MI355X package -- the three names INTEGRATION.md section 2 swaps in"""
     from lerf_pytorch_amd.resample.eval_lut_sr import FourSimplexInterpFaster, mode_pad_dict
