@@ -53,7 +53,10 @@
 namespace lerf {
 namespace LERF_FUSED_NS {
 
-constexpr int NT = 1024;           // threads per workgroup
+#ifndef LERF_FUSED_NT
+#define LERF_FUSED_NT 1024         // threads per workgroup (a 512-thread instance of the persistent experiment was tried: profiles/r04_experiments.txt)
+#endif
+constexpr int NT = LERF_FUSED_NT;  // threads per workgroup
 constexpr int NW = NT / 64;        // waves
 constexpr int CH = LERF_FUSED_CH;  // channels per pixel of this instance
 static_assert(CH == 1 || CH == 3 || CH == 4, "192 pixel-channels per tile row");
@@ -151,7 +154,7 @@ struct Dims {
     static constexpr int LDS_BYTES = cmax(END1, cmax(END2, GEO_EARLY ? END3 : 0)) + 512;  // + small control block
     static constexpr int OFF_CTL = LDS_BYTES - 512;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KiB of LDS");
-    static_assert(MAXR <= 14 && (NH + NT - 1) / NT <= 15, "slot rounds / positions per thread the register budget was sized for");
+    static_assert(NT != 1024 || (MAXR <= 14 && (NH + NT - 1) / NT <= 15), "slot rounds / positions per thread the register budget was sized for");
 };
 
 // Frames of DIFFERENT sizes in one launch (general kernels only): the descriptors travel in the kernel-argument segment, so

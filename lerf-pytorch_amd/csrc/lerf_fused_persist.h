@@ -60,7 +60,12 @@ static_assert(sizeof(DeferredTile) == 64, "two records in the control block");
 __device__ __forceinline__ int dt_nrow(const uint32_t dims) { return (int)(dims & 0xFFFFu); }
 __device__ __forceinline__ int dt_ncol(const uint32_t dims) { return (int)(dims >> 16); }
 
-__global__ void __launch_bounds__(NT)
+#if LERF_FUSED_NT == 512
+#define LERF_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))       // 8 waves per CU: up to 256 VGPRs per thread
+#else
+#define LERF_PERSIST_ATTR
+#endif
+__global__ void __launch_bounds__(NT) LERF_PERSIST_ATTR
 sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
     using D = Dims<2, false, false>;
     using PD = PersistDims;
@@ -365,7 +370,10 @@ sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
         int* tab = reinterpret_cast<int*>(smem + D::OFF_TAB);
         for (int i = tid; i < MAXR * NT / 2; i += NT) reinterpret_cast<uint32_t*>(lst)[i] = 0xFFFFFFFFu;
         constexpr int KH = (D::NH + NT - 1) / NT;
-        uint32_t qlo = 0, qhi = 0;
+        constexpr int KQ = (((D::NH + NT - 1) / NT) + 7) / 8;                   // registers of bin nibbles (8 positions each)
+        uint32_t qn[KQ];
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) qn[i] = 0;
         uint32_t xa, xb;
         {
             uint32_t hist = 0;
@@ -378,7 +386,7 @@ sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
                     const int a = center_addr<D::HP, D::FP>(p, hy0, hx0, fy0, fx0, Hc, Wc, &in);
                     if (in) q = bin_of_level((uint32_t)Bt[a] >> 4);
                 }
-                if (k < 8) qlo |= q << (4 * k); else qhi |= q << (4 * (k - 8));
+                qn[k >> 3] |= q << (4 * (k & 7));
                 hist += q < NBIN ? 1u << (8 * q) : 0u;
             }
             xa = (hist & 0xFFu) | ((hist << 8) & 0xFF0000u);
@@ -403,14 +411,14 @@ sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
         uint32_t cur01, cur23;
         {
             const int bb = lane & 3;
-            const int c = tab[lane];
+            const int c = lane < NW * 4 ? tab[lane] : 0;                 // lane = w * 4 + bb, w < NW
             int incl = c;
 #pragma unroll
             for (int d = 4; d < 64; d <<= 1) {
                 const int up = __shfl_up(incl, d);
                 if (lane >= d) incl += up;
             }
-            const int tot = __shfl(incl, 60 + bb);
+            const int tot = __shfl(incl, (NW - 1) * 4 + bb);
             const int padded = (tot + 63) & ~63;
             int start = padded;
 #pragma unroll
@@ -433,15 +441,17 @@ sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
                       ((uint32_t)__builtin_amdgcn_readlane(ec, 2) << 16) | ((uint32_t)__builtin_amdgcn_readlane(ec, 3) << 24);
             ne_bins = (uint32_t)(__ballot(tot > 0) & 0xFull);
         }
-        uint4 pr[NSLAB];
+        // a thread's share of a piece: 16 bytes of every NW-th 1-KiB block (block NW i + wave).  1024 threads: 9 slabs; 512: 17
+        constexpr int NSL = (PIECE_BLOCKS + NW - 1) / NW;
+        uint4 pr[NSL];
 #pragma unroll
-        for (int i = 0; i < NSLAB; ++i) pr[i] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < NSL; ++i) pr[i] = make_uint4(0, 0, 0, 0);
         const uint8_t* s2p = P.pack + (size_t)3 * LUT_PAD;
         constexpr int NL2 = 6;
         auto pre_load = [&](int l, int bq) {
             const uint4* s_ = reinterpret_cast<const uint4*>(s2p + ((size_t)l * NBIN + bq) * PIECE_BYTES) + (wave * 64 + lane);
 #pragma unroll
-            for (int i = 0; i < NSLAB; ++i) pr[i] = s_[i * NT];
+            for (int i = 0; i < NSL; ++i) pr[i] = s_[i * NT];            // (the pack pads every piece to PIECE_BYTES: the last slab's loads stay inside it)
         };
         const int nbins = __builtin_popcount(ne_bins);
         const int nph = nbins * NL2;
@@ -452,7 +462,7 @@ sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
             uint32_t ap = (uint32_t)((ry0 + D::HO) * D::FP + D::HO * CH) + col;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-                const uint32_t q = k < 8 ? (qlo >> (4 * k)) & 0xFu : (qhi >> (4 * (k - 8))) & 0xFu;
+                const uint32_t q = (qn[k >> 3] >> (4 * (k & 7))) & 0xFu;
                 if (q < NBIN) {
                     const uint32_t pair = q < 2 ? cur01 : cur23;
                     const uint32_t v = (q & 1u) ? pair >> 16 : pair & 0xFFFFu;
@@ -500,25 +510,32 @@ sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
         // VALU work runs under the other half's LDS writes (a wave issues in order: its own stores and its own arithmetic do not overlap)
         const bool math_first = wv >= NW / 2;
         auto pre_store_issue = [&]() {
+            // slab i = block NW i + wave at OFF_X + (NW i + wave) * 1024; the DS offset field is 16 bits, M0 moves in 64-KiB windows
             const uint32_t m0a = __builtin_amdgcn_readfirstlane((uint32_t)D::OFF_X + (uint32_t)wave * 1024u);
-#define LERF_SLAB_OK(I) ((I) < NSLAB && (16 * (I) + 15 < PIECE_BLOCKS || 16 * (I) + wave < PIECE_BLOCKS))
-            LERF_SET_M0(m0a);
-            if (LERF_SLAB_OK(0)) { LERF_ADDTID4(pr[0], 0, 256, 512, 768); }
-            if (LERF_SLAB_OK(1)) { LERF_ADDTID4(pr[1 < NSLAB ? 1 : 0], 16384, 16640, 16896, 17152); }
-            if (LERF_SLAB_OK(2)) { LERF_ADDTID4(pr[2 < NSLAB ? 2 : 0], 32768, 33024, 33280, 33536); }
-            if (LERF_SLAB_OK(3)) { LERF_ADDTID4(pr[3 < NSLAB ? 3 : 0], 49152, 49408, 49664, 49920); }
-            if (NSLAB > 4) {
-                LERF_SET_M0(m0a + 65536u);
-                if (LERF_SLAB_OK(4)) { LERF_ADDTID4(pr[4 < NSLAB ? 4 : 0], 0, 256, 512, 768); }
-                if (LERF_SLAB_OK(5)) { LERF_ADDTID4(pr[5 < NSLAB ? 5 : 0], 16384, 16640, 16896, 17152); }
-                if (LERF_SLAB_OK(6)) { LERF_ADDTID4(pr[6 < NSLAB ? 6 : 0], 32768, 33024, 33280, 33536); }
-                if (LERF_SLAB_OK(7)) { LERF_ADDTID4(pr[7 < NSLAB ? 7 : 0], 49152, 49408, 49664, 49920); }
+            constexpr int PER_WIN = 65536 / (NW * 1024);                 // slabs per window (4 at 1024 threads, 8 at 512)
+#define LERF_PSLAB(I, O)                                                                                   \
+            if constexpr ((I) < NSL) {                                                                         \
+                /* M0 must stay below 128 KiB: the third window sits at +73728 and uses the top of the offset range */ \
+                if ((I) % PER_WIN == 0) LERF_SET_M0(m0a + ((I) / PER_WIN < 2 ? (uint32_t)((I) / PER_WIN) * 65536u : 131072u - 57344u)); \
+                if (NW * (I) + NW - 1 < PIECE_BLOCKS || NW * (I) + wave < PIECE_BLOCKS) {                      \
+                    const uint4& r_ = pr[(I) < NSL ? (I) : 0];                                                 \
+                    asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(r_.x), "n"((O)) : "memory");          \
+                    asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(r_.y), "n"((O) + 256) : "memory");    \
+                    asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(r_.z), "n"((O) + 512) : "memory");    \
+                    asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(r_.w), "n"((O) + 768) : "memory");    \
+                }                                                                                              \
             }
-            if (NSLAB > 8) {
-                LERF_SET_M0(m0a + 81920u);
-                if (LERF_SLAB_OK(8)) { LERF_ADDTID4(pr[8 < NSLAB ? 8 : 0], 49152, 49408, 49664, 49920); }
+            if constexpr (NW == 16) {
+                LERF_PSLAB(0, 0) LERF_PSLAB(1, 16384) LERF_PSLAB(2, 32768) LERF_PSLAB(3, 49152)
+                LERF_PSLAB(4, 0) LERF_PSLAB(5, 16384) LERF_PSLAB(6, 32768) LERF_PSLAB(7, 49152)
+                LERF_PSLAB(8, 57344)
+            } else {
+                static_assert(NW == 8 || NW == 16, "512 or 1024 threads");
+                LERF_PSLAB(0, 0) LERF_PSLAB(1, 8192) LERF_PSLAB(2, 16384) LERF_PSLAB(3, 24576) LERF_PSLAB(4, 32768) LERF_PSLAB(5, 40960) LERF_PSLAB(6, 49152) LERF_PSLAB(7, 57344)
+                LERF_PSLAB(8, 0) LERF_PSLAB(9, 8192) LERF_PSLAB(10, 16384) LERF_PSLAB(11, 24576) LERF_PSLAB(12, 32768) LERF_PSLAB(13, 40960) LERF_PSLAB(14, 49152) LERF_PSLAB(15, 57344)
+                LERF_PSLAB(16, 57344)
             }
-#undef LERF_SLAB_OK
+#undef LERF_PSLAB
         };
         int bq = 0, bq_next = 0, l = 0, bi = 0;
         uint32_t ne_left = ne_bins;
@@ -529,7 +546,8 @@ sr_persist_kernel(Params P, uint32_t* __restrict__ scratch_all, int total) {
                 ne_left &= ne_left - 1u;
                 bq_next = ne_left != 0u ? __builtin_ctz(ne_left) : 0;
                 const int cs = (int)((cs_pack >> (8 * bq)) & 0xFFu), ce = (int)((ce_pack >> (8 * bq)) & 0xFFu);
-                const int klo = cs > wv ? (cs - wv + 15) >> 4 : 0, khi = ce > wv ? (ce - wv + 15) >> 4 : 0;
+                // list entry i sits in round i / NT of thread i % NT: chunk c (64 entries) = round c / NW of wave c % NW
+                const int klo = cs > wv ? (cs - wv + NW - 1) / NW : 0, khi = ce > wv ? (ce - wv + NW - 1) / NW : 0;
                 act = wrounds & ((1u << khi) - 1u) & ~((1u << klo) - 1u);
                 qbase = lds_addr(smem + D::OFF_X) - (uint32_t)bin_lo(bq) * (kStrideA * 4u);
             }
