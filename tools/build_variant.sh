@@ -19,7 +19,7 @@ $LL/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknow
     -input=/dev/null -input=$tmp/dev.hsaco -output=$tmp/dev.hipfb
 /opt/rocm/bin/hipcc $flags --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $tmp/dev.hipfb -c -o $tmp/lerf_fused.o $src/lerf_fused.hip
 objs=""
-for o in lerf_api lerf_kernels lerf_fused_g3 lerf_fused_c1 lerf_fused_c4 lerf_metrics lerf_train lerf_transfer lerf_ubench; do objs="$objs $src/build/$o.o"; done
+for o in lerf_api lerf_kernels lerf_fused_g3 lerf_fused_h32 lerf_fused_h16 lerf_fused_c1 lerf_fused_c4 lerf_metrics lerf_train lerf_transfer lerf_ubench; do objs="$objs $src/build/$o.o"; done
 /opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $root/lerf-pytorch_amd/liblerf_hip_$name.so $objs $tmp/lerf_fused.o
 cp $tmp/dev2.s /tmp/variant_$name.s
 rm -rf $tmp
