@@ -1,0 +1,38 @@
+"""How should a 25 MB float32 host array (the reference's stage-1 input of a 1080p frame) reach the device?  (round 4)"""
+import time, numpy as np, torch
+H, W = 1082, 1922
+rng = np.random.default_rng(0)
+def fresh():
+    return np.ascontiguousarray(rng.integers(0, 256, (3, H, W)).astype(np.float32))
+def t(f, n=12):
+    arrs = [fresh() for _ in range(n)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    outs = [f(a) for a in arrs]
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    return (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3
+pin = [torch.empty(3 * H * W, dtype=torch.float32).pin_memory() for _ in range(2)]
+pin_np = [p.numpy() for p in pin]
+ev = [None, None]; k = [0]
+def staged(a):
+    i = k[0] & 1; k[0] += 1
+    if ev[i] is not None: ev[i].synchronize()
+    np.copyto(pin_np[i], a.reshape(-1))
+    d = pin[i].cuda(non_blocking=True)
+    e = torch.cuda.Event(); e.record(); ev[i] = e
+    return d
+pin8 = [torch.empty(3 * H * W, dtype=torch.uint8).pin_memory() for _ in range(2)]
+pin8_np = [p.numpy() for p in pin8]
+def staged_u8(a):
+    i = k[0] & 1; k[0] += 1
+    if ev[i] is not None: ev[i].synchronize()
+    np.copyto(pin8_np[i], a.reshape(-1), casting="unsafe")
+    d = pin8[i].cuda(non_blocking=True)
+    e = torch.cuda.Event(); e.record(); ev[i] = e
+    return d
+for name, f in [("pageable .cuda()", lambda a: torch.from_numpy(a).cuda()),
+                ("astype(uint8) + .cuda()", lambda a: torch.from_numpy(a.astype(np.uint8)).cuda()),
+                ("np.copyto(pinned) + async copy", staged),
+                ("np.copyto(pinned uint8, cast) + async copy", staged_u8)]:
+    for _ in range(2):
+        h, tot = t(f)
+    print(f"{name:45s} host {h:6.2f} ms  until on device {tot:6.2f} ms per array")
