@@ -109,7 +109,7 @@ class DeviceArray(object):
     def numpy(self):
         """the host copy (made once; the object is treated as immutable by everything in this package)"""
         if self._np is None:
-            self._np = self.t.contiguous().cpu().numpy() if not self.t.is_contiguous() else self.t.cpu().numpy()
+            self._np = download(self.t)
         return self._np
 
     def __array__(self, dtype=None, copy=None):
@@ -373,9 +373,57 @@ def asdevice(a, dtype=None):
 
 
 # ---- host -> device
+_STAGE = {}          # (nbytes) -> [slots, next]; a slot = (pinned tensor, its numpy view, event of its last copy)
+_STAGE_MIN = 1 << 20
+_STAGE_MAX_BYTES = 256 << 20
+
+
 def upload(a):
-    """contiguous numpy array -> CUDA tensor.  A plain pageable copy: staging through a cached pinned buffer was tried (round 4) and
-    is no faster on these hosts (25 MB: 0.54 ms against 0.45 ms), while its host-side memcpy runs on torch's CPU thread pool, which
-    a container with fewer CPUs than the machine shows makes slow and erratic."""
+    """contiguous numpy array -> CUDA tensor.  Arrays of 1 MB and more go through a ring of two pinned buffers per size: a
+    single-threaded `np.copyto` (0.9 ms per 25 MB) and an asynchronous copy, so the host neither waits for the device work queued
+    before nor depends on the runtime's pageable path, which takes 0.55 ms per 25 MB on one host and 2.4 ms on the next
+    (profiles/r04_experiments.txt); smaller ones take the plain pageable copy.  (torch's `pinned.copy_(pageable)` is not used: it
+    runs on the CPU thread pool, slow and erratic in a container with fewer CPUs than the machine shows.)"""
     torch = _torch()
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a = np.ascontiguousarray(a)
+    if a.nbytes < _STAGE_MIN or a.dtype.hasobject:
+        return torch.from_numpy(a).cuda()
+    tdt = _torch_dtype(torch, a.dtype)                 # raises for dtypes torch does not have, before anything is staged
+    ring = _STAGE.get(a.nbytes)
+    if ring is None:
+        if sum(k * 2 for k in _STAGE) + 2 * a.nbytes > _STAGE_MAX_BYTES:
+            _STAGE.clear()
+        ring = _STAGE[a.nbytes] = [[], 0]
+        for _ in range(2):
+            t = torch.empty(a.nbytes, dtype=torch.uint8).pin_memory()
+            ring[0].append([t, t.numpy(), None])
+    slot = ring[0][ring[1] & 1]
+    ring[1] += 1
+    if slot[2] is not None:
+        slot[2].synchronize()
+    np.copyto(slot[1], a.reshape(-1).view(np.uint8))
+    d = slot[0].cuda(non_blocking=True).view(tdt).reshape(a.shape)
+    ev = torch.cuda.Event()
+    ev.record()
+    slot[2] = ev
+    return d
+
+
+def _torch_dtype(torch, dt):
+    return torch.from_numpy(np.empty(0, dtype=dt)).dtype
+
+
+def download(t):
+    """CUDA tensor -> numpy array.  1 MB and more land in a pinned host tensor from torch's caching host allocator (the DMA runs at
+    the link's rate: 0.6 ms instead of 2.9 ms for a 25 MB frame) and the array returned is a view of it -- ordinary writable
+    memory to its user, handed back to the allocator's cache when the array is dropped."""
+    torch = _torch()
+    if not t.is_cuda:
+        return t.contiguous().numpy()
+    t = t.contiguous()
+    if t.numel() * t.element_size() < _STAGE_MIN:
+        return t.cpu().numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return h.numpy()

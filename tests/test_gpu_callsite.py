@@ -140,3 +140,22 @@ def test_interp_accepts_device_arrays_and_caches_luts(torch, oracle):
     changed = FourSimplexInterpFaster(w, img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
     fresh = FourSimplexInterpFaster(w.copy(), img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)     # another buffer: no cache hit possible
     assert np.array_equal(np.asarray(changed), np.asarray(fresh)) and not np.array_equal(np.asarray(changed), want)
+
+
+def test_upload_ring_reuses_its_pinned_slots_safely(torch):
+    """lazy.upload: five large arrays in a row through the two-slot pinned ring (a slot is rewritten only after its copy has
+    finished), other dtypes and sizes, and the small-array path."""
+    from lerf_pytorch_amd import lazy
+    rng = np.random.default_rng(5)
+    arrs = [rng.integers(0, 256, (3, 700, 900)).astype(np.float32) for _ in range(5)]
+    devs = [lazy.upload(a) for a in arrs]                       # no synchronisation in between
+    for a, d in zip(arrs, devs):
+        assert d.dtype == torch.float32 and tuple(d.shape) == a.shape
+        assert np.array_equal(d.cpu().numpy(), a)
+    for dt in (np.uint8, np.int16, np.float64, np.int64):
+        a = rng.integers(0, 100, (1200, 1100)).astype(dt)
+        assert np.array_equal(lazy.upload(a).cpu().numpy(), a)
+    v = arrs[0].transpose(1, 2, 0)                              # not contiguous: gathered on the host first
+    assert np.array_equal(lazy.upload(v).cpu().numpy(), v)
+    s = rng.integers(0, 9, (7, 5)).astype(np.float32)
+    assert np.array_equal(lazy.upload(s).cpu().numpy(), s)
