@@ -415,3 +415,28 @@ def test_tile_rows_give_the_same_bytes(torch, model, S, scale, shapes):
     feat, hq = eng.stages(xs[0])
     f2, h2 = ops.lut_stages(xs[0], eng.luts)
     assert torch.equal(torch.as_tensor(feat).cuda(), f2) and torch.equal(torch.as_tensor(hq).cuda(), h2)     # small launch: small tiles by default
+
+
+@pytest.mark.parametrize("model,S,N,H,W,scale", [("lerf-g", 2, 1, 256, 256, 2), ("lerf-g", 4, 2, 70, 90, 2), ("lerf-l", 2, 1, 130, 67, (1.5, 2.0)),
+                                                 ("lerf-g", 2, 2, 300, 520, 2)])
+def test_fused_path_is_capturable_in_a_hip_graph(torch, model, S, N, H, W, scale):
+    """The C ABI issues only stream-ordered work (two kernel launches + the tie-queue reset; no allocation, no synchronisation, no
+    pointer query once the workspace exists): a caller may capture it (torch.cuda.CUDAGraph = hipGraph) and replay it on new
+    input bytes.  Replay must give the bytes of an eager call."""
+    import lerf_pytorch_amd as L
+    eng = L.LerfEngine.shipped(model, support=S)
+    rng = np.random.default_rng(N * H + W)
+    x = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                              # warm-up off the default stream: workspace and tables exist before the capture
+        eng.sr(x, scale)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = eng.sr(x, scale)
+    for k in range(3):
+        x2 = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).cuda()
+        x.copy_(x2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, eng.sr(x2, scale))
