@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Where does one LUT fine-tuning iteration (tools/bench_lutft.py) spend its time: device kernels against host launches."""
+import os, sys, time, types
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+from lerf_pytorch_amd.resample.model import SWF2LUT, lutft_step
+from lerf_pytorch_amd.resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch
+from torch.profiler import profile, ProfilerActivity
+B, scale = 256, 4.0
+opt = types.SimpleNamespace(modes="sct", modes2="sct", stages=2, norm=255, interval=4, lutName="LUTft",
+                            expDir=os.path.join(ROOT, "lerf-pytorch_amd", "assets", "models", "lerf-g"))
+m = SWF2LUT(opt, inC=1, outC=3).cuda()
+r = SteeringGaussianResize2dTorch(support_sz=2, device=torch.device("cuda"), max_sigma=10)
+r.set_shape([B, 1, 48, 48], scale_factors=scale)
+rng = np.random.default_rng(0)
+im = torch.tensor(rng.random((B, 1, 48, 48), dtype=np.float32), device="cuda")
+lb = torch.tensor(rng.random((B, 1, 192, 192), dtype=np.float32), device="cuda")
+opt_G = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+for _ in range(3): lutft_step(m, r, im, lb, opt_G)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(10): lutft_step(m, r, im, lb, opt_G)
+torch.cuda.synchronize(); print("eager: %.2f ms per iteration" % ((time.perf_counter() - t) / 10 * 1e3))
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+    lutft_step(m, r, im, lb, opt_G); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=70))
