@@ -348,13 +348,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
-    if local_rank >= torch.cuda.device_count():
+    # TEST HOOK (tests/test_gpu_fullsize.py): LERF_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and runs the barrier / the MAX over the
+    # ranks on gloo, so the multi-rank code below can be exercised on a one-GPU box (RCCL refuses two ranks on one device).  The
+    # line it prints says so ("backend": "gloo (ranks share one GPU: test hook)"); it is no measurement.
+    share_gpu = world > 1 and os.environ.get("LERF_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(dev_index)
     rccl_ranks = 1
+    coll_dev = "cpu" if share_gpu else "cuda"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        rccl_ranks = dist.get_world_size()
+        if share_gpu:
+            dist.init_process_group("gloo")
+            rccl_ranks = 0
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            rccl_ranks = dist.get_world_size()
     n_gpus = world
     if args.gpus != n_gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -482,7 +492,7 @@ def main():
 
     dt, launch_ms = timed(step, args.steps, args.warmup)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -505,7 +515,7 @@ def main():
                 step()
             n_sus += 20
             torch.cuda.synchronize()
-            stop = torch.tensor([1.0 if time.perf_counter() - t0 >= args.sustained else 0.0], device="cuda")
+            stop = torch.tensor([1.0 if time.perf_counter() - t0 >= args.sustained else 0.0], device=coll_dev)
             if world > 1:
                 dist.all_reduce(stop, op=dist.ReduceOp.MAX)
             if stop.item() > 0:
@@ -608,6 +618,7 @@ def main():
         "config": {"workload": names[cfg][1], "baseline_config": cfg, "frames_per_step_per_gpu": B_local, "input": input_kind,
                    "path": "unfused-3-launch" if args.unfused else ("stages_packed + warp_packed" if cfg == 4 else "sr_fused_u8"),
                    "mode": mode if strips else "frames", "parallelism": par, "ranks_reported_by_rccl": rccl_ranks,
+                   "backend": ("gloo (ranks share one GPU: test hook, not a measurement)" if share_gpu else ("nccl" if world > 1 else None)),
                    "channels": C, "scale": list(scale)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
@@ -627,7 +638,7 @@ def main():
         r3 = 0 if cfg == 4 else S // 2              # the EMIT kernels of the warp path look up the tile itself, no stage-3 ring
         halo = ((64 + 2 * r3) * (192 // C + 2 * r3) * C) / float(64 * 192)
         wave_gathers = B_local * H * W * C * 60.0 * (1.0 + halo) / 64.0
-        n_cu = int(torch.cuda.get_device_properties(local_rank).multi_processor_count)
+        n_cu = int(torch.cuda.get_device_properties(dev_index).multi_processor_count)
         try:
             lds_ns, lds_ns_free = measure_lds_gather(torch, L, n_cu)           # measured in THIS run on THIS chip (~2 ms each)
         except Exception:                                                      # (never seen; the recorded figures of profiles/r04_bench.json then)
