@@ -312,17 +312,18 @@ def test_rccl_two_rank_halo_exchange_and_stitch(torch, tmp_path):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
 
 
-@pytest.mark.parametrize("launcher", ["bare", "torchrun"])
-def test_bench_two_ranks_on_one_shared_gpu(torch, launcher):
+@pytest.mark.parametrize("launcher,extra", [("bare", []), ("torchrun", []), ("bare", ["--config", "5", "--mode", "strips", "--frames", "2"]),
+                                            ("torchrun", ["--config", "5", "--mode", "blocks", "--frames", "2"])])
+def test_bench_two_ranks_on_one_shared_gpu(torch, launcher, extra):
     """bench.py's multi-rank code (rank -> device, barriers around the timed region, MAX over the ranks, rank 0 prints the one
-    line, weak-scaling aggregate) run for real on a one-GPU box: LERF_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 and the
-    collectives on gloo (RCCL refuses two ranks on one device).  Both ways the driver may start it: bare (the GPU-free parent
-    spawns the ranks) and under torch.distributed.run."""
+    line, weak-scaling aggregate; config 5: the strip / block partition with its pack, exchange and unpack every step) run for
+    real on a one-GPU box: LERF_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 and the collectives on gloo (RCCL refuses two ranks
+    on one device).  Both ways the driver may start it: bare (the GPU-free parent spawns the ranks) and under torch.distributed.run."""
     import json
     env = dict(os.environ, LERF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    args = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained", "0"]
+    args = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained", "0"] + extra
     if launcher == "bare":
         cmd = [sys.executable] + args
     else:
@@ -337,7 +338,12 @@ def test_bench_two_ranks_on_one_shared_gpu(torch, launcher):
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3 and j["value"] > 0
-    assert j["config"]["backend"].startswith("gloo") and j["config"]["frames_per_step_per_gpu"] == 8
-    # the aggregate counts both ranks' frames: 2 x 8 frames of 3840 x 2160 per step
-    assert abs(j["value"] - 2 * 8 * 3840 * 2160 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * j["value"]
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["config"]["backend"].startswith("gloo")
+    if not extra:
+        assert j["scaling"] == "weak" and j["config"]["frames_per_step_per_gpu"] == 8
+        # the aggregate counts both ranks' frames: 2 x 8 frames of 3840 x 2160 per step
+        assert abs(j["value"] - 2 * 8 * 3840 * 2160 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * j["value"]
+    else:
+        assert j["scaling"] == "strong" and j["config"]["mode"] == extra[3]
+        # strong scaling: the batch of whole 8K frames once, whatever the number of ranks
+        assert abs(j["value"] - 2 * 7680 * 4320 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * j["value"]
