@@ -196,8 +196,9 @@ def measure_lds_gather(torch, L, n_cu, target_ms=2.0):
 
 def end_to_end_legs(torch, L, eng, frame_u8, scale, B):
     """SURVEY 8(d) 'end-to-end incl. H2D/D2H, reported separately': host buffer in -> host buffer out for one 1080p frame,
-    (a) pageable numpy through LerfEngine.sr, (b) pinned buffers with async copies on one stream, (c) stream.StreamingSR:
-    the kernel reads / writes the pinned host buffers itself, B frames per launch, two slots in flight.  Never `value`."""
+    (a) pageable numpy through LerfEngine.sr, (b) pinned buffers with async copies on one stream, (c) stream.StreamingSR, B frames per launch:
+    the kernel reads / writes the pinned host buffers itself (two slots), and (d) upload / launch / download of neighbouring batches on three
+    streams (three slots).  Never `value`."""
     from lerf_pytorch_amd.stream import StreamingSR
     H, W = frame_u8.shape[:2]
     out = {}
@@ -224,26 +225,27 @@ def end_to_end_legs(torch, L, eng, frame_u8, scale, B):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
     out["pinned_async_copies"] = {"ms_per_frame": round(dt * 1e3, 3), "mpix_s": round(opx / dt / 1e6, 1)}
-    st = StreamingSR(eng, (H, W), scale, frames_per_batch=B, depth=2)
-    for k in range(st.depth):
-        st.input(k)[:] = frame_u8
-    for _ in range(2):
-        st.result(st.submit())
-    nb = 6
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    pend = []
-    for _ in range(nb):
-        if len(pend) == st.depth:
+    for transport, key in (("zero_copy", "streaming_zero_copy"), ("dma", "streaming_dma_pipeline")):
+        st = StreamingSR(eng, (H, W), scale, frames_per_batch=B, transport=transport)
+        for k in range(st.depth):
+            st.input(k)[:] = frame_u8
+        for _ in range(3):
+            st.result(st.submit())
+        nb = 9
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        pend = []
+        for _ in range(nb):
+            if len(pend) == st.depth:
+                st.result(pend.pop(0))
+            pend.append(st.submit())
+        while pend:
             st.result(pend.pop(0))
-        pend.append(st.submit())
-    while pend:
-        st.result(pend.pop(0))
-    dt = (time.perf_counter() - t) / (nb * B)
-    out["streaming_zero_copy"] = {"ms_per_frame": round(dt * 1e3, 3), "mpix_s": round(opx / dt / 1e6, 1), "frames_per_launch": B}
+        dt = (time.perf_counter() - t) / (nb * B)
+        out[key] = {"ms_per_frame": round(dt * 1e3, 3), "mpix_s": round(opx / dt / 1e6, 1), "frames_per_launch": B, "slots": st.depth}
+        del st
     out["note"] = ("host uint8 frame in -> host uint8 frame out, %dx%d -> %dx%d, PCIe inside the figure (%.1f MB in + %.1f MB out per frame); "
                    "reported beside `value`, never as it" % (W, H, o.shape[1], o.shape[0], frame_u8.nbytes / 1e6, o.nbytes / 1e6))
-    del st
     return out
 
 

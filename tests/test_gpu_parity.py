@@ -611,14 +611,21 @@ def test_engine_downscale_vs_oracle(eng_g, eng_l, oracle, luts_g, luts_l, model,
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-9, equal_nan=True)
 
 
-def test_streaming_sr_matches_engine(torch, eng_g):
-    """host -> host pipeline (kernel I/O on pinned host memory) returns the same bytes as the synchronous engine."""
+@pytest.mark.parametrize("transport", ["dma", "zero_copy"])
+def test_streaming_sr_matches_engine(torch, eng_g, transport):
+    """host -> host pipeline (copy engines beside the kernel on three streams, or kernel I/O on pinned host memory) returns
+    the same bytes as the synchronous engine, batch after batch through the reused slots."""
     from lerf_pytorch_amd.stream import StreamingSR
     rng = np.random.default_rng(12)
-    batches = [rng.integers(0, 256, (2, 40, 52, 3), dtype=np.uint8) for _ in range(5)]
-    st = StreamingSR(eng_g, (40, 52), 2, frames_per_batch=2, depth=2)
+    batches = [rng.integers(0, 256, (2, 40, 52, 3), dtype=np.uint8) for _ in range(7)]
+    st = StreamingSR(eng_g, (40, 52), 2, frames_per_batch=2, depth=2, transport=transport)
     outs = [o.copy() for o in st.run(batches)]
-    assert len(outs) == 5
+    assert len(outs) == 7
+    st3 = StreamingSR(eng_g, (40, 52), 2, frames_per_batch=2, transport=transport)         # default depth
+    assert st3.depth == (3 if transport == "dma" else 2)
+    assert all(np.array_equal(a, b) for a, b in zip(outs, [o.copy() for o in st3.run(batches)]))
+    with pytest.raises(ValueError):
+        StreamingSR(eng_g, (40, 52), 2, transport="carrier pigeon")
     for b, o in zip(batches, outs):
         assert np.array_equal(o, eng_g.sr(torch.from_numpy(b).cuda(), 2).cpu().numpy())
     st.input()[:] = batches[1]                     # producer fills the pinned buffer itself

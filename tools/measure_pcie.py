@@ -22,7 +22,7 @@ print("pinned host buffers, async copies on one stream: %.3f ms/frame = %.1f Mpi
 
 from lerf_pytorch_amd.stream import StreamingSR
 for B in (1, 4, 8):
-    st = StreamingSR(eng, (1080, 1920), 2, frames_per_batch=B, depth=2)
+    st = StreamingSR(eng, (1080, 1920), 2, frames_per_batch=B, depth=2, transport="zero_copy")
     for k in range(st.depth): st.input(k)[:] = img                # the producer writes straight into the pinned inputs
     for _ in range(3): st.result(st.submit())
     nb = max(6, 48 // B)
