@@ -374,6 +374,7 @@ def asdevice(a, dtype=None):
 
 # ---- host -> device
 _STAGE = {}          # (nbytes) -> [slots, next]; a slot = (pinned tensor, its numpy view, event of its last copy)
+_STAGE_LOCK = __import__("threading").Lock()      # the ring is shared by every caller of the process
 _STAGE_MIN = 1 << 20
 _STAGE_MAX_BYTES = 256 << 20
 
@@ -389,23 +390,24 @@ def upload(a):
     if a.nbytes < _STAGE_MIN or a.dtype.hasobject:
         return torch.from_numpy(a).cuda()
     tdt = _torch_dtype(torch, a.dtype)                 # raises for dtypes torch does not have, before anything is staged
-    ring = _STAGE.get(a.nbytes)
-    if ring is None:
-        if sum(k * 2 for k in _STAGE) + 2 * a.nbytes > _STAGE_MAX_BYTES:
-            _STAGE.clear()
-        ring = _STAGE[a.nbytes] = [[], 0]
-        for _ in range(2):
-            t = torch.empty(a.nbytes, dtype=torch.uint8).pin_memory()
-            ring[0].append([t, t.numpy(), None])
-    slot = ring[0][ring[1] & 1]
-    ring[1] += 1
-    if slot[2] is not None:
-        slot[2].synchronize()
-    np.copyto(slot[1], a.reshape(-1).view(np.uint8))
-    d = slot[0].cuda(non_blocking=True).view(tdt).reshape(a.shape)
-    ev = torch.cuda.Event()
-    ev.record()
-    slot[2] = ev
+    with _STAGE_LOCK:
+        ring = _STAGE.get(a.nbytes)
+        if ring is None:
+            if sum(k * 2 for k in _STAGE) + 2 * a.nbytes > _STAGE_MAX_BYTES:
+                _STAGE.clear()
+            ring = _STAGE[a.nbytes] = [[], 0]
+            for _ in range(2):
+                t = torch.empty(a.nbytes, dtype=torch.uint8).pin_memory()
+                ring[0].append([t, t.numpy(), None])
+        slot = ring[0][ring[1] & 1]
+        ring[1] += 1
+        if slot[2] is not None:
+            slot[2].synchronize()
+        np.copyto(slot[1], a.reshape(-1).view(np.uint8))
+        d = slot[0].cuda(non_blocking=True).view(tdt).reshape(a.shape)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[2] = ev
     return d
 
 
