@@ -59,7 +59,9 @@ def _torch_to_np_dtype(dt):
 
 HANDLED = {}
 _UFUNC_OPS = {np.add: ("__add__", "__radd__"), np.subtract: ("__sub__", "__rsub__"), np.multiply: ("__mul__", "__rmul__"),
-              np.true_divide: ("__truediv__", "__rtruediv__")}
+              np.true_divide: ("__truediv__", "__rtruediv__"),
+              np.equal: ("__eq__", "__eq__"), np.not_equal: ("__ne__", "__ne__"), np.less: ("__lt__", "__gt__"),
+              np.less_equal: ("__le__", "__ge__"), np.greater: ("__gt__", "__lt__"), np.greater_equal: ("__ge__", "__le__")}
 
 
 def _implements(*funcs):
@@ -85,38 +87,75 @@ def _host(x):
     return x
 
 
+_PY_SCALARS = (bool, int, float)
+
+
+def _result_dtype(ufunc, a, b):
+    """numpy's OWN result dtype for `ufunc(a, b)`, by running it on empty arrays of the operands' dtypes (python scalars stay
+    python scalars: numpy 2's weak promotion; numpy scalars stay strongly typed).  None when numpy would raise (e.g.
+    uint8 + 300) -- the caller then takes the host path and gets numpy's own error."""
+    def probe(x):
+        if isinstance(x, DeviceArray):
+            return np.empty(0, dtype=x.dtype)
+        if isinstance(x, np.ndarray):
+            return np.empty(0, dtype=x.dtype) if x.ndim else x[()]
+        return x
+    try:
+        return ufunc(probe(a), probe(b)).dtype
+    except Exception:
+        return None
+
+
 class DeviceArray(object):
-    """An ndarray-shaped view of a torch CUDA tensor.  See the module docstring for what stays on the device."""
+    """An ndarray-shaped view of a torch tensor (a CUDA tensor in product use).  See the module docstring for what stays on
+    the device.  Contract: every operation gives numpy's value AND dtype; whatever the device path cannot guarantee that for
+    runs on the host copy (numpy's own result).  Views made by transpose / reshape / basic indexing share their base's storage
+    as in numpy: a write through any of them (`a[idx] = v`, `a += v`, `out=a`) is seen by all, and drops every cached host copy.
+    Not an `np.ndarray` subclass (`isinstance(x, np.ndarray)` is False -- INTEGRATION.md section 2)."""
     __array_priority__ = 1000.0
 
-    def __init__(self, t):
+    def __init__(self, t, base=None):
         self.t = t
         self._np = None
+        self._np_ver = -1
+        self._vc = base._vc if base is not None else [0]      # version cell shared by all views of one storage
 
     # ---- ndarray surface
     shape = property(lambda self: tuple(self.t.shape))
     ndim = property(lambda self: self.t.dim())
     size = property(lambda self: self.t.numel())
     dtype = property(lambda self: np.dtype(_torch_to_np_dtype(self.t.dtype)))
-    T = property(lambda self: DeviceArray(self.t.permute(*reversed(range(self.t.dim())))))
+    itemsize = property(lambda self: self.t.element_size())
+    nbytes = property(lambda self: self.t.numel() * self.t.element_size())
+    T = property(lambda self: self.transpose())
 
     def __len__(self):
+        if self.t.dim() == 0:
+            raise TypeError("len() of unsized object")          # numpy's words; torch's sequence walk relies on the TypeError
         return self.t.shape[0]
 
     def __repr__(self):
         return "DeviceArray(shape=%s, dtype=%s, device=%s)" % (self.shape, self.dtype, self.t.device)
 
+    def _touch(self):
+        """the storage was written: every cached host copy of it is stale"""
+        self._vc[0] += 1
+        self._np = None
+
     def numpy(self):
-        """the host copy (made once; the object is treated as immutable by everything in this package)"""
-        if self._np is None:
-            self._np = download(self.t)
+        """the host copy: made once per version of the storage, READ-ONLY (a write into it could not reach the device; numpy
+        raises instead of losing it -- `np.array(x)` / `x.copy()` give writable arrays)"""
+        if self._np is None or self._np_ver != self._vc[0]:
+            a = download(self.t)
+            a.flags.writeable = False
+            self._np, self._np_ver = a, self._vc[0]
         return self._np
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
         if dtype is not None and np.dtype(dtype) != a.dtype:
             return a.astype(dtype)
-        return a.copy() if copy else a
+        return a.copy(order="K") if copy else a
 
     @property
     def __array_interface__(self):
@@ -127,114 +166,253 @@ class DeviceArray(object):
         d["strides"] = a.strides
         return d
 
+    # torch.Tensor(x) / torch.tensor(x) / torch.as_tensor(x) (the warp harness builds its mPSNR operands that way,
+    # resample/eval_lut_warp.py:225-233) look for DLPack before they walk an object as a sequence.  The export is a HOST tensor
+    # -- to torch this object is what it is to numpy, a CPU array -- and a private copy, so that nothing aliases the cache.
+    def __dlpack__(self, *a, **k):
+        return _torch().from_numpy(self.numpy().copy(order="K")).__dlpack__()
+
+    def __dlpack_device__(self):
+        return (1, 0)                                           # kDLCPU
+
     def tobytes(self, *a, **k):
         return self.numpy().tobytes(*a, **k)
 
+    def tolist(self):
+        return self.numpy().tolist()
+
+    def item(self, *a):
+        return self.numpy().item(*a)
+
     def astype(self, dtype, *a, **k):
         td = _np_to_torch_dtype(dtype)
-        if td is None:
+        if td is None or a or k:
             return self.numpy().astype(dtype, *a, **k)
-        return DeviceArray(self.t.to(td))             # float -> integer truncates, as numpy's conversion does
+        t = self.t
+        if t.is_floating_point() and not td.is_floating_point and td != _torch().bool:
+            # float -> integer: numpy truncates toward zero and wraps modulo 2^n through int64 for out-of-range values on
+            # this platform; torch's direct conversion saturates or is undefined there.  Via int64 both agree for every
+            # finite value below 2^63 (the call sites convert clip(round(.), 0, 255)).
+            t = t.to(_torch().int64)
+        return DeviceArray(t.to(td, copy=True))
 
     def transpose(self, *axes):
         if len(axes) == 1 and isinstance(axes[0], (tuple, list)):
             axes = tuple(axes[0])
         if not axes or axes == (None,):
             axes = tuple(reversed(range(self.t.dim())))
-        return DeviceArray(self.t.permute(*axes))
+        return DeviceArray(self.t.permute(*axes), base=self)
 
-    def reshape(self, *shape):
+    def reshape(self, *shape, **kw):
+        if kw:
+            return self.numpy().reshape(*shape, **kw)
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])
-        return DeviceArray(self.t.reshape(*shape))
+        return DeviceArray(self.t.reshape(*shape), base=self)     # a view where torch can make one, like numpy
 
-    def copy(self):
+    def copy(self, *a, **k):
         return DeviceArray(self.t.clone())
 
     def round(self, decimals=0, out=None):
         if decimals != 0 or out is not None:
-            return self.numpy().round(decimals, out)
-        return DeviceArray(self.t.round() if self.t.is_floating_point() else self.t)      # half to even, like np.round
+            return _with_out(lambda: self.numpy().round(decimals), out)
+        return DeviceArray(self.t.round() if self.t.is_floating_point() else self.t.clone())      # half to even, like np.round
 
     def clip(self, min=None, max=None, out=None, **kw):
-        if out is not None or kw:
-            return self.numpy().clip(min, max, out, **kw)
-        return DeviceArray(self.t.clamp(min=_scalar(min), max=_scalar(max)))
+        lo, hi = _scalar(min), _scalar(max)
+        ok = (not kw and (lo is not None or hi is not None) and all(v is None or isinstance(v, _PY_SCALARS) for v in (lo, hi))
+              and _result_dtype(np.add, self, 0 if lo is None else lo) == self.dtype
+              and _result_dtype(np.add, self, 0 if hi is None else hi) == self.dtype)
+        if not ok or out is not None:
+            return _with_out(lambda: self.numpy().clip(_host(min), _host(max), **kw), out)
+        return DeviceArray(self.t.clamp(min=lo, max=hi))
 
     def __getattr__(self, name):
-        # anything else an ndarray offers (max, mean, tobytes, flags ...): on the host copy
-        if name.startswith("__") or name in ("t", "_np"):
+        # anything else an ndarray offers (max, mean, flags ...): on the (read-only) host copy
+        if name.startswith("__") or name in ("t", "_np", "_np_ver", "_vc"):
             raise AttributeError(name)
         return getattr(self.numpy(), name)
 
-    def __getitem__(self, idx):
-        try:
-            return DeviceArray(self.t[idx])
-        except (TypeError, IndexError, RuntimeError):
-            return self.numpy()[idx]
-
-    # ---- arithmetic with scalars and other arrays (numpy's result types: float64 stays float64, float32 with python
-    #      scalars stays float32)
-    def _bin(self, other, op, reflected=False):
+    # ---- indexing.  On the device: basic indices (a view, as in numpy) and ONE advanced index among slices (the call
+    #      sites' img_hyper[[0, 3, 6], :, :] and a[mask]); combinations whose axis placement rules are subtle: host copy.
+    def _index(self, idx):
+        """-> (torch index, is_view) or None"""
         torch = _torch()
-        o = other
-        if isinstance(o, DeviceArray):
-            o = o.t
-        elif isinstance(o, np.ndarray):
-            if o.ndim == 0:
-                o = o.item()
+        items = idx if isinstance(idx, tuple) else (idx,)
+        out, adv, ints = [], 0, 0
+        for it in items:
+            if isinstance(it, DeviceArray):
+                it = it.t
+            if it is None or it is Ellipsis or isinstance(it, slice):
+                out.append(it)
+            elif isinstance(it, (int, np.integer)) and not isinstance(it, (bool, np.bool_)):
+                out.append(int(it))
+                ints += 1
+            elif isinstance(it, (list, np.ndarray, torch.Tensor)):
+                if isinstance(it, list):
+                    it = np.asarray(it)
+                    if it.dtype.kind not in "iub" or it.ndim != 1:
+                        return None
+                if isinstance(it, np.ndarray):
+                    if it.dtype.kind not in "iub":
+                        return None
+                    it = torch.from_numpy(np.ascontiguousarray(it if it.dtype.kind == "b" else it.astype(np.int64))).to(self.t.device)
+                elif it.dtype not in (torch.bool, torch.int64, torch.int32, torch.uint8, torch.int16, torch.int8):
+                    return None
+                elif it.dtype not in (torch.bool, torch.int64):
+                    it = it.to(torch.int64)
+                out.append(it.to(self.t.device))
+                adv += 1
             else:
-                td = _np_to_torch_dtype(o.dtype)
-                if td is None:
-                    return NotImplemented
-                o = torch.from_numpy(np.ascontiguousarray(o)).to(self.t.device)
-        elif isinstance(o, (np.generic,)):
-            o = o.item()
-        elif not isinstance(o, (int, float, bool)):
-            return NotImplemented
-        a, b = (o, self.t) if reflected else (self.t, o)
-        return DeviceArray(op(a, b))
+                return None
+        if adv > 1 or (adv == 1 and ints):
+            return None
+        return (tuple(out) if isinstance(idx, tuple) else out[0]), adv == 0
 
-    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
-    def __radd__(self, o): return self._bin(o, lambda a, b: a + b, True)
-    def __iadd__(self, o): return self._bin(o, lambda a, b: a + b)          # a fresh array: `pred += x` rebinds `pred`
-    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
-    def __rsub__(self, o): return self._bin(o, lambda a, b: a - b, True)
-    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
-    def __rmul__(self, o): return self._bin(o, lambda a, b: a * b, True)
+    def __getitem__(self, idx):
+        ti = self._index(idx)
+        if ti is None:
+            return self.numpy()[_host(idx)]
+        try:
+            r = self.t[ti[0]]
+        except (TypeError, IndexError, RuntimeError):
+            return self.numpy()[_host(idx)]                                     # numpy's own error for a bad index
+        if r.dim() == 0 and ti[1] and not _has_ellipsis_or_none(idx):
+            return self.dtype.type(r.item())                                    # a[i, j, k] is a scalar in numpy
+        return DeviceArray(r, base=self if ti[1] else None)
 
-    # Division by a host scalar: torch multiplies by the reciprocal when the divisor is a CPU scalar (one rounding more than
-    # numpy's IEEE division: (N / 16) / 3 at N = 48 k + 24 must be exactly k + 0.5 for the round-half-even that follows).
-    # The scalar therefore travels as a 0-dim DEVICE tensor of the array's dtype: a true division.
-    def _div(self, o, reflected):
+    def __setitem__(self, idx, value):
         torch = _torch()
-        t = self.t if self.t.is_floating_point() else self.t.to(torch.float64)    # numpy: int / x -> float64
-        if isinstance(o, (np.generic,)) or (isinstance(o, np.ndarray) and o.ndim == 0):
+        ti = self._index(idx)
+        v = value
+        if isinstance(v, DeviceArray):
+            v = v.t
+        elif isinstance(v, np.ndarray):
+            v = v[()] if v.ndim == 0 else (torch.from_numpy(np.ascontiguousarray(v)).to(self.t.device)
+                                          if _np_to_torch_dtype(v.dtype) is not None else None)
+        if isinstance(v, np.generic):
+            v = v.item()
+        dev_ok = ti is not None and (isinstance(v, _PY_SCALARS) or isinstance(v, torch.Tensor))
+        if dev_ok and isinstance(v, _PY_SCALARS) and not self.t.is_floating_point():
+            # numpy 2 refuses out-of-range python integers for integer arrays and truncates floats: host rules
+            dev_ok = isinstance(v, (bool, int)) and np.can_cast(np.min_scalar_type(v), self.dtype, "safe")
+        if dev_ok and isinstance(v, torch.Tensor) and v.is_floating_point() and not self.t.is_floating_point():
+            v = v.to(torch.int64)                                               # numpy's float -> int conversion (see astype)
+        if dev_ok:
+            try:
+                self.t[ti[0]] = v
+                self._touch()
+                return
+            except (TypeError, IndexError, RuntimeError):
+                pass
+        h = self.numpy().copy()
+        h[_host(idx)] = _host(value)                                            # numpy's own semantics and errors
+        self.t.copy_(torch.from_numpy(h).to(self.t.device))
+        self._touch()
+
+    # ---- arithmetic.  The result dtype is numpy's (`_result_dtype`); the operands are cast to it on the device, which
+    #      is what numpy's loops do for + - * and comparisons never reach this path with integer arrays.
+    def _operand(self, o, rd):
+        """other operand -> torch tensor / python scalar usable with a tensor of numpy dtype `rd`; NotImplemented if none"""
+        torch = _torch()
+        td = _np_to_torch_dtype(rd)
+        if isinstance(o, DeviceArray):
+            return o.t.to(td)
+        if isinstance(o, np.ndarray):
+            if o.ndim == 0:
+                o = o[()]
+            elif _np_to_torch_dtype(o.dtype) is None:
+                return NotImplemented
+            else:
+                return torch.from_numpy(np.ascontiguousarray(o)).to(self.t.device).to(td)
+        if isinstance(o, np.generic):
             o = o.item()
-        if isinstance(o, (int, float, bool)):
-            o = DeviceArray(torch.full((), float(o), dtype=t.dtype, device=t.device))
-        return DeviceArray(t)._bin(o, lambda a, b: torch.true_divide(a, b), reflected)
+        if isinstance(o, _PY_SCALARS):
+            if rd.kind == "f":
+                # as a 0-dim device tensor of the result dtype: the value numpy's loop would see (a python float rounded to
+                # float32 for a float32 array), and torch treats it as an array operand, not as a reciprocal / opmath scalar
+                return torch.full((), float(o), dtype=td, device=self.t.device)
+            return o
+        return NotImplemented
 
-    def __truediv__(self, o):
-        return self._div(o, False)
+    def _bin(self, other, ufunc, op, reflected=False, inplace=False):
+        rd = _result_dtype(ufunc, other, self) if reflected else _result_dtype(ufunc, self, other)
+        if rd is None or _np_to_torch_dtype(rd) is None or not isinstance(other, (DeviceArray, np.ndarray, np.generic) + _PY_SCALARS) \
+                or rd.kind not in "fiub" or (rd.kind != "f" and ufunc is np.true_divide):
+            return self._host_bin(other, ufunc, reflected, inplace)
+        if rd.kind != "f" and not (ufunc in (np.add, np.subtract, np.multiply) and isinstance(other, (DeviceArray, np.ndarray))):
+            return self._host_bin(other, ufunc, reflected, inplace)             # integer arrays with scalars: numpy's range checks
+        o = self._operand(other, rd)
+        if o is NotImplemented:
+            return self._host_bin(other, ufunc, reflected, inplace)
+        if inplace:
+            if rd != self.dtype:
+                return self._host_bin(other, ufunc, reflected, inplace)         # numpy's casting rule decides (usually an error)
+            try:
+                op(self.t, o, out=self.t)
+            except RuntimeError:                                                # the operand does not broadcast INTO self
+                return self._host_bin(other, ufunc, reflected, inplace)
+            self._touch()
+            return self
+        a = self.t.to(_np_to_torch_dtype(rd))
+        try:
+            return DeviceArray(op(o, a) if reflected else op(a, o))
+        except RuntimeError:
+            return self._host_bin(other, ufunc, reflected, inplace)
 
-    def __rtruediv__(self, o):
-        return self._div(o, True)
+    def _host_bin(self, other, ufunc, reflected, inplace):
+        if inplace:
+            h = self.numpy().copy()
+            ufunc(h, _host(other), out=h)                                       # numpy's own casting errors
+            self.t.copy_(_torch().from_numpy(h).to(self.t.device))
+            self._touch()
+            return self
+        return ufunc(_host(other), self.numpy()) if reflected else ufunc(self.numpy(), _host(other))
 
-    def __neg__(self): return DeviceArray(-self.t)
-    def __abs__(self): return DeviceArray(self.t.abs())
+    def _t(name):
+        return lambda a, b, out=None: getattr(_torch(), name)(a, b, out=out) if out is not None else getattr(_torch(), name)(a, b)
 
-    # comparisons on the device (boolean arrays, like numpy's); a comparison torch cannot form falls back to the host copy
-    def _cmp(self, o, op, hop):
-        r = self._bin(o, op)
-        return hop(self.numpy(), _host(o)) if r is NotImplemented else r
+    def __add__(self, o): return self._bin(o, np.add, DeviceArray._add)
+    def __radd__(self, o): return self._bin(o, np.add, DeviceArray._add, True)
+    def __iadd__(self, o): return self._bin(o, np.add, DeviceArray._add, inplace=True)     # in place, like numpy
+    def __sub__(self, o): return self._bin(o, np.subtract, DeviceArray._sub)
+    def __rsub__(self, o): return self._bin(o, np.subtract, DeviceArray._sub, True)
+    def __isub__(self, o): return self._bin(o, np.subtract, DeviceArray._sub, inplace=True)
+    def __mul__(self, o): return self._bin(o, np.multiply, DeviceArray._mul)
+    def __rmul__(self, o): return self._bin(o, np.multiply, DeviceArray._mul, True)
+    def __imul__(self, o): return self._bin(o, np.multiply, DeviceArray._mul, inplace=True)
+    # Division: IEEE on the device because the divisor is a device TENSOR (`_operand`): torch multiplies by the reciprocal
+    # when the divisor is a host scalar -- one rounding more than numpy's division ((N / 16) / 3 at N = 48 k + 24 must be
+    # exactly k + 0.5 for the round-half-even that follows).
+    def __truediv__(self, o): return self._bin(o, np.true_divide, DeviceArray._div)
+    def __rtruediv__(self, o): return self._bin(o, np.true_divide, DeviceArray._div, True)
+    def __itruediv__(self, o): return self._bin(o, np.true_divide, DeviceArray._div, inplace=True)
 
-    def __eq__(self, o): return self._cmp(o, lambda a, b: a == b, lambda a, b: a == b)
-    def __ne__(self, o): return self._cmp(o, lambda a, b: a != b, lambda a, b: a != b)
-    def __lt__(self, o): return self._cmp(o, lambda a, b: a < b, lambda a, b: a < b)
-    def __le__(self, o): return self._cmp(o, lambda a, b: a <= b, lambda a, b: a <= b)
-    def __gt__(self, o): return self._cmp(o, lambda a, b: a > b, lambda a, b: a > b)
-    def __ge__(self, o): return self._cmp(o, lambda a, b: a >= b, lambda a, b: a >= b)
+    def __neg__(self): return DeviceArray(-self.t) if self.t.is_floating_point() else -self.numpy()
+    def __pos__(self): return self.copy()
+    def __abs__(self): return DeviceArray(self.t.abs()) if self.t.is_floating_point() else abs(self.numpy())
+
+    # comparisons: boolean arrays like numpy's; on the device for floating-point arrays against arrays / scalars (the warp
+    # harness' `mask_output == 255`), else numpy's own result (python integers out of an integer dtype's range etc.)
+    def _cmp(self, o, ufunc, op):
+        torch = _torch()
+        if self.t.is_floating_point() and isinstance(o, (DeviceArray, np.ndarray, np.generic) + _PY_SCALARS):
+            ct = _result_dtype(np.add, self, o)                                # the common type numpy compares in
+            if ct is not None and ct.kind == "f" and _np_to_torch_dtype(ct) is not None:
+                b = self._operand(o, ct)
+                if b is not NotImplemented:
+                    try:
+                        return DeviceArray(op(self.t.to(_np_to_torch_dtype(ct)), b))
+                    except RuntimeError:
+                        pass
+        return ufunc(self.numpy(), _host(o))
+
+    def __eq__(self, o): return self._cmp(o, np.equal, lambda a, b: a == b)
+    def __ne__(self, o): return self._cmp(o, np.not_equal, lambda a, b: a != b)
+    def __lt__(self, o): return self._cmp(o, np.less, lambda a, b: a < b)
+    def __le__(self, o): return self._cmp(o, np.less_equal, lambda a, b: a <= b)
+    def __gt__(self, o): return self._cmp(o, np.greater, lambda a, b: a > b)
+    def __ge__(self, o): return self._cmp(o, np.greater_equal, lambda a, b: a >= b)
     __hash__ = None
 
     def __bool__(self):
@@ -246,27 +424,48 @@ class DeviceArray(object):
     def __int__(self):
         return int(self.numpy())
 
+    def __index__(self):
+        return self.numpy().__index__()
+
     # the rest of the operator table: numpy's own result on the host copy
     def __pow__(self, o): return self.numpy() ** _host(o)
     def __rpow__(self, o): return _host(o) ** self.numpy()
     def __mod__(self, o): return self.numpy() % _host(o)
+    def __rmod__(self, o): return _host(o) % self.numpy()
     def __floordiv__(self, o): return self.numpy() // _host(o)
+    def __rfloordiv__(self, o): return _host(o) // self.numpy()
     def __and__(self, o): return self.numpy() & _host(o)
+    def __rand__(self, o): return _host(o) & self.numpy()
     def __or__(self, o): return self.numpy() | _host(o)
+    def __ror__(self, o): return _host(o) | self.numpy()
     def __xor__(self, o): return self.numpy() ^ _host(o)
+    def __rxor__(self, o): return _host(o) ^ self.numpy()
     def __invert__(self): return ~self.numpy()
     def __matmul__(self, o): return self.numpy() @ _host(o)
-    def __iter__(self): return iter(self.numpy())
+    def __rmatmul__(self, o): return _host(o) @ self.numpy()
+    def __iter__(self):
+        if self.t.dim() == 0:
+            raise TypeError("iteration over a 0-d array")
+        return iter(self.numpy())
 
     # ---- numpy protocol: the handful of functions of the call sites run on the device, everything else on the host copy
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        out = kwargs.get("out")
+        if out is not None and any(isinstance(o, DeviceArray) for o in out):
+            # results INTO device arrays: numpy's value (host), then written through to the device storage
+            kw = {k: _host(v) for k, v in kwargs.items() if k != "out"}
+            r = getattr(ufunc, method)(*_host(inputs), **kw)
+            rs = r if isinstance(r, tuple) else (r,)
+            for o, v in zip(out, rs):
+                if o is not None:
+                    o[...] = v
+            got = tuple(o if o is not None else v for o, v in zip(out, rs))
+            return got if isinstance(r, tuple) else got[0]
         if method == "__call__" and not kwargs:
             names = _UFUNC_OPS.get(ufunc)
             if names is not None and len(inputs) == 2:
                 a, b = inputs
-                r = getattr(a, names[0])(b) if isinstance(a, DeviceArray) else getattr(b, names[1])(a)
-                if r is not NotImplemented:
-                    return r
+                return getattr(a, names[0])(b) if isinstance(a, DeviceArray) else getattr(b, names[1])(a)
             if ufunc is np.rint and len(inputs) == 1:
                 return self.round()
         return getattr(ufunc, method)(*_host(inputs), **_host(kwargs))
@@ -277,7 +476,29 @@ class DeviceArray(object):
             r = h(*args, **kwargs)
             if r is not NotImplemented:
                 return r
+        out = kwargs.get("out")
+        if isinstance(out, DeviceArray):
+            return _with_out(lambda: func(*_host(args), **{k: _host(v) for k, v in kwargs.items() if k != "out"}), out)
         return func(*_host(args), **_host(kwargs))
+
+
+for _n, _f in (("_add", "add"), ("_sub", "sub"), ("_mul", "mul"), ("_div", "true_divide")):
+    setattr(DeviceArray, _n, staticmethod(DeviceArray._t(_f)))
+del DeviceArray._t
+
+
+def _has_ellipsis_or_none(idx):
+    items = idx if isinstance(idx, tuple) else (idx,)
+    return any(it is None or it is Ellipsis for it in items)
+
+
+def _with_out(compute, out):
+    """numpy's result of `compute()`; into `out` when one is given (a DeviceArray is written through to the device)"""
+    r = compute()
+    if out is None:
+        return r
+    out[...] = r
+    return out
 
 
 def _scalar(v):
@@ -295,9 +516,9 @@ def _round(a, decimals=0, out=None):
 
 @_implements(np.clip)
 def _clip(a, a_min=None, a_max=None, out=None, **kw):
-    if not isinstance(a, DeviceArray) or out is not None or kw or isinstance(a_min, DeviceArray) or isinstance(a_max, DeviceArray):
+    if not isinstance(a, DeviceArray) or kw or isinstance(a_min, DeviceArray) or isinstance(a_max, DeviceArray):
         return NotImplemented
-    return a.clip(a_min, a_max)
+    return a.clip(a_min, a_max, out=out)
 
 
 @_implements(np.transpose)
@@ -307,6 +528,9 @@ def _transpose(a, axes=None):
 
 @_implements(np.rot90)
 def _rot90(m, k=1, axes=(0, 1)):
+    """a fresh array (numpy returns a view: a write through the rotated array does not reach `m` here)"""
+    if not isinstance(m, DeviceArray):
+        return NotImplemented
     torch = _torch()
     return DeviceArray(torch.rot90(m.t, int(k), [int(axes[0]), int(axes[1])]))
 
@@ -357,7 +581,7 @@ def _concatenate(arrays, axis=0, out=None, **kw):
 
 @_implements(np.expand_dims)
 def _expand_dims(a, axis):
-    return DeviceArray(a.t.unsqueeze(int(axis))) if isinstance(axis, (int, np.integer)) else NotImplemented
+    return DeviceArray(a.t.unsqueeze(int(axis)), base=a) if isinstance(axis, (int, np.integer)) else NotImplemented
 
 
 def asdevice(a, dtype=None):
@@ -373,38 +597,48 @@ def asdevice(a, dtype=None):
 
 
 # ---- host -> device
-_STAGE = {}          # (nbytes) -> [slots, next]; a slot = (pinned tensor, its numpy view, event of its last copy)
-_STAGE_LOCK = __import__("threading").Lock()      # the ring is shared by every caller of the process
+_STAGE = {}          # size class -> [slots, next]; a slot = [pinned tensor, its numpy view, event of its last copy]; LRU order
+_STAGE_LOCK = __import__("threading").Lock()      # the rings are shared by every caller of the process
 _STAGE_MIN = 1 << 20
 _STAGE_MAX_BYTES = 256 << 20
 
 
+def _size_class(n):
+    """bytes -> ring size: four classes per octave (at most 25 % slack), so a folder of photographs of assorted sizes
+    settles on a handful of rings instead of pinning two buffers per distinct byte count"""
+    step = 1 << max(n.bit_length() - 3, 12)
+    return (n + step - 1) // step * step
+
+
 def upload(a):
-    """contiguous numpy array -> CUDA tensor.  Arrays of 1 MB and more go through a ring of two pinned buffers per size: a
+    """contiguous numpy array -> CUDA tensor.  Arrays of 1 MB and more go through a ring of two pinned buffers per size class: a
     single-threaded `np.copyto` (0.9 ms per 25 MB) and an asynchronous copy, so the host neither waits for the device work queued
     before nor depends on the runtime's pageable path, which takes 0.55 ms per 25 MB on one host and 2.4 ms on the next
     (profiles/r04_experiments.txt); smaller ones take the plain pageable copy.  (torch's `pinned.copy_(pageable)` is not used: it
-    runs on the CPU thread pool, slow and erratic in a container with fewer CPUs than the machine shows.)"""
+    runs on the CPU thread pool, slow and erratic in a container with fewer CPUs than the machine shows.)  Rings are kept up to
+    256 MB of pinned memory in all; beyond that the least recently used ring goes."""
     torch = _torch()
     a = np.ascontiguousarray(a)
     if a.nbytes < _STAGE_MIN or a.dtype.hasobject:
         return torch.from_numpy(a).cuda()
     tdt = _torch_dtype(torch, a.dtype)                 # raises for dtypes torch does not have, before anything is staged
+    cls = _size_class(a.nbytes)
     with _STAGE_LOCK:
-        ring = _STAGE.get(a.nbytes)
+        ring = _STAGE.pop(cls, None)
         if ring is None:
-            if sum(k * 2 for k in _STAGE) + 2 * a.nbytes > _STAGE_MAX_BYTES:
-                _STAGE.clear()
-            ring = _STAGE[a.nbytes] = [[], 0]
+            while _STAGE and 2 * (sum(_STAGE) + cls) > _STAGE_MAX_BYTES:
+                _STAGE.pop(next(iter(_STAGE)))         # least recently used first (dicts keep insertion order)
+            ring = [[], 0]
             for _ in range(2):
-                t = torch.empty(a.nbytes, dtype=torch.uint8).pin_memory()
+                t = torch.empty(cls, dtype=torch.uint8).pin_memory()
                 ring[0].append([t, t.numpy(), None])
+        _STAGE[cls] = ring                             # (re-)inserted last = most recently used
         slot = ring[0][ring[1] & 1]
         ring[1] += 1
         if slot[2] is not None:
             slot[2].synchronize()
-        np.copyto(slot[1], a.reshape(-1).view(np.uint8))
-        d = slot[0].cuda(non_blocking=True).view(tdt).reshape(a.shape)
+        np.copyto(slot[1][:a.nbytes], a.reshape(-1).view(np.uint8))
+        d = slot[0][:a.nbytes].cuda(non_blocking=True).view(tdt).reshape(a.shape)
         ev = torch.cuda.Event()
         ev.record()
         slot[2] = ev
@@ -416,16 +650,29 @@ def _torch_dtype(torch, dt):
 
 
 def download(t):
-    """CUDA tensor -> numpy array.  1 MB and more land in a pinned host tensor from torch's caching host allocator (the DMA runs at
+    """torch tensor -> numpy array.  1 MB and more land in a pinned host tensor from torch's caching host allocator (the DMA runs at
     the link's rate: 0.6 ms instead of 2.9 ms for a 25 MB frame) and the array returned is a view of it -- ordinary writable
-    memory to its user, handed back to the allocator's cache when the array is dropped."""
+    memory to its user, handed back to the allocator's cache when the array is dropped.
+    The MEMORY LAYOUT is numpy's: the result of an elementwise operation on a transposed view is laid out like the view (order
+    'K'), and so is the array this returns for a permuted dense tensor -- torch's float32 reductions (the reference's mPSNR,
+    common/utils.py:168-175) add in memory order, so a C-contiguous copy would change their last bits."""
     torch = _torch()
+    t = t.detach()
+    perm = None
+    if t.dim() > 1 and not t.is_contiguous():
+        order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))
+        tp = t.permute(*order)
+        if tp.is_contiguous():                                 # a permutation of a dense array: copy it as it lies
+            t, perm = tp, [order.index(d) for d in range(len(order))]
     if not t.is_cuda:
-        return t.contiguous().numpy()
-    t = t.contiguous()
-    if t.numel() * t.element_size() < _STAGE_MIN:
-        return t.cpu().numpy()
-    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    h.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    return h.numpy()
+        a = t.contiguous().numpy().copy()                      # (CPU tensors: tests only) never an alias of the tensor
+    else:
+        t = t.contiguous()
+        if t.numel() * t.element_size() < _STAGE_MIN:
+            a = t.cpu().numpy()
+        else:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            a = h.numpy()
+    return a.transpose(perm) if perm is not None else a

@@ -79,6 +79,103 @@ def test_warp_worker_protocol_gives_the_reference_bytes(torch, oracle, model, p,
         lazy.set_enabled(True)
 
 
+@pytest.mark.parametrize("lazy_on", [True, False])
+@pytest.mark.parametrize("model,scale", [("lerf-g", 2), ("lerf-g", 3), ("lerf-l", 4)])
+def test_whole_sr_worker_to_its_last_statement(torch, oracle, tmp_path, model, scale, lazy_on):
+    """the SR worker to its END (resample/eval_lut_sr.py:514-744: the library calls, then Image.fromarray(...).save,
+    np.save of the hyper maps, the crop, the colour transform with its item assignment, PSNR, SSIM), lazy results on and off:
+    the reference's md5 of the output, its PSNR (float32 arithmetic: equal) and SSIM, and files that read back as the values."""
+    import callsite_driver as cd
+    from lerf_pytorch_amd import lazy
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["sr"]
+    ref8 = json.load(open(os.path.join(GOLDEN, "g8_ssim.json")))
+    linear = model == "lerf-l"
+    luts = cd.float_luts(oracle.load_luts(os.path.join(ASSETS, model), linear=linear))
+    interp, pads, resizer = cd.mirror_api(linear=linear)
+    lazy.set_enabled(lazy_on)
+    try:
+        for n in ("bird", "head"):
+            key = "%s/x%d/%s" % (model, scale, n)
+            lr = np.array(Image.open(os.path.join(DATA, "LR_bicubic/rrLR_X%.2f_%.2f" % (scale, scale), n + ".png"))).astype(np.float32)
+            gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+            keep = {}
+            out = cd.worker_sr(interp, pads, resizer, luts, lr, (scale, scale), out_c=1 if linear else 3, linear=linear, keep=keep)
+            assert isinstance(out, lazy.DeviceArray) == lazy_on
+            ps, ss = cd.tail_sr(out, keep["feat_chw"], keep["hyper"], gt, (scale, scale), str(tmp_path), n)
+            assert float(ps) == pytest.approx(ref[key]["psnr_y"], abs=1e-5) and float(ss) == pytest.approx(ref8[key]["ssim"], abs=1e-9)
+            saved = np.array(Image.open(os.path.join(str(tmp_path), n + "_LUTft.png")))
+            assert _md5(saved) == ref[key]["md5_out"]
+            assert _md5(np.array(Image.open(os.path.join(str(tmp_path), n + "_lr.png")))) == ref[key]["md5_feat"]
+            hy = np.load(os.path.join(str(tmp_path), n + "_LUTft_hyper.npy"))
+            assert hy.dtype == np.float32 and _md5(np.round(hy * 255).astype(np.uint8).transpose((1, 2, 0))) == ref[key]["md5_hq"]
+    finally:
+        lazy.set_enabled(True)
+
+
+@pytest.mark.parametrize("lazy_on", [True, False])
+@pytest.mark.parametrize("model,p", [("lerf-g", "isc"), ("lerf-g", "osc"), ("lerf-l", "isc")])
+def test_whole_warp_worker_to_its_last_statement(torch, oracle, tmp_path, model, p, lazy_on):
+    """the warp worker to its END (resample/eval_lut_warp.py:70-302): torch.Tensor(img_out) -- the statement that raised on the
+    round-4 DeviceArray --, np.array(mask_output == 255), mPSNR on float32 tensors, the white fill by boolean arithmetic and the
+    PNGs.  mPSNR equals the reference's number (its float32 sum runs in the same memory order: lazy.download keeps numpy's layout)."""
+    import callsite_driver as cd
+    from lerf_pytorch_amd import lazy
+    ref = json.load(open(os.path.join(GOLDEN, "g5_set5.json")))["warp"]
+    linear = model == "lerf-l"
+    luts = cd.float_luts(oracle.load_luts(os.path.join(ASSETS, model), linear=linear))
+    interp, pads, warper, nn = cd.mirror_warp_api(linear=linear)
+    lazy.set_enabled(lazy_on)
+    try:
+        for n in ("baby", "woman"):
+            r = ref["%s/%s/%s" % (model, p, n)]
+            lr = np.array(Image.open(os.path.join(DATA, p, n + ".png"))).astype(np.float32)
+            gt = np.array(Image.open(os.path.join(DATA, "HR", n + ".png")))
+            keep = {}
+            out8, mask = cd.worker_warp(interp, pads, warper, nn, luts, lr, np.array(r["matrix"]), gt.shape[:2],
+                                        out_c=1 if linear else 3, linear=linear, keep=keep)
+            assert isinstance(out8, lazy.DeviceArray) == lazy_on and isinstance(keep["mask_output"], lazy.DeviceArray) == lazy_on
+            (mp,) = cd.tail_warp(out8, keep["mask_output"], keep["feat_chw"], gt, str(tmp_path), n)
+            assert float(mp) == pytest.approx(r["mpsnr"], abs=2e-5)
+            mk = np.array(Image.open(os.path.join(str(tmp_path), n + "_mask.png")))
+            assert _md5((mk == 255).astype(np.uint8)) == r["md5_mask"] and int((mk == 255).sum()) == r["mask_sum"]
+            saved = np.array(Image.open(os.path.join(str(tmp_path), n + "_LUTft.png")))
+            assert _md5(saved * (mk == 255)) == r["md5_out_masked"] and bool((saved[mk != 255] == 255).all())
+    finally:
+        lazy.set_enabled(True)
+
+
+def test_device_results_take_everything_the_callers_do(torch):
+    """the conversions and writes of tests/test_lazy_cpu.py on real device tensors"""
+    from lerf_pytorch_amd import lazy
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)
+    A = lazy.asdevice(a)
+    assert A.t.is_cuda
+    x = torch.Tensor(A)
+    assert x.device.type == "cpu" and x.dtype == torch.float32 and torch.equal(x, torch.Tensor(a))
+    assert torch.equal(torch.tensor(A), torch.tensor(a)) and torch.equal(torch.as_tensor(A), torch.as_tensor(a))
+    f = rng.standard_normal((9, 270, 480))
+    F = lazy.asdevice(f)
+    f = f.copy()
+    F[f > 1.0] = 0.0
+    f[f > 1.0] = 0.0
+    F[:, 5:9, ::2] = 3.0
+    f[:, 5:9, ::2] = 3.0
+    v, vn = F.transpose((1, 2, 0)), f.transpose((1, 2, 0))
+    v[:, 0] += 16.0
+    vn[:, 0] += 16.0
+    F *= 0.5
+    f *= 0.5
+    assert np.array_equal(np.asarray(F), f) and np.array_equal(np.asarray(v), vn)
+    O = lazy.asdevice(np.zeros_like(f))
+    np.clip(F, -1, 1, out=O)
+    assert np.array_equal(O.t.cpu().numpy(), np.clip(f, -1, 1))
+    i = lazy.asdevice(np.arange(12, dtype=np.int32).reshape(3, 4))
+    assert (i * 0.5).dtype == np.float64 and np.array_equal(np.asarray(i * 0.5), np.arange(12).reshape(3, 4) * 0.5)
+    m = np.asarray(v == 3.0)
+    assert m.strides == (vn == 3.0).strides                 # numpy's memory layout for results of transposed views
+
+
 def test_device_array_answers_like_numpy(torch):
     """every operation the call sites apply between the library calls, DeviceArray against the same numpy expression"""
     from lerf_pytorch_amd import lazy
@@ -140,6 +237,14 @@ def test_interp_accepts_device_arrays_and_caches_luts(torch, oracle):
     changed = FourSimplexInterpFaster(w, img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
     fresh = FourSimplexInterpFaster(w.copy(), img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)     # another buffer: no cache hit possible
     assert np.array_equal(np.asarray(changed), np.asarray(fresh)) and not np.array_equal(np.asarray(changed), want)
+    w[1000:1100] = 7.0                                    # a SPARSE change between the points any sample grid would look at
+    changed = FourSimplexInterpFaster(w, img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
+    fresh = FourSimplexInterpFaster(w.copy(), img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
+    assert np.array_equal(np.asarray(changed), np.asarray(fresh))
+    w[40000, 1] = -9.0                                    # one element
+    changed = FourSimplexInterpFaster(w, img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
+    fresh = FourSimplexInterpFaster(w.copy(), img, 30, 44, 4, 1, upscale=1, mode="c", oC=3)
+    assert np.array_equal(np.asarray(changed), np.asarray(fresh))
 
 
 def test_upload_ring_reuses_its_pinned_slots_safely(torch):
