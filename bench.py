@@ -249,6 +249,108 @@ def end_to_end_legs(torch, L, eng, frame_u8, scale, B):
     return out
 
 
+def recorded_traffic(cfg, S, Cn, scale, frames, input_kind, sha):
+    """(bytes per launch, where from) of profiles/hbm_traffic.json for a workload, only when it was measured on exactly these
+    kernel sources; (None, why not) otherwise"""
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    key = traffic_key(cfg, S, Cn, scale, frames, input_kind)
+    try:
+        tj = json.load(open(tfile)).get("entries", {}).get(key)
+    except Exception as e:
+        return None, "none: %s" % e, None
+    if tj is None:
+        return None, "none: profiles/hbm_traffic.json has no entry for this workload (%s)" % key, None
+    if tj.get("frames") == frames and tj.get("input") == input_kind and tj.get("kernel_src_sha16") == sha:
+        return tj.get("bytes_per_launch"), "recorded, not measured in this run: %s (rocprofv3 --pmc passes of this workload on kernel sources sha %s)" % (
+            tj.get("source"), sha), tj
+    return None, "none: profiles/hbm_traffic.json was recorded for other kernel sources / workload (file sha %s, sources %s)" % (
+        tj.get("kernel_src_sha16"), sha), None
+
+
+def other_config_legs(torch, L, ops, steps=5, warmup=2):
+    """every BASELINE configuration on the driver's record.  Short legs beside the headline (never `value`): config 3
+    (LeRF-L x1.5/x2.0), config 4 (LeRF-G warp, isc matrix), config 5 (4K -> 8K, 4 frames on one GPU) and config 2 at S = 4 --
+    `warmup` + `steps` steps each, HIP events around every step, the product output of the last step compared with the C port of
+    the oracle on one frame (bytes), and the workload's own recorded HBM traffic.  A failing leg reports its error and nothing else."""
+    global C
+    C = 3
+    sha = kernel_source_sha()
+    from oracle import c_oracle
+    c_oracle.set_threads(host_cpu_budget()[0])
+    legs = {}
+    specs = [("config3_lerf_l_x1.5x2.0", 3, "lerf-l", 2, (1080, 1920), (1.5, 2.0), 8, "noise"),
+             ("config4_warp_isc", 4, "lerf-g", 2, (1080, 1920), (2.0, 2.0), 8, "natural"),
+             ("config5_4k_to_8k_one_gpu", 5, "lerf-g", 2, (2160, 3840), (2.0, 2.0), 4, "noise"),
+             ("config2_support4", 2, "lerf-g", 4, (1080, 1920), (2.0, 2.0), 8, "noise")]
+    for name, cfg, model, S, (H, W), scale, B, input_kind in specs:
+        t_leg = time.perf_counter()
+        try:
+            eng = L.LerfEngine.shipped(model, support=S, max_sigma=10.0)
+            kind = "linear" if model == "lerf-l" else "gauss"
+            if input_kind == "natural":
+                two = synth_frames("natural", 2, 1000, H, W)
+                host = np.ascontiguousarray(np.tile(two, (B // 2 + 1, 1, 1, 1))[:B])
+            else:
+                host = synth_frames("noise", B, 1000, H, W)
+            frames = torch.from_numpy(host).cuda()
+            ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, 3, B)), dtype=torch.uint8, device="cuda")
+            if cfg == 4:
+                oH, oW = 2 * H, 2 * W
+                geo = ops.WarpGeometry((H, W), np.array(M_ISC), (oH, oW), eng.support)
+                out = torch.empty((B, oH, oW, 3), dtype=torch.uint8, device="cuda")
+
+                def step():
+                    ops.warp_packed(ops.stages_packed(frames, eng.luts, workspace=ws), geo, kind, eng.max_sigma, out=out)
+            else:
+                geo = eng.sr_geometry((H, W), list(scale))
+                oH, oW = geo.out_hw
+                out = torch.empty((B, oH, oW, 3), dtype=torch.uint8, device="cuda")
+
+                def step():
+                    ops.sr_fused_u8(frames, eng.luts, geo, kind, eng.max_sigma, out=out, workspace=ws)
+            for _ in range(warmup):
+                step()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for a, b in ev:
+                a.record()
+                step()
+                b.record()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            alg = B * (H * W * 3 + oH * oW * 3) + LUT_BYTES[model]
+            traffic, tsrc, _ = recorded_traffic(cfg, S, 3, scale, B, input_kind, sha)
+            leg = {"mpix_s": round(steps * B * oH * oW / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+                   "frames_per_step": B, "input": input_kind, "workload": "%s %dx%d -> %dx%d, S=%d%s" % (
+                       model, W, H, oW, oH, S, ", homography M_ISC + validity mask" if cfg == 4 else ", scale %gx%g" % scale),
+                   "roofline": {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+                                "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": alg}}
+            # parity of the timed product output against the checker (one frame; the C port is test infrastructure)
+            k = B - 1
+            luts = _oracle_luts(model)
+            if cfg == 4:
+                cpu_out, cpu_mask = c_oracle.warp_u8(host[k], luts, np.array(M_ISC), (oH, oW))
+                white = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+                white[4:H - 4, 4:W - 4] = 255
+                mk = (ops.warp_hwc_u8(white, None, ops.WarpGeometry((H, W), np.array(M_ISC), (oH, oW), 1), "nearest", 1.0, out="f32") == 255).cpu().numpy()
+                diff = out[k].cpu().numpy() != cpu_out
+                leg["parity_vs_cpu_port"] = {"mismatches": int(diff.sum()), "mask_mismatches": int((mk != cpu_mask).sum()), "bytes": int(diff.size)}
+            else:
+                cpu_out = c_oracle.sr_u8(host[k], luts, scale[0], scale[1], S=S, linear=model == "lerf-l")
+                diff = out[k].cpu().numpy() != cpu_out
+                leg["parity_vs_cpu_port"] = {"mismatches": int(diff.sum()), "bytes": int(diff.size)}
+            leg["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+            legs[name] = leg
+            del frames, out, ws, eng
+        except Exception as e:                                  # a secondary leg must never cost the headline line
+            legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return legs
+
+
 # --------------------------------------------------------------------------------------------- rank launcher
 def _free_port():
     s = socket.socket()
@@ -319,6 +421,8 @@ def parse():
     ap.add_argument("--channels", type=int, choices=[1, 3, 4], default=3, help="config 2: channels per pixel (1 / 4: general kernels)")
     ap.add_argument("--sustained", type=float, default=5.0,
                     help="seconds of back-to-back steps for the `sustained` leg (0 = skip; reported beside `value`, never replacing it)")
+    ap.add_argument("--lib", default=None, help="diagnostic: load this build of liblerf_hip.so (A/B variants, tools/ab.sh); reported in the line")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (default run only)")
     ap.add_argument("--mode", choices=["frames", "strips", "blocks"], default=None,
                     help="frames: independent frames per GPU (default; config 5: the batch is divided over the GPUs); "
                          "strips: every frame is split into LR strips over the GPUs with an RCCL halo exchange "
@@ -341,6 +445,8 @@ def main():
     import torch.distributed as dist
     import lerf_pytorch_amd as L
     from lerf_pytorch_amd import ops
+    if args.lib:
+        L._lib.use_library(args.lib)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -575,25 +681,12 @@ def main():
 
     # recorded (not in-run) PMC numbers: only when they were measured on exactly these kernels and this workload
     traffic, tsrc, binding = None, None, None
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     sha = kernel_source_sha()
-    tkey = traffic_key(cfg, S, C, scale, B_local, input_kind)
-    if os.path.exists(tfile) and not args.unfused and world == 1:
-        try:
-            tj = json.load(open(tfile)).get("entries", {}).get(tkey)
-            if tj is None:
-                tsrc = "none: profiles/hbm_traffic.json has no entry for this workload (%s)" % tkey
-            elif tj.get("frames") == B_local and tj.get("input") == input_kind and tj.get("kernel_src_sha16") == sha:
-                traffic = tj.get("bytes_per_launch")
-                tsrc = "recorded, not measured in this run: %s (rocprofv3 --pmc passes of this command on kernel sources sha %s)" % (
-                    tj.get("source"), sha)
-                binding = {k: tj[k] for k in ("valu_instr_per_cu_cycle", "valu_busy", "lds_array_busy", "lds_bank_conflict_share",
-                                              "l2_hit_rate", "kernel_trace_avg_us") if k in tj}
-            else:
-                tsrc = "none: profiles/hbm_traffic.json was recorded for other kernel sources / workload (file sha %s, sources %s)" % (
-                    tj.get("kernel_src_sha16"), sha)
-        except Exception:
-            traffic, tsrc, binding = None, None, None
+    if not args.unfused and world == 1:
+        traffic, tsrc, tj = recorded_traffic(cfg, S, C, scale, B_local, input_kind, sha)
+        if tj is not None:
+            binding = {k: tj[k] for k in ("valu_instr_per_cu_cycle", "valu_busy", "lds_array_busy", "lds_bank_conflict_share",
+                                          "l2_hit_rate", "kernel_trace_avg_us") if k in tj}
 
     chn = {1: "grey", 3: "RGB", 4: "RGBA"}[C]
     names = {2: ("Mpix/s LeRF-G x%g SR (2K->%s)" % (scale[0], "4K" if scale[0] == 2.0 else "%dx%d" % (oW, oH)),
@@ -621,7 +714,8 @@ def main():
                    "path": "unfused-3-launch" if args.unfused else ("stages_packed + warp_packed" if cfg == 4 else "sr_fused_u8"),
                    "mode": mode if strips else "frames", "parallelism": par, "ranks_reported_by_rccl": rccl_ranks,
                    "backend": ("gloo (ranks share one GPU: test hook, not a measurement)" if share_gpu else ("nccl" if world > 1 else None)),
-                   "channels": C, "scale": list(scale)},
+                   "channels": C, "scale": list(scale),
+                   "library": os.path.relpath(L._lib.LIB_PATH, ROOT)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                      "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
@@ -708,6 +802,11 @@ def main():
             torch.cuda.synchronize()
             diff = np.abs(out[ref_idx].cpu().numpy().astype(int) - cpu_out.astype(int))
             res["parity_vs_cpu_port"] = {"max_abs_diff_u8": int(diff.max()), "mismatches": int((diff != 0).sum())}
+    default_run = cfg == 2 and S == 2 and C == 3 and scale == (2.0, 2.0) and not args.unfused and input_kind == "noise"
+    if rank == 0 and world == 1 and default_run and not args.no_other_configs and not args.no_other_input:
+        del out, frames
+        torch.cuda.empty_cache()
+        res["other_configs"] = other_config_legs(torch, L, ops)
     if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
@@ -730,7 +829,8 @@ def run_callsite(args):
     H, W = 1080, 1920
     frame = synth_frames(args.input or "noise", 1, 1000, H, W)[0]
     img = frame.astype(np.float32)
-    luts = cd.float_luts(_oracle_luts("lerf-g"))
+    from lerf_pytorch_amd import luts as lutmod
+    luts = cd.float_luts(lutmod.load_lut_arrays(os.path.join(lutmod.ASSET_DIR, "lerf-g")))
     interp, pads, resizer = cd.mirror_api(linear=False, support=2, max_sigma=10)
     eng = L.LerfEngine.shipped("lerf-g", support=2, max_sigma=10.0)
     want = eng.sr(frame, 2)

@@ -2,7 +2,7 @@
 """stamped sr_fused_kernel totals per tile column / row for one rank's block (region of interest, two launches)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ.setdefault("LERF_HIP_LIB", os.path.join(ROOT, "lerf-pytorch_amd", "liblerf_hip_stamps.so"))
+# (round 4: selected the stamped build through LERF_HIP_LIB; today: lerf_pytorch_amd._lib.use_library(path))
 import numpy as np, torch
 import lerf_pytorch_amd as L
 from lerf_pytorch_amd import ops, dist as ldist

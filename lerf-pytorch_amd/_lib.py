@@ -11,8 +11,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LERF_HIP_LIB selects a diagnostic build (tools/stamps.py); the default is the in-tree product library
-LIB_PATH = os.environ.get("LERF_HIP_LIB") or os.path.join(_HERE, "liblerf_hip.so")
+# The in-tree product library.  The package reads NO environment variable for this: diagnostic builds (cycle stamps, A/B
+# variants under csrc/build_*/) are selected explicitly by the tools that own them, through use_library() before the first
+# call (tools/stamps.py, `bench.py --lib`, which prints the path in its JSON line).
+LIB_PATH = os.path.join(_HERE, "liblerf_hip.so")
 
 LERF_MAX_MODES = 5
 LERF_LUT_ENTRIES = 83521
@@ -110,6 +112,15 @@ class WarpGeo(C.Structure):
 
 
 _lib = None
+
+
+def use_library(path):
+    """tools only: load another build of liblerf_hip.so (same ABI) instead of the product library.  Must come before the first
+    library call of the process; the choice is visible as `_lib.LIB_PATH`."""
+    global LIB_PATH
+    if _lib is not None:
+        raise LerfError("use_library(%s): liblerf_hip.so is already loaded from %s" % (path, LIB_PATH))
+    LIB_PATH = os.path.abspath(path)
 
 
 def lib():

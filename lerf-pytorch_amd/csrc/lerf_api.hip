@@ -374,10 +374,7 @@ size_t lerf_sr_fused_workspace_bytes(int H, int W, int C, int n) {
     // fallback keeps feat + up to 3 hyper planes per frame.
     if (H < 1 || W < 1 || C < 1 || n < 1) return 0;
     const size_t hwc = (size_t)H * W * C;
-    // (a) + one 52-KB scratch per workgroup of the persistent kernel (lerf_fused_persist.h; at most one workgroup per tile and
-    // per compute unit -- 512 covers every gfx9 part) + alignment slack
-    const size_t tiles = (size_t)n * ((H + 63) / 64) * ((W + 63) / 64);
-    const size_t a = (size_t)n * ((hwc + 15) / 16 * 16) + (tiles < 512 ? tiles : 512) * 53248 + 512;
+    const size_t a = (size_t)n * ((hwc + 15) / 16 * 16) + 512;                     // (a) + alignment slack
     const size_t b = general_workspace_bytes(H, W, C, n);
     return a > b ? a : b;
 }

@@ -45,6 +45,15 @@ __host__ __device__ inline bool mode_offsets(char mode, int rot, int8_t dy[4], i
     return true;
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8; an affinity, not a guarantee -- nothing
+// depends on it but speed).  xcd_contiguous() hands every XCD a CONTIGUOUS eighth of a launch's block sequence instead of
+// every eighth block, so that the blocks running side by side on one XCD are neighbours in the frame and what they read
+// together meets in that XCD's own 4-MiB L2.  A bijection of [0, total) for any total.
+__device__ __forceinline__ int xcd_contiguous(int b, int total) {
+    const int x = b & 7, j = b >> 3, q = total >> 3, r = total & 7;
+    return x * q + (x < r ? x : r) + j;
+}
+
 // round-half-to-even of n/d for n >= 0 (np.round), clipped to [0,255].
 __host__ __device__ inline int rne_div_clip255(int n, int d) {
     if (n <= 0) return 0;

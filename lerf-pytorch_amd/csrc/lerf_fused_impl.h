@@ -54,7 +54,7 @@ namespace lerf {
 namespace LERF_FUSED_NS {
 
 #ifndef LERF_FUSED_NT
-#define LERF_FUSED_NT 1024         // threads per workgroup (a 512-thread instance of the persistent experiment was tried: profiles/r04_experiments.txt)
+#define LERF_FUSED_NT 1024         // threads per workgroup
 #endif
 constexpr int NT = LERF_FUSED_NT;  // threads per workgroup
 constexpr int NW = NT / 64;        // waves
@@ -1425,28 +1425,6 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 #undef LERF_SLAB_OK
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
-#ifdef LERF_DBG_OVERLAP
-        // timing experiment only (wrong results): the VALU work of a tile's stage 3 (4 block tasks x 392 instructions per thread,
-        // an eighth of them v_exp_f32) dealt out over the tile's 18 phases -- how much of it hides (a) under the LDS-bound lookups
-        // of the other waves (behind a wave's own slot rounds, in front of the phase barrier), (b) under the LDS-WRITE-bound piece
-        // copies (-DLERF_DBG_OVERLAP_AT_COPY: behind the wave's own stores)?  Built with -DLERF_DBG_NOS3 (stage 3 itself skipped):
-        // tools/build_variant.sh ovl "-DLERF_DBG_NOS3 -DLERF_DBG_OVERLAP=87"
-#define LERF_DBG_CHUNK()                                                                                              \
-        do {                                                                                                          \
-            float x0 = __uint_as_float(slot2[0]), x1 = __uint_as_float(accA[0] | 0x3f000000u), x2 = 1.0f;             \
-            _Pragma("unroll") for (int i_ = 0; i_ < LERF_DBG_OVERLAP / 8; ++i_) {                                     \
-                x0 = __builtin_fmaf(x0, x1, x2);                                                                      \
-                x2 = __builtin_fmaf(x2, x0, x1);                                                                      \
-                x1 = x1 * x2;                                                                                         \
-                x0 = __builtin_amdgcn_exp2f(-x0);                                                                     \
-                x2 = __builtin_fmaf(x2, x1, x0);                                                                      \
-                x1 = __builtin_fmaf(x1, x2, x0);                                                                      \
-                x0 = x0 + x1;                                                                                         \
-                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));                                                      \
-            }                                                                                                         \
-            if (x0 + x1 + x2 == 12345.678f) accB[0] ^= 1u;                                                            \
-        } while (0)
-#endif
         // phases = (non-empty bin) x (6 LUTs).  The next piece is fetched into registers while the current one is being
         // used, so the L2 latency of the piece copies hides behind the lookups.
         const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -1471,9 +1449,6 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             const unsigned long long t_copy = LERF_NOW();
             (void)t_copy;
             pre_store();
-#if defined(LERF_DBG_OVERLAP) && defined(LERF_DBG_OVERLAP_AT_COPY)
-            LERF_DBG_CHUNK();                      // behind the wave's own piece stores, in front of the barrier: the other waves' stores keep the LDS busy
-#endif
             Off3 o0, o1;                                     // LUT l = mode (l>>1), rotation parity (l&1)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -1507,22 +1482,10 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                     const Walk<4> W1 = simplex_walk<4>(ka, basea, rb1, rc1, rd1, st_b, st_c, st_d);
                     // stage C: ten dword gathers in flight together
                     uint32_t d0[5], d1[5];
-#if defined(LERF_DBG_GATHER) && LERF_DBG_GATHER == 1      // timing experiment only: conflict-free gathers (wrong results)
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) d0[n] = lds_ld32(qbase + (uint32_t)lane * 4u + (uint32_t)n * 256u + ((uint32_t)W0.a(n) >> 30));
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) d1[n] = lds_ld32(qbase + (uint32_t)lane * 4u + (uint32_t)n * 256u + 2048u + ((uint32_t)W1.a(n) >> 30));
-#elif defined(LERF_DBG_GATHER) && LERF_DBG_GATHER == 2    // timing experiment only: no gathers at all
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) d0[n] = W0.a(n);
-#pragma unroll
-                    for (int n = 0; n < 5; ++n) d1[n] = W1.a(n);
-#else
 #pragma unroll
                     for (int n = 0; n < 5; ++n) d0[n] = W0.ld32(n);
 #pragma unroll
                     for (int n = 0; n < 5; ++n) d1[n] = W1.ld32(n);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                     // stage D: two multiply-adds per corner.  The entry is e0 | 0 << 8 | e2 << 16 | e1 << 24: a 24-bit multiply reads
                     // bits 0..23 only, so the (e0, e2) pair needs no mask; the second one multiplies the entry's HIGH HALF
@@ -1546,9 +1509,6 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                     accB[k] = bb;
                 }
             }
-#if defined(LERF_DBG_OVERLAP) && !defined(LERF_DBG_OVERLAP_AT_COPY)
-            LERF_DBG_CHUNK();
-#endif
             __syncthreads();
             LERF_STAMP_ADD(9, t_look);
             if (++l == NL2) { l = 0; ++bi; }
@@ -1589,9 +1549,6 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 
     if (EMIT) {
         __syncthreads();
-#ifdef LERF_DBG_NOEMIT
-        if (P.pad_mode != 77) return;          // timing experiment only: the stages kernel without its packed-map stores
-#endif
         uint32_t* eo = F.emit;
         const int rows = min(TH, H - ty0), cols3 = min(TW, W - tx0) * CH;
         for (int il = wave; il < rows; il += NW) {
@@ -1602,9 +1559,6 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         return;
     }
 
-#ifdef LERF_DBG_NOS3
-    if (P.pad_mode != 77) return;              // timing experiment only: the tile without its stage 3
-#endif
     // ---- stage 3 geometry of the owned output block (staged here for S = 4; S = 2 did it at kernel start)
     if (!D::GEO_EARLY) {
         geo_search();
@@ -2398,12 +2352,6 @@ s1_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 #endif
 }
 
-// round-4 experiment, NOT in the product build (make EXTRA=-DLERF_PERSIST_EXPERIMENT): a persistent stages-2+3 kernel that
-// defers stage 3 into the next tile's piece copies -- byte-exact, measured slower (register wall; profiles/r04_experiments.txt)
-#if LERF_FUSED_CH == 3 && defined(LERF_PERSIST_EXPERIMENT)
-#include "lerf_fused_persist.h"
-#endif
-
 #undef LERF_S1_LOAD
 #undef LERF_S1_STORE
 #undef LERF_ADDTID
@@ -2429,18 +2377,6 @@ static int ensure_lds(int bytes) {
 }
 
 inline size_t feat_slice_bytes(int H, int W) { return ((size_t)H * W * CH + 15) / 16 * 16; }
-
-// compute units of the current device (the grid of the persistent kernel), asked once per device
-static int cu_count() {
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    int v = cached[dev & 63].load(std::memory_order_relaxed);
-    if (v > 0) return v;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return 0;
-    cached[dev & 63].store(v, std::memory_order_relaxed);
-    return v;
-}
 
 template <int S, int KIND, bool EMIT, bool GEN>
 static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
@@ -2581,24 +2517,6 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
             if (blocks1 > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
         }
         hipLaunchKernelGGL(ka, dim3((unsigned)blocks1), dim3(NT), DimsA::LDS_BYTES, st, Pa, T);
-#if LERF_FUSED_CH == 3 && defined(LERF_PERSIST_EXPERIMENT)
-        if constexpr (S == 2 && KIND == LERF_KIND_GAUSS && !EMIT && !GEN) {
-            // the persistent kernel with stage 3 deferred into the next tile's piece copies (lerf_fused_persist.h): exact x2 tables
-            // (the caller vouches: LERF_GEO_X2_TABLES), constant padding, room for one 52-KB scratch per workgroup behind the
-            // stage-1 output; at least two tiles per workgroup, or there is nothing to hide anything under
-            int G = cu_count();
-            G = G >= 8 ? (G & ~7) : G;
-            const size_t feat_end = (size_t)(P.feat - (uint8_t*)a.workspace) + (size_t)a.n * feat_slice_bytes(a.H, a.W);
-            const size_t scr_off = (feat_end + 255) & ~(size_t)255;
-            if ((a.flags & LERF_GEO_X2_TABLES) && !(a.flags & LERF_GEO_NO_PERSIST) && a.pad_mode == LERF_PAD_CONSTANT && G > 0 &&
-                blocks >= 2 * (int64_t)G && a.workspace_bytes >= scr_off + (size_t)G * PersistDims::SCR_DWORDS * 4) {
-                if ((rc = ensure_lds<sr_persist_kernel>(PersistDims::LDS_BYTES)) != LERF_OK) return rc;
-                hipLaunchKernelGGL(sr_persist_kernel, dim3((unsigned)G), dim3(NT), PersistDims::LDS_BYTES, st, P,
-                                   (uint32_t*)((uint8_t*)a.workspace + scr_off), (int)blocks);
-                return LERF_OK;
-            }
-        }
-#endif
         hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(NT), D::LDS_BYTES, st, P, T);
         return LERF_OK;
     }

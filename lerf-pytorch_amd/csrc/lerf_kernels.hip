@@ -779,8 +779,13 @@ __global__ void __launch_bounds__(256)
 warp_packed_px_kernel(const uint32_t* __restrict__ packed0, int64_t packed_sn, int n_frames, int H, int W, WarpGeo g, float max_sigma,
                       TO* __restrict__ out0, int64_t oy, int64_t ox, int64_t oc, int64_t out_sn) {
     constexpr int S = 2, C = 3;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
+    // 1-D grid of (output row, 256-pixel segment) blocks in row-major order, each XCD on a contiguous eighth of it = a band of
+    // output rows: the packed-map rows two neighbouring output rows share are then fetched into ONE L2 (round 4, linear
+    // order: every map byte came from HBM 2.5 times, L2 hit 0.62 -- neighbouring rows sat on different XCDs)
+    const int gx = (g.oW + 255) >> 8;
+    const int b = (int)gridDim.x >= 1024 ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int i = b / gx;
+    const int j = (b - i * gx) * 256 + (int)threadIdx.x;
     if (j >= g.oW) return;
     double gr, gc;
     project_point(g.minv, i, j, H, W, &gr, &gc);
@@ -833,10 +838,6 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed0, int64_t packed_sn, i
         uint32_t d[S * S];
 #pragma unroll
         for (int t = 0; t < S * S; ++t) d[t] = packed[pos[t] + c];
-#ifdef LERF_DBG_WARP_NOLOAD          // timing experiment only (wrong results): the kernel without its tap loads = what a tile-fused warp could save at most
-#pragma unroll
-        for (int t = 0; t < S * S; ++t) d[t] = (uint32_t)(pos[t] + c) * 2654435761u + (uint32_t)fr;
-#endif
         if constexpr (PROD) {
             float e[S * S], v[S * S];
 #pragma unroll
@@ -909,7 +910,7 @@ int launch_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, 
     if (n < 1 || n > 65535 || geo.oH > 65535) return LERF_EUNSUPPORTED;
     if (C == 3 && geo.S == 2 && (kind == LERF_KIND_GAUSS || kind == LERF_KIND_LINEAR) &&
         (out_dtype == LERF_U8 || out_dtype == LERF_F32)) {
-        dim3 blockp(256), gridp((geo.oW + 255) / 256, geo.oH, 1);
+        dim3 blockp(256), gridp((unsigned)(((geo.oW + 255) / 256) * geo.oH), 1, 1);
 #define LERF_WPX(TO, KIND, PROD)                                                                                      \
     hipLaunchKernelGGL((warp_packed_px_kernel<TO, KIND, PROD>), gridp, blockp, 0, st, packed, packed_sn, n, H, W, geo, max_sigma, (TO*)out, \
                        oy, ox, oc, out_sn)

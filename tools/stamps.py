@@ -13,11 +13,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("LERF_HIP_LIB", os.path.join(ROOT, "lerf-pytorch_amd", "liblerf_hip_stamps.so"))
 
 import numpy as np
 import torch
 import lerf_pytorch_amd as L
+L._lib.use_library(os.environ.get("LERF_STAMPS_LIB") or os.path.join(ROOT, "lerf-pytorch_amd", "csrc", "build_stamps", "liblerf_hip_stamps.so"))
 from lerf_pytorch_amd import ops
 import bench
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM-side traffic of the headline bench only (two rocprofv3 --pmc passes): tools/traffic.sh <tag> ; LERF_HIP_LIB selects the build
+# HBM-side traffic of the headline bench only (two rocprofv3 --pmc passes): tools/traffic.sh <tag> ; pass `--lib PATH` among the bench arguments to profile another build
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/traffic_$tag
@@ -14,7 +14,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+"/p*/**/*counter_collection.csv", recursive=True):
     rows=collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        k="s1" if "s1_kernel" in r["Kernel_Name"] else ("s23" if "sr_fused_kernel" in r["Kernel_Name"] else None)
+        k="s1" if "s1_kernel" in r["Kernel_Name"] else ("s23" if "sr_fused_kernel" in r["Kernel_Name"] else ("warp" if "warp_packed" in r["Kernel_Name"] else None))
         if k: rows[(k,r["Dispatch_Id"])][r["Counter_Name"]]+=float(r["Counter_Value"])
     for (k,_),cs in rows.items():
         for c,v in cs.items(): acc[k][c].append(v)
