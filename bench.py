@@ -472,7 +472,13 @@ def main():
             rccl_ranks = 0
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            rccl_ranks = dist.get_world_size()
+            # the ranks RCCL itself reaches: an all-reduce of ones over xGMI, not the launcher's WORLD_SIZE.  A line whose
+            # `ranks_reported_by_rccl` differs from --gpus is never printed: the run fails here instead.
+            one = torch.ones(1, dtype=torch.int32, device="cuda")
+            dist.all_reduce(one)
+            rccl_ranks = int(one.item())
+            if rccl_ranks != args.gpus:
+                raise SystemExit("bench.py: --gpus %d but the RCCL all-reduce counted %d ranks" % (args.gpus, rccl_ranks))
     n_gpus = world
     if args.gpus != n_gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -808,6 +814,8 @@ def main():
         torch.cuda.empty_cache()
         res["other_configs"] = other_config_legs(torch, L, ops)
     if rank == 0:
+        # every mode, every N: the printed line's rank count is the launch's (share_gpu, the gloo test hook, reports 0 RCCL ranks)
+        assert res["n_gpus"] == args.gpus and res["config"]["ranks_reported_by_rccl"] == (0 if share_gpu else args.gpus), res["config"]
         print(json.dumps(res))
         sys.stdout.flush()
     if world > 1:

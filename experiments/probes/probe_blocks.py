@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One rank's batched block launch pair (config 5, 2 x 4 grid), for rocprofv3 --kernel-trace: tools/probe_blocks.py <rank>"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 from lerf_pytorch_amd import ops, dist as ldist

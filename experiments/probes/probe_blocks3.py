@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """stamped sr_fused_kernel totals per tile column / row for one rank's block (region of interest, two launches)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 # (round 4: selected the stamped build through LERF_HIP_LIB; today: lerf_pytorch_amd._lib.use_library(path))
 import numpy as np, torch
 import lerf_pytorch_amd as L

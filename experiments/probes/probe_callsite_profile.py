@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """cProfile of the lazy leg of the unchanged call sites (host image in), sorted by own time; plus a device-side kernel time sum."""
 import os, sys, time, cProfile, pstats
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, torch
 import callsite_driver as cd
 from oracle import lerf_oracle as O

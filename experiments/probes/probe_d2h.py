@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """D2H / H2D copy rates to pinned memory, alone and beside a running SR launch (can a copy-engine pipeline beat the zero-copy kernel?)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 eng = L.LerfEngine.shipped("lerf-g")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the fused path capturable in a HIP graph (torch.cuda.CUDAGraph), and what does replay save on launch-bound sizes?"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 rng = np.random.default_rng(0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does one LUT fine-tuning iteration (tools/bench_lutft.py) spend its time: device kernels against host launches."""
 import os, sys, time, types
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from lerf_pytorch_amd.resample.model import SWF2LUT, lutft_step
 from lerf_pytorch_amd.resize_right.resize_right2d_torch import SteeringGaussianResize2dTorch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """timing only: headline step (8 x 1080p, noise) through whatever kernel the library build takes"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 from lerf_pytorch_amd import ops, _lib

@@ -2,7 +2,7 @@
 """Input dependence of the headline step (8 x 1080p -> 4K, LeRF-G): how much of it is LDS bank conflicts?  A constant frame turns every
 LUT gather into a broadcast (all lanes of a wave read one address): what is left is VALU issue, the piece copies and stage 3."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 import bench

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """StreamingSR transports: per-batch completion times of a 12-batch run (is the three-stream pipeline overlapping?)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 from lerf_pytorch_amd.stream import StreamingSR

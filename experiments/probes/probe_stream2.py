@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Hybrid host-to-host pipeline: the kernel reads the pinned input itself, writes device memory; a copy engine takes the result down."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 from lerf_pytorch_amd import ops, _lib

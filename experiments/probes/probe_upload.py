@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does a stage-1 call of the unchanged call sites spend its time? (host numpy, host -> pinned, H2D, device ops)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from lerf_pytorch_amd import lazy, ops, _lib

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """config 4 step (8 x 1080p -> 4K, isc matrix) kernel by kernel: events around the stages launch pair and the warp launch"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lerf_pytorch_amd as L
 from lerf_pytorch_amd import ops

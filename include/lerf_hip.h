@@ -112,8 +112,14 @@ typedef struct {
     int roi_y, roi_x;        /* LR region the tiles of lerf_sr_fused_u8 are laid over (origin and extent in LR pixels); roi_h = 0 or */
     int roi_h, roi_w;        /* roi_w = 0: the whole frame.  A rank of a 2-D block partition passes its OWNED block here and the block
                               * plus halo as the frame: halo pixels then only ever serve as tile halos (255 instead of 288 tiles for a
-                              * 1080x960 block of a 2160x3840 frame).  The output tables must list only outputs whose support starts
-                              * inside the region (the caller's slicing rule; lerf-pytorch_amd/dist.py BlockPlan).  With a workspace
+                              * 1080x960 block of a 2160x3840 frame).  OWNERSHIP RULE (ABI 5, exact): the output tables must list
+                              * exactly the outputs whose support CENTRE lies in the region, left + S/2 in [roi_y, roi_y + roi_h)
+                              * for rows (columns alike) -- i.e. left in [roi_y - S/2, roi_y + roi_h - S/2); outputs beyond a TRUE
+                              * frame border (left + S/2 < 0 or >= H) belong to the region that touches that border.  This is the
+                              * slicing rule of lerf-pytorch_amd/dist.py (BlockPlan / StripPlan, `check_support`).  A tile looks the
+                              * hyper-parameters up on [tile - S/2, tile + T + S/2 - 1): an output whose support merely STARTS in
+                              * the last row / column of the region (left = roi_y + roi_h - 1; accepted by ABI 4's wording) reads a
+                              * position no tile of this launch fills.  The library cannot check device tables.  With a workspace
                               * the region takes the two-launch path too: stage 1 runs once per pixel over the region widened by
                               * 3 + S/2 pixels (ABI 5; ABI 4 recomputed stage 1 on every tile's halo for regions) */
     /* ---- ABI 5 (zero = the behaviour of ABI 4) */
@@ -125,10 +131,9 @@ typedef struct {
 #define LERF_GEO_FORCE_GENERAL 1   /* diagnostic: take the general tile-fused kernels where the specialised ones would serve (A/B runs) */
 #define LERF_GEO_SINGLE_LAUNCH 2   /* diagnostic: the single-launch kernel although a workspace is passed (the stamped build keeps its stamps there) */
 #define LERF_GEO_X2_TABLES 16      /* the caller vouches that the tables are lerf_sr_axis_tables(scale = 2) on both axes (or row / column slices of
-                                    * them): output rows and columns pair up on their taps, the distances have period 2.  Read only by the
-                                    * round-4 experiment build (-DLERF_PERSIST_EXPERIMENT: a persistent kernel that defers stage 3 into the next
-                                    * tile's LUT-piece copies; byte-exact, slower -- DESIGN.md); the product library ignores it */
-#define LERF_GEO_NO_PERSIST 32     /* experiment build only: never take that kernel (A/B runs) */
+                                    * them).  Reserved: read only by the round-4 persistent-kernel experiment (experiments/r04_persist,
+                                    * not in this library); ignored */
+#define LERF_GEO_NO_PERSIST 32     /* reserved (same experiment); ignored */
 #define LERF_GEO_TILE_ROWS_64 64    /* force the tile height of the RGB tile-fused kernels (default: 64 rows, 32 / 16 for launches too small to */
 #define LERF_GEO_TILE_ROWS_32 128   /* fill the chip with 64-row tiles -- a 256 x 256 frame runs as 64 tiles of 16 rows); tests and A/B runs */
 #define LERF_GEO_TILE_ROWS_16 256

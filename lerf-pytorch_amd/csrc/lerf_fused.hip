@@ -45,7 +45,9 @@ bool fused_supported(const FusedArgs& a) {
     if (a.kind == LERF_KIND_GAUSS && !(a.max_sigma <= s3::kNoShiftMaxSigma)) return false;   // float64 direct kernel (lerf_stage3.h)
     if (a.pad_mode < LERF_PAD_CONSTANT || a.pad_mode > LERF_PAD_WRAP) return false;
     const bool roi = a.roi_h > 0 && a.roi_w > 0;
-    if (a.pad_mode == LERF_PAD_WRAP && (a.workspace == nullptr || roi)) return false;      // far-side pixels come from the stage-1 output
+    // wrap padding: the far-side pixels come from the stage-1 output of the two-launch path -- no workspace, or a workspace the
+    // caller told the launch not to use (LERF_GEO_SINGLE_LAUNCH), means the direct kernels
+    if (a.pad_mode == LERF_PAD_WRAP && (a.workspace == nullptr || (a.flags & LERF_GEO_SINGLE_LAUNCH) || roi)) return false;
     if (a.items != nullptr) {
         if (a.n_items < 1 || roi) return false;
         for (int i = 0; i < a.n_items; ++i)

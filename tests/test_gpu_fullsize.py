@@ -339,6 +339,7 @@ def test_bench_two_ranks_on_one_shared_gpu(torch, launcher, extra):
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["config"]["backend"].startswith("gloo")
+    assert j["config"]["ranks_reported_by_rccl"] == 0          # the hook's label; a real N-GPU line carries N (bench.py asserts it)
     if not extra:
         assert j["scaling"] == "weak" and j["config"]["frames_per_step_per_gpu"] == 8
         # the aggregate counts both ranks' frames: 2 x 8 frames of 3840 x 2160 per step
@@ -347,3 +348,31 @@ def test_bench_two_ranks_on_one_shared_gpu(torch, launcher, extra):
         assert j["scaling"] == "strong" and j["config"]["mode"] == extra[3]
         # strong scaling: the batch of whole 8K frames once, whatever the number of ranks
         assert abs(j["value"] - 2 * 7680 * 4320 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * j["value"]
+
+
+def test_bench_default_line_carries_every_baseline_config(torch):
+    """the default `python bench.py` line (what the driver records) holds a leg for configs 3, 4, 5 (one GPU)
+    and S = 4, each with its own in-run byte parity against the C port and a roofline block; and `--config 5 --frames 4` (the
+    N = 1 point of the driver's scaling run in frames mode) agrees with the config-5 leg."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "LERF_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "10", "--warmup", "3", "--sustained", "0"]
+    r = subprocess.run(base + ["--no-end-to-end", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["config"]["ranks_reported_by_rccl"] == 1 and j["config"]["library"].endswith("liblerf_hip.so")
+    legs = j["other_configs"]
+    assert sorted(legs) == ["config2_support4", "config3_lerf_l_x1.5x2.0", "config4_warp_isc", "config5_4k_to_8k_one_gpu"]
+    for name, leg in legs.items():
+        assert "error" not in leg, (name, leg)
+        assert leg["mpix_s"] > 5000 and leg["parity_vs_cpu_port"]["mismatches"] == 0 and leg["parity_vs_cpu_port"].get("mask_mismatches", 0) == 0
+        assert leg["roofline"]["bound"] == "hbm" and leg["roofline"]["achieved"] > 0 and "traffic" in leg["roofline"]
+    assert sum(leg["leg_seconds"] for leg in legs.values()) < 30.0
+    r5 = subprocess.run(base + ["--config", "5", "--frames", "4", "--mode", "frames", "--no-cpu-baseline", "--no-other-input"], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r5.returncode == 0, r5.stderr.decode()[-3000:]
+    j5 = json.loads([l for l in r5.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert j5["config"]["ranks_reported_by_rccl"] == 1 and j5["config"]["frames_per_step_per_gpu"] == 4
+    assert abs(j5["value"] / legs["config5_4k_to_8k_one_gpu"]["mpix_s"] - 1.0) < 0.03, (j5["value"], legs["config5_4k_to_8k_one_gpu"]["mpix_s"])

@@ -137,6 +137,12 @@ def test_pad_modes_on_the_fused_uint8_path(torch, oracle, luts_g, luts_l, pad, m
     if pad != "wrap":                                         # single launch: every source pixel is inside the tile
         one = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma, workspace=False).cpu().numpy()
         assert np.array_equal(one, a)
+    else:
+        # a workspace the caller tells the launch not to use (LERF_GEO_SINGLE_LAUNCH) must not put wrap padding on
+        # the single-launch kernel (it cannot serve the far side of the frame): the call takes the direct kernels, same bytes
+        geo.struct.flags |= _lib.GEO_SINGLE_LAUNCH
+        forced = ops.sr_fused_u8(x, eng.luts, geo, eng.kind, eng.max_sigma).cpu().numpy()
+        assert np.array_equal(forced, a)
 
 
 @pytest.mark.parametrize("max_sigma", [13.0, 14.0, 20.0, 40.0])
