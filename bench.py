@@ -267,7 +267,7 @@ def recorded_traffic(cfg, S, Cn, scale, frames, input_kind, sha):
         tj.get("kernel_src_sha16"), sha), None
 
 
-def other_config_legs(torch, L, ops, steps=5, warmup=2):
+def other_config_legs(torch, L, ops, steps=20, warmup=5):
     """every BASELINE configuration on the driver's record.  Short legs beside the headline (never `value`): config 3
     (LeRF-L x1.5/x2.0), config 4 (LeRF-G warp, isc matrix), config 5 (4K -> 8K, 4 frames on one GPU) and config 2 at S = 4 --
     `warmup` + `steps` steps each, HIP events around every step, the product output of the last step compared with the C port of

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LERF_ABI_VERSION 5
+#define LERF_ABI_VERSION 6
 #define LERF_MAX_MODES 5          /* s, c, t, d, y  (resample/eval_lut_sr.py:12-18) */
 #define LERF_LUT_ENTRIES 83521    /* 17^4, interval = 4 (resample/eval_lut_sr.py:27-28) */
 #define LERF_MAX_SUPPORT 8
@@ -200,6 +200,14 @@ int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_
 int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C,
                         int h, int w, const int8_t dy[4], const int8_t dx[4],
                         const int8_t* lut, int oC, int interval, int16_t* out, void* stream);
+
+/* ABI 6.  The same pass with the reference's epilogue inside the store: the image may be LERF_U8 or LERF_F32 (float32 arrays of
+ * integer values are what the call sites hand over, resample/eval_lut_sr.py:549-553; other values are rounded half-to-even and
+ * clipped to 0..255), `out` is LERF_I16 (numerators, value * q), LERF_F32 or LERF_F64 (VALUES, numerator / q: :469) with SIGNED
+ * element strides sy / sx over the h x w positions and sc between the C * oC result planes -- a caller that points `ptr` at the
+ * right corner and hands in the strides of a rotated view gets np.rot90(result, rot, [1, 2]) (:464-468) written in place. */
+int lerf_lut_interp(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
+                    const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, void* stream);
 
 /* LUT pack for the tile-fused kernel (1..4 modes per stage, any of "sdyct"; oC = 1 or 3): the stage-1
  * LUTs padded to 16-byte multiples, and the stage-2 LUTs as one uint32 per

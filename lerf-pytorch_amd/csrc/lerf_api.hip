@@ -176,13 +176,22 @@ int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_
 
 int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4],
                         const int8_t dx[4], const int8_t* lut, int oC, int interval, int16_t* out, void* stream) {
-    if (!plane_ok(img) || img->dtype != LERF_U8 || !lut || !out || !dy || !dx) return LERF_EINVAL;
+    if (!out) return LERF_EINVAL;
+    lerf_mplane_t o;
+    o.ptr = out; o.dtype = LERF_I16; o.sy = w; o.sx = 1; o.sc = (int64_t)h * w;
+    return lerf_lut_interp(img, img_h, img_w, C, h, w, dy, dx, lut, oC, interval, &o, stream);
+}
+
+int lerf_lut_interp(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
+                    const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, void* stream) {
+    if (!plane_ok(img) || (img->dtype != LERF_U8 && img->dtype != LERF_F32) || !lut || !dy || !dx) return LERF_EINVAL;
+    if (!out || !out->ptr || (out->dtype != LERF_I16 && out->dtype != LERF_F32 && out->dtype != LERF_F64)) return LERF_EINVAL;
     if (img_h < 1 || img_w < 1 || C < 1 || h < 1 || w < 1) return LERF_EINVAL;
     Offsets4 off;
     memcpy(off.dy, dy, 4);
     memcpy(off.dx, dx, 4);
-    int rc = launch_lut_interp((const uint8_t*)img->ptr, img->sy, img->sx, img->sc, img_h, img_w, C, h, w, off, lut,
-                               oC, interval, out, as_stream(stream));
+    int rc = launch_lut_interp(img->ptr, img->dtype, img->sy, img->sx, img->sc, img_h, img_w, C, h, w, off, lut, oC, interval,
+                               out->ptr, out->dtype, out->sy, out->sx, out->sc, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
 

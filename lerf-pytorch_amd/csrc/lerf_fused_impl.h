@@ -302,6 +302,13 @@ __device__ __forceinline__ unsigned key_of(uint32_t r, unsigned stride) {
 }
 __device__ __forceinline__ unsigned msb_of(uint32_t r) { return r >> 20; }
 
+// acc + d.lo16 * key.hi16 (signed): one Abel term of a byte-LUT walk, the LSB taken from the sorted key's high half in place --
+// sub + mad per term instead of sub + multiply (SDWA) + half a three-input add (round 5: -2 of ~30 instructions per walk)
+__device__ __forceinline__ int mad_i16_keyhi(int d, unsigned key, int acc) {
+    asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[0,1,0,0]" : "+v"(acc) : "v"(d), "v"(key));
+    return acc;
+}
+
 // acc + w.lo16 * d.hi16: the upper half of a packed stage-2 entry multiplied in place (op_sel picks the high half of src1)
 __device__ __forceinline__ uint32_t mad_hi16(uint32_t w, uint32_t d, uint32_t acc) {
     asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[0,1,0,0]" : "+v"(acc) : "v"(w), "v"(d));
@@ -313,6 +320,7 @@ struct Walk {
     static constexpr int ALL = (kStrideA + kStrideB + kStrideC + kStrideD) * STRIDE_SCALE;   // vertex 4 - vertex 0
     int i0, i1, i2, i3m;        // byte offsets of vertices 0, 1, 2 and (vertex 3 - ALL); vertex 4 = i0 + ALL
     unsigned f0, f1, f2, f3;    // sorted LSBs
+    unsigned k0, k1, k2, k3;    // the sorted keys themselves (LSB in the high half: a v_mad_*_i16 reads it there with op_sel)
     // vertex n = address a(n) + constant c(n): the constant goes into the DS immediate offset
     __device__ __forceinline__ uint32_t a(int n) const { return (uint32_t)(n == 0 ? i0 : n == 1 ? i1 : n == 2 ? i2 : n == 3 ? i3m : i0); }
     static constexpr int c(int n) { return n >= 3 ? ALL : 0; }
@@ -339,6 +347,7 @@ __device__ __forceinline__ Walk<STRIDE_SCALE> simplex_walk(unsigned ka, int base
     W.i2 = W.i1 + (int)(s1 & 0xFFFFu);
     W.i3m = W.i0 - (int)(s3 & 0xFFFFu);
     W.f0 = s0 >> 16; W.f1 = s1 >> 16; W.f2 = s2 >> 16; W.f3 = s3 >> 16;
+    W.k0 = s0; W.k1 = s1; W.k2 = s2; W.k3 = s3;
     return W;
 }
 
@@ -451,10 +460,17 @@ __device__ __forceinline__ int byte_walks(uint32_t lut_a, uint32_t ra, const uin
 #pragma unroll
     for (int i = 0; i < NROT; ++i) {
         sum0 += e[i][0];
+#ifndef LERF_S1_MUL24
+        acc = mad_i16_keyhi(e[i][1] - e[i][0], W[i].k0, acc);
+        acc = mad_i16_keyhi(e[i][2] - e[i][1], W[i].k1, acc);
+        acc = mad_i16_keyhi(e[i][3] - e[i][2], W[i].k2, acc);
+        acc = mad_i16_keyhi(e[i][4] - e[i][3], W[i].k3, acc);
+#else
         acc += __mul24((int)W[i].f0, e[i][1] - e[i][0]);
         acc += __mul24((int)W[i].f1, e[i][2] - e[i][1]);
         acc += __mul24((int)W[i].f2, e[i][3] - e[i][2]);
         acc += __mul24((int)W[i].f3, e[i][4] - e[i][3]);
+#endif
     }
     return acc + kQ * sum0;
 }

@@ -202,6 +202,38 @@ def lut_interp_i16(img_u8_chw, h, w, dy, dx, lut_i8, interval=4):
     return out
 
 
+def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None):
+    """One LUT pass with the reference's epilogue in the store (lerf_lut_interp, ABI 6): img uint8 or float32 [C,Hp,Wp] (any
+    strides) -> [C*oC, h', w'] = np.rot90(values, rot, [1, 2]) as float64 (default) / float32 VALUES (numerator / 2^interval),
+    or the int16 numerators.  The rotation costs nothing: the kernel stores through the strides of the rotated view."""
+    torch = _torch()
+    if img_chw.dtype not in (torch.uint8, torch.float32) or img_chw.dim() != 3:
+        raise ValueError("img must be uint8 or float32 [C,H,W]")
+    if not 1 <= int(interval) <= 7:
+        raise ValueError("interval must be 1..7")
+    if lut_i8.dtype != torch.int8 or lut_i8.dim() != 2 or lut_i8.shape[0] != (2 ** (8 - int(interval)) + 1) ** 4:
+        raise ValueError("lut must be int8 [L^4,oC] with L = 2^(8-interval) + 1")
+    out_dtype = out_dtype or torch.float64
+    if out_dtype not in (torch.float64, torch.float32, torch.int16):
+        raise ValueError("out_dtype must be float64, float32 or int16")
+    lut = lut_i8.contiguous()
+    Cn, Hp, Wp = img_chw.shape
+    oC = lut.shape[1]
+    h, w, rot = int(h), int(w), int(rot) % 4
+    oh, ow = (h, w) if rot % 2 == 0 else (w, h)
+    out = torch.empty((Cn * oC, oh, ow), dtype=out_dtype, device=img_chw.device)
+    # element (y, x) of the un-rotated result lands at R = rot90(A, rot): rot 1: R[w-1-x, y]; 2: R[h-1-y, w-1-x]; 3: R[x, h-1-y]
+    sy, sx, off = {0: (ow, 1, 0), 1: (1, -ow, (w - 1) * ow), 2: (-ow, -1, h * w - 1), 3: (-1, ow, ow - 1)}[rot]
+    po = _lib.plane(out, sy, sx, oh * ow, offset=off)
+    dy = np.ascontiguousarray(dy, dtype=np.int8)
+    dx = np.ascontiguousarray(dx, dtype=np.int8)
+    p = _planes_chw(img_chw)
+    with _lib.on_device(out):
+        _lib.check(_lib.lib().lerf_lut_interp(C.byref(p), Hp, Wp, Cn, h, w, dy.ctypes.data, dx.ctypes.data, lut.data_ptr(), oC,
+                                              int(interval), C.byref(po), _lib.current_stream()), "lerf_lut_interp")
+    return out
+
+
 # --------------------------------------------------------------------------- A2/A3
 def lut_stages(img_u8_hwc, luts):
     """uint8 [H,W,C] -> (feat uint8 [H,W,C], hq uint8 [H,W,C,oC])."""

@@ -29,20 +29,16 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
     else:
         lazy_out = False
     as_numpy = not isinstance(img_in, torch.Tensor)
-    if as_numpy:
-        img = _upload_image(torch, np.asarray(img_in))
-        lut = _device_lut(torch, weight, oC, img.device)
-    else:
-        img = img_in
-        lut = _device_lut(torch, weight, oC, img.device)
-    img = img.round().clamp(0, 255).to(torch.uint8) if img.dtype != torch.uint8 else img
+    img = _upload_image(torch, np.asarray(img_in)) if as_numpy else img_in
+    lut = _device_lut(torch, weight, oC, img.device)
+    if img.dtype not in (torch.uint8, torch.float32):
+        img = img.to(torch.float32)                    # (float64 / integer images: exact for the 0..255 values of the contract)
     pad = mode_pad_dict[mode]
     if img.shape[1] < h + pad or img.shape[2] < w + pad:
         raise ValueError("img_in must be padded by {} pixels for mode {}".format(pad, mode))
-    num = ops.lut_interp_i16(img, h, w, dy, dx, lut, interval)    # [C, oC, h, w] int16, value * 2^interval
-    Cn = img.shape[0]
-    out = num.reshape(Cn * oC, h, w)
-    out = torch.rot90(out, int(rot), [1, 2]).to(torch.float64) / float(2 ** interval)
+    # one launch: float32 / uint8 pixels in, float64 values out, already rotated back by `rot` quarter turns and divided by
+    # q (:464-469) -- the kernel stores through the strides of the rotated view (lerf_lut_interp, ABI 6)
+    out = ops.lut_interp(img, h, w, dy, dx, lut, interval, rot=int(rot), out_dtype=torch.float64)
     if lazy_out or (as_numpy and lazy.enabled()):
         return lazy.DeviceArray(out)                   # numpy-shaped, device-backed: the caller's += / clip / round stay in HBM
     return out.cpu().numpy() if as_numpy else out
