@@ -1668,22 +1668,24 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         } else if (wave == 1) {
             // the columns (block tasks below): do they pair up as (2h, 2h + 1) -- code 1 -- or, behind a leading single (the
             // frame's left edge), as (2h - 1, 2h) -- code 2?  A trailing single is fine either way.
-            bool ok0 = true, ok1 = true;
+            bool ok0 = true, ok1 = true, step1 = true;
             for (int base = 0; base < ncol; base += 64) {
                 const int jl = base + lane;
                 if (jl + 1 < ncol && g_lc[jl + 1] != g_lc[jl]) { if (jl & 1) ok1 = false; else ok0 = false; }
+                if (!(jl & 1) && jl + 2 < ncol && g_lc[jl + 2] != g_lc[jl] + 1) step1 = false;
             }
-            const bool p0 = __ballot(!ok0) == 0ull, p1 = __ballot(!ok1) == 0ull;
-            if (lane == 0) ctl[24] = p0 ? 1 : (p1 ? 2 : 0);
+            const bool p0 = __ballot(!ok0) == 0ull, p1 = __ballot(!ok1) == 0ull, q1 = __ballot(!step1) == 0ull;
+            if (lane == 0) { ctl[24] = p0 ? 1 : (p1 ? 2 : 0); ctl[28] = q1 ? 1 : 0; }   // [28]: pair h + 1 starts one tap right of pair h (x2)
         } else if (wave == 2 && KIND == LERF_KIND_GAUSS) {
             // the rows, the same question on the rows' first taps
-            bool ok0 = true, ok1 = true;
+            bool ok0 = true, ok1 = true, step1 = true;
             for (int base = 0; base < nrow; base += 64) {
                 const int il = base + lane;
                 if (il + 1 < nrow && g_lr[il + 1] != g_lr[il]) { if (il & 1) ok1 = false; else ok0 = false; }
+                if (!(il & 1) && il + 2 < nrow && g_lr[il + 2] != g_lr[il] + 1) step1 = false;
             }
-            const bool p0 = __ballot(!ok0) == 0ull, p1 = __ballot(!ok1) == 0ull;
-            if (lane == 0) ctl[26] = p0 ? 1 : (p1 ? 2 : 0);
+            const bool p0 = __ballot(!ok0) == 0ull, p1 = __ballot(!ok1) == 0ull, q1 = __ballot(!step1) == 0ull;
+            if (lane == 0) { ctl[26] = p0 ? 1 : (p1 ? 2 : 0); ctl[29] = q1 ? 1 : 0; }
         }
         __syncthreads();
         const int ngrp = ctl[21];
@@ -2003,6 +2005,150 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             }
             }
         };
+        // ---- quad tasks (round 5): RP x CP neighbouring blocks of an INTERIOR x2 tile in one task.  Pair h + 1 starts exactly one
+        //      tap right of / below pair h (ctl[28], ctl[29]), so the (S + RP - 1) x (S + CP - 1) taps of the task serve up to
+        //      RP x CP blocks each: a tap's load and u8 -> f32 conversions once per task instead of once per block (S = 4,
+        //      2 x 2 blocks: 25 instead of 64), its column-only terms once per column pair (40 instead of 64), its row
+        //      products once per row pair.  Every output still sums ITS S x S taps in the order (a outer, b inner) with the
+        //      operations of run_blocks: identical bytes.  One task per thread on a 64 x 64 tile with 2 x 2 blocks.
+        //      Measured (A/B on one box, profiles/r05_experiments.txt): S = 4: 2 x 2 blocks +1.7 % (23.58 -> 23.99 Gpix/s; 2 x 1: +1.6 %,
+        //      1 x 2: +1.2 %) -- the four v_exp_f32 per (tap, block) and their packed consumers are not shared, they are 3/4 of a
+        //      tap's issue time; S = 2: 2 x 2 blocks -1.4 % (one 48-output task per thread hides less latency than four of 12), 2 x 1
+        //      and 1 x 2 +-0: the 2 x 2 support keeps its single blocks.
+#ifdef LERF_QUAD_RP
+        constexpr int QRP = LERF_QUAD_RP, QCP = LERF_QUAD_CP;          // (A/B builds)
+#else
+        constexpr int QRP = S == 4 ? 2 : 1, QCP = S == 4 ? 2 : 1;
+#endif
+        const bool quad = BLK && QRP * QCP > 1 && blk_uni && __builtin_amdgcn_readfirstlane(ctl[28]) != 0 &&
+                          __builtin_amdgcn_readfirstlane(ctl[29]) != 0 && ((nrow >> 1) % QRP) == 0 && ((ncol >> 1) % QCP) == 0;
+        auto run_quads = [&]() {
+            if constexpr (BLK && QRP * QCP > 1) {
+            constexpr int RP = QRP, CP = QCP, TR = S + RP - 1, TC = S + CP - 1, SS2 = S * S;
+            const int ncq = (ncol >> 1) / CP;
+            const int ntq = ((nrow >> 1) / RP) * ncq;
+            const unsigned magicq = (unsigned)((0x100000000ull + (unsigned)ncq - 1) / (unsigned)(ncq > 0 ? ncq : 1));
+            for (int t = tid; t < ntq; t += NT) {
+                const int g = ncq == 1 ? t : (int)__umulhi((unsigned)t, magicq);
+                const int h = t - g * ncq;
+                const int il0 = 2 * RP * g, jl0 = 2 * CP * h;
+                const int lr = g_lr[il0], lc = g_lc[jl0];
+                s3::f2 DX[RP][S], DY[CP][S];               // [pair][tap]: lanes = the two rows / the two columns of the pair
+#pragma unroll
+                for (int rp = 0; rp < RP; ++rp)
+#pragma unroll
+                    for (int b = 0; b < S; ++b) { DX[rp][b].x = g_dr[(il0 + 2 * rp) * S + b]; DX[rp][b].y = g_dr[(il0 + 2 * rp + 1) * S + b]; }
+#pragma unroll
+                for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                    for (int a = 0; a < S; ++a) { DY[cp][a].x = g_dc[(jl0 + 2 * cp) * S + a]; DY[cp][a].y = g_dc[(jl0 + 2 * cp + 1) * S + a]; }
+                const uint32_t* dp = Dt + lr * D::HP + lc * CH;
+                uint8_t* ob = outt + il0 * D::OUT_PITCH + ophase + jl0 * CH;
+#pragma unroll 1
+                for (int c = 0; c < CH; ++c) {
+                    s3::f2 NUM[RP][CP][2], DEN[RP][CP][2];   // [row pair][column pair][row of the pair], lanes = columns of the pair
+#pragma unroll
+                    for (int A = 0; A < TC; ++A) {
+#pragma unroll
+                        for (int B = 0; B < TR; ++B) {
+                            const uint32_t d = dp[B * D::HP + A * CH + c];
+                            s3::f2 V, K1, K2, M2;
+                            V.x = V.y = (float)(d >> 24);
+                            K1.x = (float)((d >> 8) & 0xFFu);
+                            M2.x = s3::gauss_m2rho_u8((float)(d & 0xFFu));
+                            K2.x = (float)((d >> 16) & 0xFFu);
+                            s3::f2 P0[CP], TY2[CP], TX[RP];
+#pragma unroll
+                            for (int cp = 0; cp < CP; ++cp) {
+                                const int a = A - cp;
+                                if (a >= 0 && a < S) {
+                                    const s3::f2 TYV = s3::pk_mul_blo(DY[cp][a < 0 ? 0 : (a >= S ? 0 : a)], K2);
+                                    P0[cp] = s3::pk_mul_blo(TYV, M2);
+                                    TY2[cp] = s3::pk_mul(TYV, TYV);
+                                }
+                            }
+#pragma unroll
+                            for (int rp = 0; rp < RP; ++rp) {
+                                const int b = B - rp;
+                                if (b >= 0 && b < S) TX[rp] = s3::pk_mul_blo(DX[rp][b < 0 ? 0 : (b >= S ? 0 : b)], K1);
+                            }
+#pragma unroll
+                            for (int cp = 0; cp < CP; ++cp) {
+                                const int a = A - cp;
+                                if (a < 0 || a >= S) continue;
+#pragma unroll
+                                for (int rp = 0; rp < RP; ++rp) {
+                                    const int b = B - rp;
+                                    if (b < 0 || b >= S) continue;
+                                    const s3::f2 E0 = s3::pk_fma_ab<false>(TX[rp], P0[cp], s3::pk_fma_aa<false>(TX[rp], TY2[cp]));
+                                    const s3::f2 E1 = s3::pk_fma_ab<true>(TX[rp], P0[cp], s3::pk_fma_aa<true>(TX[rp], TY2[cp]));
+                                    s3::f2 W0, W1;
+                                    W0.x = __builtin_amdgcn_exp2f(-E0.x); W0.y = __builtin_amdgcn_exp2f(-E0.y);
+                                    W1.x = __builtin_amdgcn_exp2f(-E1.x); W1.y = __builtin_amdgcn_exp2f(-E1.y);
+                                    // (compiler-generated consumers of the v_exp results: see run_blocks)
+                                    if (a == 0 && b == 0) {
+                                        DEN[rp][cp][0] = W0; DEN[rp][cp][1] = W1;
+                                        NUM[rp][cp][0] = W0 * V; NUM[rp][cp][1] = W1 * V;
+                                    } else {
+                                        NUM[rp][cp][0] = __builtin_elementwise_fma(W0, V, NUM[rp][cp][0]);
+                                        NUM[rp][cp][1] = __builtin_elementwise_fma(W1, V, NUM[rp][cp][1]);
+                                        DEN[rp][cp][0] = DEN[rp][cp][0] + W0; DEN[rp][cp][1] = DEN[rp][cp][1] + W1;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    float dist[RP * CP * 4];
+                    float dmax = 0.0f;
+#pragma unroll
+                    for (int rp = 0; rp < RP; ++rp)
+#pragma unroll
+                        for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                                for (int q = 0; q < 2; ++q) {
+                                    const float den = q ? DEN[rp][cp][r].y : DEN[rp][cp][r].x, num = q ? NUM[rp][cp][r].y : NUM[rp][cp][r].x;
+                                    const float xf = s3::finish_div(num, den);
+                                    const float rr = __builtin_rintf(xf);
+                                    const float ds = xf - rr;
+                                    dist[((rp * CP + cp) * 2 + r) * 2 + q] = ds;
+                                    dmax = __builtin_fmaxf(dmax, __builtin_fabsf(ds));
+                                    ob[(2 * rp + r) * D::OUT_PITCH + (2 * cp + q) * CH + c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(rr, 0u, 0u);
+                                }
+                    if (dmax > 0.5f - s3::kTieEps && F.dis_r64 != nullptr) {
+#pragma unroll 1
+                        for (int k = 0; k < RP * CP * 4; ++k) {
+                            float dk = 0.0f;
+#pragma unroll
+                            for (int u = 0; u < RP * CP * 4; ++u) dk = (u == k) ? dist[u] : dk;       // (a register array: no dynamic index)
+                            if (!(__builtin_fabsf(dk) > 0.5f - s3::kTieEps)) continue;
+                            const int blkq = k >> 2, r = (k >> 1) & 1, q = k & 1;
+                            const int rp = blkq / CP, cp = blkq - rp * CP;
+                            const int il = il0 + 2 * rp + r, jl = jl0 + 2 * cp + q, xc = jl * CH + c;
+                            const int slot = atomicAdd(tq_count, 1);
+                            if (slot < P.tq_cap) {
+                                tq[slot] = ((uint32_t)il << 16) | (uint32_t)xc;
+                                continue;
+                            }
+                            // queue full: evaluated on the spot (float64, the reference's own dtype chain), patched behind the store above
+                            uint32_t dd[SS2];
+                            double dx64[S], dy64[S];
+#pragma unroll
+                            for (int b = 0; b < S; ++b) dx64[b] = F.dis_r64[(int64_t)(i0 + il) * S + b];
+#pragma unroll
+                            for (int a = 0; a < S; ++a) dy64[a] = F.dis_c64[(int64_t)(j0 + jl) * S + a];
+#pragma unroll
+                            for (int a = 0; a < S; ++a)
+#pragma unroll
+                                for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + rp + b) * D::HP + (lc + cp + a) * CH + c];
+                            outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<true, S>(dd, dx64, dy64, P.max_sigma));
+                        }
+                    }
+                }
+            }
+            }
+        };
         // ---- LeRF-L block tasks (amplified-linear weights, 2 x 2 support): row groups and column groups of ONE or two
         //      members (x1.5 gives groups of 1, 2, 1, 2 ..., x2 pairs; the frame edges singles), one task = the up to 2 x 2
         //      outputs of a (row group, column group), all channels.  The dword-column tasks ran the general five-row form
@@ -2166,7 +2312,8 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         // the group size per task
         constexpr bool WIDE = KIND == LERF_KIND_GAUSS && S == 2;      // x3 / x4 variants where the registers allow
         // (max_sigma <= s3::kNoShiftMaxSigma here: the host sends larger values to the float64 direct kernel, lerf_fused.hip)
-        if (blk_uni) run_blocks(std::true_type{});
+        if (quad) run_quads();
+        else if (blk_uni) run_blocks(std::true_type{});
         else if (blk) run_blocks(std::false_type{});
         else if (blkl) run_blocks_lin();
         else if (gsame == 2) run_tasks(std::integral_constant<int, 2>{});

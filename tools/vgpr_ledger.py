@@ -75,9 +75,14 @@ def main():
         for r in rows:
             if r[4] or r[5]:
                 print("    +%-6d %5d instr  %3d VGPRs referenced  max index v%-3d  exp %3d  v_pk %3d  ds_b32 %3d" % r[:7])
-        peak = max(r[3] for r in rows)
-        print("  -> stage 3 peaks at v%d: %d registers are free below the 128 of a 1024-thread workgroup\n" % (peak, 127 - peak))
-
+        blk = [r for r in rows if r[5] >= 40]                      # windows of the packed-f32 block tasks
+        oth = [r for r in rows if r[4] and r[5] < 40]
+        print("  -> block tasks (windows with >= 40 packed operations): at most %d VGPRs referenced, highest index v%d;" % (
+            max(r[2] for r in blk), max(r[3] for r in blk)))
+        print("     other task shapes: at most %d referenced, highest index v%d.  The allocation (%s) is stage 2's: prefetch 36 + sums up to 2 x 14 + slot"
+              % (max(r[2] for r in oth), max(r[3] for r in oth), total.group(1) if total else "?"))
+        print("     temporaries; stage 3 runs after it with those registers dead -- a larger task shape has %d registers to grow into.\n"
+              % (128 - max(r[2] for r in blk) - 12))
 
 if __name__ == "__main__":
     main()
