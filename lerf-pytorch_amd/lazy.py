@@ -611,103 +611,38 @@ def _size_class(n):
 
 
 def upload(a):
-    """contiguous numpy array -> CUDA tensor.  Arrays of 1 MB and more go through a ring of two (pinned host, device staging)
-    buffer pairs per size class: the host copies into the pinned buffer (`_host_copy`), a dedicated UPLOAD STREAM moves it to the
-    staging buffer, and the caller's stream picks it up with a device-to-device copy behind an event -- so the host neither waits
-    for the device work queued before, nor depends on the runtime's pageable path (0.55 ms per 25 MB on one host, 2.4 ms on the
-    next: profiles/r04_experiments.txt), and the transfer runs beside the kernels already queued instead of behind them (round
-    5: the twelve 25-MB stage-1 images of the unchanged call sites).  Smaller arrays take the plain pageable copy.  (torch's
-    `pinned.copy_(pageable)` is not used: it runs on the CPU thread pool, slow and erratic in a container with fewer CPUs than the
-    machine shows.)  Rings are kept up to 256 MB of pinned memory in all; beyond that the least recently used ring goes."""
+    """contiguous numpy array -> CUDA tensor.  Arrays of 1 MB and more go through a ring of two pinned buffers per size class: a
+    single-threaded `np.copyto` (0.9 ms per 25 MB) and an asynchronous copy, so the host neither waits for the device work queued
+    before nor depends on the runtime's pageable path, which takes 0.55 ms per 25 MB on one host and 2.4 ms on the next
+    (profiles/r04_experiments.txt); smaller ones take the plain pageable copy.  (torch's `pinned.copy_(pageable)` is not used: it
+    runs on the CPU thread pool, slow and erratic in a container with fewer CPUs than the machine shows.)  Rings are kept up to
+    256 MB of pinned memory in all; beyond that the least recently used ring goes."""
     torch = _torch()
     a = np.ascontiguousarray(a)
     if a.nbytes < _STAGE_MIN or a.dtype.hasobject:
         return torch.from_numpy(a).cuda()
     tdt = _torch_dtype(torch, a.dtype)                 # raises for dtypes torch does not have, before anything is staged
     cls = _size_class(a.nbytes)
-    n = a.nbytes
-    dev = torch.device("cuda", torch.cuda.current_device())
     with _STAGE_LOCK:
-        ring = _STAGE.pop((cls, dev.index), None)
+        ring = _STAGE.pop(cls, None)
         if ring is None:
-            while _STAGE and 2 * (sum(k[0] for k in _STAGE) + cls) > _STAGE_MAX_BYTES:
+            while _STAGE and 2 * (sum(_STAGE) + cls) > _STAGE_MAX_BYTES:
                 _STAGE.pop(next(iter(_STAGE)))         # least recently used first (dicts keep insertion order)
             ring = [[], 0]
             for _ in range(2):
                 t = torch.empty(cls, dtype=torch.uint8).pin_memory()
-                ring[0].append({"pin": t, "np": t.numpy(), "dev": torch.empty(cls, dtype=torch.uint8, device=dev), "dma": None, "free": None})
-        _STAGE[(cls, dev.index)] = ring                # (re-)inserted last = most recently used
+                ring[0].append([t, t.numpy(), None])
+        _STAGE[cls] = ring                             # (re-)inserted last = most recently used
         slot = ring[0][ring[1] & 1]
         ring[1] += 1
-        if slot["dma"] is not None:
-            slot["dma"].synchronize()                  # the pinned buffer is rewritten only after its last transfer has left it
-        _host_copy(slot["np"], a.reshape(-1).view(np.uint8), n)
-        up = _upload_stream(torch, dev)
-        cur = torch.cuda.current_stream(dev)
-        with torch.cuda.stream(up):
-            if slot["free"] is not None:
-                up.wait_event(slot["free"])            # the staging buffer is free once the last pick-up out of it has run
-            slot["dev"][:n].copy_(slot["pin"][:n], non_blocking=True)
-            slot["dma"] = torch.cuda.Event()
-            slot["dma"].record(up)
-        cur.wait_event(slot["dma"])
-        d = torch.empty(n, dtype=torch.uint8, device=dev)
-        d.copy_(slot["dev"][:n])
-        slot["free"] = torch.cuda.Event()
-        slot["free"].record(cur)
-    return d.view(tdt).reshape(a.shape)
-
-
-_UPLOAD_STREAMS = {}
-
-
-def _upload_stream(torch, dev):
-    s = _UPLOAD_STREAMS.get(dev.index)
-    if s is None:
-        s = _UPLOAD_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-    return s
-
-
-# host-side copy into the pinned buffer: one memmove, or -- where the host gains from it -- four threads on quarters of the
-# buffer (ctypes calls release the GIL).  Decided once per process on the first large copy, by timing both on the caller's own
-# data: the boxes of the pool copy 25 MB in 0.9 ms on one thread; containers with a CPU quota below their visible cores lose.
-_COPY_MODE = [None, None]            # [threads (1 or 4), executor]
-
-
-def _memmove_chunks(dst, src, n, k):
-    import ctypes
-    step = ((n + k - 1) // k + 4095) // 4096 * 4096
-    return [(dst + o, src + o, min(step, n - o)) for o in range(0, n, step)], ctypes.memmove
-
-
-def _host_copy(dst_u8, src_u8, n):
-    import time
-    dp, sp = dst_u8.ctypes.data, src_u8.ctypes.data
-    if _COPY_MODE[0] is None and n >= (8 << 20):
-        from concurrent.futures import ThreadPoolExecutor
-        ex = ThreadPoolExecutor(4, thread_name_prefix="lerf-upload")
-        chunks, mv = _memmove_chunks(dp, sp, n, 4)
-        t = []
-        for mode in (1, 4, 1, 4):
-            t0 = time.perf_counter()
-            if mode == 1:
-                mv(dp, sp, n)
-            else:
-                for f in [ex.submit(mv, *c) for c in chunks]:
-                    f.result()
-            t.append(time.perf_counter() - t0)
-        if min(t[1], t[3]) < 0.7 * min(t[0], t[2]):
-            _COPY_MODE[0], _COPY_MODE[1] = 4, ex
-        else:
-            _COPY_MODE[0] = 1
-            ex.shutdown(wait=False)
-        return                                          # (the timing copies were the copy)
-    if _COPY_MODE[0] == 4 and n >= (4 << 20):
-        chunks, mv = _memmove_chunks(dp, sp, n, 4)
-        for f in [_COPY_MODE[1].submit(mv, *c) for c in chunks]:
-            f.result()
-    else:
-        np.copyto(dst_u8[:n], src_u8)
+        if slot[2] is not None:
+            slot[2].synchronize()
+        np.copyto(slot[1][:a.nbytes], a.reshape(-1).view(np.uint8))
+        d = slot[0][:a.nbytes].cuda(non_blocking=True).view(tdt).reshape(a.shape)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[2] = ev
+    return d
 
 
 def _torch_dtype(torch, dt):
