@@ -786,3 +786,39 @@ def test_four_simplex_interp_modes_d_y(torch, golden, oracle, luts_g, mode):
     of, oh = oracle.lut_stages(x, arrays, 3, modes, modes)
     assert np.array_equal(feat, of) and np.array_equal(hq, oh)
     assert np.array_equal(eng.sr(x, 2), oracle.sr_pipeline(x, arrays, 2, 2, modes=modes, modes2=modes))
+
+
+@pytest.mark.parametrize("oC,interval", [(1, 4), (3, 4), (3, 3)])
+def test_lut_interp_abi6_forms_agree(torch, oracle, luts_g, oC, interval):
+    """lerf_lut_interp (ABI 6): uint8 and float32 images, int16 numerators and float32 / float64 values, the four rotations
+    written through the strides of the rotated view -- all equal to the int16 entry point of ABI 5 followed by np.rot90 and /q
+    (resample/eval_lut_sr.py:464-469), which the golden passes above pin to the reference."""
+    from lerf_pytorch_amd import _lib, ops
+    rng = np.random.default_rng(oC * 10 + interval)
+    L = 2 ** (8 - interval) + 1
+    lut = torch.from_numpy(rng.integers(-128, 128, (L ** 4, oC), dtype=np.int8)).cuda() if interval != 4 else \
+        torch.from_numpy(np.ascontiguousarray(luts_g["s2_cr1" if oC == 3 else "s1_tr0"].reshape(-1, oC))).cuda()
+    h, w = 37, 53
+    img8 = rng.integers(0, 256, (3, h + 3, w + 3), dtype=np.uint8)
+    x8 = torch.from_numpy(img8).cuda()
+    xf = x8.to(torch.float32)
+    xv = torch.from_numpy(np.ascontiguousarray(img8.transpose(1, 2, 0))).cuda().to(torch.float32).permute(2, 0, 1)     # an HWC buffer viewed as CHW
+    for mode in ("s", "c", "t"):
+        dy, dx = _lib.mode_offsets(mode, 0)
+        want = ops.lut_interp_i16(x8, h, w, dy, dx, lut, interval).reshape(3 * oC, h, w).cpu().numpy()
+        for rot in (0, 1, 2, 3, 4, -1):
+            ref = np.rot90(want, rot, [1, 2])
+            for x in (x8, xf, xv):
+                got = ops.lut_interp(x, h, w, dy, dx, lut, interval, rot=rot, out_dtype=torch.float64).cpu().numpy()
+                assert got.dtype == np.float64 and got.shape == ref.shape and np.array_equal(got, ref / float(2 ** interval))
+            n16 = ops.lut_interp(x8, h, w, dy, dx, lut, interval, rot=rot, out_dtype=torch.int16).cpu().numpy()
+            f32 = ops.lut_interp(xf, h, w, dy, dx, lut, interval, rot=rot, out_dtype=torch.float32).cpu().numpy()
+            assert np.array_equal(n16, ref) and f32.dtype == np.float32 and np.array_equal(f32, (ref / float(2 ** interval)).astype(np.float32))
+    # non-integer / out-of-range float pixels: rounded half-to-even and clipped, as `.round().clamp(0, 255)` did for the uint8 kernels
+    odd = torch.tensor([[[-3.0, 0.5, 1.5, 2.5, 254.5, 255.5, 300.0, 7.49]]], device="cuda").expand(1, 4, 8).contiguous()
+    dy, dx = _lib.mode_offsets("s", 0)
+    a = ops.lut_interp(odd, 3, 7, dy, dx, lut, interval, out_dtype=torch.int16)
+    b = ops.lut_interp(odd.round().clamp(0, 255).to(torch.uint8), 3, 7, dy, dx, lut, interval, out_dtype=torch.int16)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        ops.lut_interp(x8.to(torch.float64), h, w, dy, dx, lut, interval)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # every measured artefact of a round in one gpurun call: tools/final_runs.sh <tag>  (outputs under gpurun_out/<tag>/ and gpurun_out/prof_*)
-tag=${1:-r04}
+tag=${1:-r05}
 mkdir -p gpurun_out/$tag
 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 {
@@ -14,7 +14,7 @@ python tools/bench_ragged.py > gpurun_out/$tag/ragged_set5.txt 2>&1
 python tools/stamps.py noise natural > gpurun_out/$tag/phase_breakdown.txt 2>&1
 python bench.py --path callsite > gpurun_out/$tag/callsite.json 2>/dev/null
 python bench.py --path classes-torch > gpurun_out/$tag/classes_torch.json 2>/dev/null
-python tools/probe_warp.py > gpurun_out/$tag/warp_split.txt 2>&1
+python experiments/probes/probe_warp.py > gpurun_out/$tag/warp_split.txt 2>&1
 python tools/eval_set5.py > gpurun_out/$tag/set5_table.txt 2>&1
 bash tools/prof_all.sh > gpurun_out/$tag/prof_all.log 2>&1
 ls gpurun_out/$tag
