@@ -348,6 +348,8 @@ class DeviceArray(object):
         if inplace:
             if rd != self.dtype:
                 return self._host_bin(other, ufunc, reflected, inplace)         # numpy's casting rule decides (usually an error)
+            if hasattr(o, "untyped_storage") and o.numel() > 1 and o.untyped_storage().data_ptr() == self.t.untyped_storage().data_ptr():
+                o = o.clone()                                                   # `a -= a[0]`: numpy reads an overlapping operand before it writes
             try:
                 op(self.t, o, out=self.t)
             except RuntimeError:                                                # the operand does not broadcast INTO self

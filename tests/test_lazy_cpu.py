@@ -144,6 +144,11 @@ def test_inplace_operators_mutate_like_numpy(pair):
     A /= 3
     a /= 3
     assert B is A and _eq(B, a) and b is a
+    A -= A[0]                                                 # an operand that overlaps the destination: read before written, like numpy
+    a -= a[0]
+    A *= A.transpose((0, 1, 2))[:, :1, :]
+    a *= a[:, :1, :]
+    assert _eq(A, a)
     i = lazy.DeviceArray(torch.arange(6, dtype=torch.int32))
     n = np.arange(6, dtype=np.int32)
     with pytest.raises(TypeError):
