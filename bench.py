@@ -268,7 +268,8 @@ def recorded_traffic(cfg, S, Cn, scale, frames, input_kind, sha):
 
 
 def other_config_legs(torch, L, ops, steps=20, warmup=5):
-    """every BASELINE configuration on the driver's record.  Short legs beside the headline (never `value`): config 3
+    """every BASELINE configuration on the driver's record.  Short legs beside the headline (never `value`): config 1
+    (the 256 x 256 CPU-plumbing tile, product path beside one core of the C port), config 3
     (LeRF-L x1.5/x2.0), config 4 (LeRF-G warp, isc matrix), config 5 (4K -> 8K, 4 frames on one GPU) and config 2 at S = 4 --
     `warmup` + `steps` steps each, HIP events around every step, the product output of the last step compared with the C port of
     the oracle on one frame (bytes), and the workload's own recorded HBM traffic.  A failing leg reports its error and nothing else."""
@@ -282,6 +283,38 @@ def other_config_legs(torch, L, ops, steps=20, warmup=5):
              ("config4_warp_isc", 4, "lerf-g", 2, (1080, 1920), (2.0, 2.0), 8, "natural"),
              ("config5_4k_to_8k_one_gpu", 5, "lerf-g", 2, (2160, 3840), (2.0, 2.0), 4, "noise"),
              ("config2_support4", 2, "lerf-g", 4, (1080, 1920), (2.0, 2.0), 8, "noise")]
+    # config 1 (BASELINE configs[0], the reference's own CPU-runnable case): one 256 x 256 RGB tile, x2 -- the C port on one core
+    # beside the product path on the same tile, bytes compared (`bench.py --config 1` is the full line)
+    t_leg = time.perf_counter()
+    try:
+        tile = np.random.default_rng(0).integers(0, 256, (256, 256, 3), dtype=np.uint8)
+        luts1 = _oracle_luts("lerf-g")
+        c_oracle.set_threads(1)
+        c_oracle.sr_u8(tile, luts1, 2.0, 2.0, S=2)
+        t0 = time.perf_counter()
+        ref1 = c_oracle.sr_u8(tile, luts1, 2.0, 2.0, S=2)
+        t_cpu = time.perf_counter() - t0
+        c_oracle.set_threads(host_cpu_budget()[0])
+        eng1 = L.LerfEngine.shipped("lerf-g", support=2, max_sigma=10.0)
+        x1 = torch.from_numpy(tile).cuda()
+        for _ in range(3):
+            o1 = eng1.sr(x1, 2)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a, b in ev:
+            a.record()
+            o1 = eng1.sr(x1, 2)
+            b.record()
+        torch.cuda.synchronize()
+        kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        d1 = o1.cpu().numpy() != ref1
+        legs["config1_256x256_tile"] = {"mpix_s": round(512 * 512 / (kms * 1e-3) / 1e6, 2), "ms_per_step": round(kms, 4), "steps": 20, "warmup": 3,
+                                        "frames_per_step": 1, "input": "noise", "workload": "lerf-g 256x256 -> 512x512, S=2, scale 2x2 (one launch pair, 16-row tiles)",
+                                        "cpu_port_one_thread_mpix_s": round(512 * 512 / t_cpu / 1e6, 3),
+                                        "parity_vs_cpu_port": {"mismatches": int(d1.sum()), "bytes": int(d1.size)},
+                                        "leg_seconds": round(time.perf_counter() - t_leg, 2)}
+        del eng1, x1, o1
+    except Exception as e:
+        legs["config1_256x256_tile"] = {"error": "%s: %s" % (type(e).__name__, e)}
     for name, cfg, model, S, (H, W), scale, B, input_kind in specs:
         t_leg = time.perf_counter()
         try:
