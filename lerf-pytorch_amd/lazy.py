@@ -275,7 +275,7 @@ class DeviceArray(object):
             return self.numpy()[_host(idx)]
         try:
             r = self.t[ti[0]]
-        except (TypeError, IndexError, RuntimeError):
+        except (TypeError, IndexError, RuntimeError, ValueError):
             return self.numpy()[_host(idx)]                                     # numpy's own error for a bad index
         if r.dim() == 0 and ti[1] and not _has_ellipsis_or_none(idx):
             return self.dtype.type(r.item())                                    # a[i, j, k] is a scalar in numpy
@@ -303,7 +303,7 @@ class DeviceArray(object):
                 self.t[ti[0]] = v
                 self._touch()
                 return
-            except (TypeError, IndexError, RuntimeError):
+            except (TypeError, IndexError, RuntimeError, ValueError):
                 pass
         h = self.numpy().copy()
         h[_host(idx)] = _host(value)                                            # numpy's own semantics and errors

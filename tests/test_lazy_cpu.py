@@ -241,3 +241,29 @@ def test_worker_tails_on_device_arrays_equal_the_tails_on_numpy(tmp_path, oracle
     assert names == sorted(os.listdir(d)) and len(names) == 8
     for n in names:
         assert open(os.path.join(d, n), "rb").read() == open(os.path.join(ref, n), "rb").read(), n
+
+
+def test_corner_cases_of_the_ndarray_surface():
+    """empty and 0-dim arrays, negative-step slices (torch refuses them: host copy), boolean / integer index arrays, iteration,
+    numpy functions that take sequences of arrays, deep copies"""
+    import copy
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    A = lazy.DeviceArray(torch.from_numpy(a.copy()))
+    E = lazy.DeviceArray(torch.empty((0, 3), dtype=torch.float64))
+    assert len(E) == 0 and np.asarray(E).shape == (0, 3) and (E + 1).shape == (0, 3) and torch.tensor(E).shape == (0, 3)
+    Z = lazy.DeviceArray(torch.tensor(2.5, dtype=torch.float64))
+    assert float(Z) == 2.5 and float(Z / 3) == 2.5 / 3 and bool(Z > 1) and np.asarray(Z * 2) == 5.0
+    assert np.array_equal(np.asarray(A[::-1]), a[::-1]) and np.array_equal(np.asarray(A[:, ::-2]), a[:, ::-2])
+    B, b = A.copy(), a.copy()
+    B[::-1, 0] = [3, 4]
+    b[::-1, 0] = [3, 4]
+    B[...] = B + 1
+    b[...] = b + 1
+    assert _eq(B, b)
+    assert _eq(A[[True, False]], a[[True, False]]) and _eq(A[np.array([1, 0]), 1:], a[np.array([1, 0]), 1:]) and _eq(A[A > 2], a[a > 2])
+    assert A[..., None].shape == (2, 3, 1) and A[None].shape == (1, 2, 3) and _eq(A[-1], a[-1]) and _eq(A.T, a.T)
+    assert [list(map(float, r)) for r in A] == a.tolist()
+    assert np.array_equal(np.stack([A, A]), np.stack([a, a])) and np.array_equal(np.where(A > 2, A, 0), np.where(a > 2, a, 0))
+    C = copy.deepcopy(A)
+    C += 1
+    assert _eq(A, a) and _eq(C, a + 1)
