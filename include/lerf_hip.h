@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LERF_ABI_VERSION 6
+#define LERF_ABI_VERSION 7
 #define LERF_MAX_MODES 5          /* s, c, t, d, y  (resample/eval_lut_sr.py:12-18) */
 #define LERF_LUT_ENTRIES 83521    /* 17^4, interval = 4 (resample/eval_lut_sr.py:27-28) */
 #define LERF_MAX_SUPPORT 8
@@ -208,6 +208,23 @@ int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C,
  * right corner and hands in the strides of a rotated view gets np.rot90(result, rot, [1, 2]) (:464-468) written in place. */
 int lerf_lut_interp(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
                     const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, void* stream);
+
+/* ABI 7.  lerf_lut_interp with per-call flags (0 = lerf_lut_interp).  For the shipped interval (4) the pass runs in persistent
+ * workgroups that keep one byte plane of the LUT in LDS (csrc/lerf_lut_interp.hip) when the launch is large enough to pay for it
+ * (>= 65 536 positions), the pattern reaches no further than 3 pixels and C <= 4; the direct kernel (LUT gathered from L1 / L2)
+ * serves everything else -- same values either way.
+ *   LERF_INTERP_ACCUMULATE  out += result instead of out = result: the call sites' `pred += FourSimplexInterpFaster(...)`
+ *                           (resample/eval_lut_sr.py:555, :564, :589, :601) without a second pass over the planes.  The planes
+ *                           must hold valid numbers (the first call of a sum runs without the flag).
+ *   LERF_INTERP_LDS / LERF_INTERP_DIRECT   tests and A/B runs: insist on one of the two kernels (LERF_EUNSUPPORTED when the LDS
+ *                           kernel does not cover the call). */
+#define LERF_INTERP_ACCUMULATE 1
+#define LERF_INTERP_LDS 2
+#define LERF_INTERP_DIRECT 4
+#define LERF_INTERP_TILE64 8       /* A/B runs: force the 64 x 64 / 64 x 32 tile of the LDS kernel (default: by the launch's tile count) */
+#define LERF_INTERP_TILE32 16
+int lerf_lut_interp_ex(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
+                       const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, int flags, void* stream);
 
 /* LUT pack for the tile-fused kernel (1..4 modes per stage, any of "sdyct"; oC = 1 or 3): the stage-1
  * LUTs padded to 16-byte multiples, and the stage-2 LUTs as one uint32 per

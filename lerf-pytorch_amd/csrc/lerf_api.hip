@@ -184,14 +184,21 @@ int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C, in
 
 int lerf_lut_interp(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
                     const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, void* stream) {
+    return lerf_lut_interp_ex(img, img_h, img_w, C, h, w, dy, dx, lut, oC, interval, out, 0, stream);
+}
+
+int lerf_lut_interp_ex(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
+                       const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, int flags, void* stream) {
     if (!plane_ok(img) || (img->dtype != LERF_U8 && img->dtype != LERF_F32) || !lut || !dy || !dx) return LERF_EINVAL;
     if (!out || !out->ptr || (out->dtype != LERF_I16 && out->dtype != LERF_F32 && out->dtype != LERF_F64)) return LERF_EINVAL;
     if (img_h < 1 || img_w < 1 || C < 1 || h < 1 || w < 1) return LERF_EINVAL;
+    if (flags & ~(LERF_INTERP_ACCUMULATE | LERF_INTERP_LDS | LERF_INTERP_DIRECT | LERF_INTERP_TILE64 | LERF_INTERP_TILE32)) return LERF_EINVAL;
+    if ((flags & LERF_INTERP_LDS) && (flags & LERF_INTERP_DIRECT)) return LERF_EINVAL;
     Offsets4 off;
     memcpy(off.dy, dy, 4);
     memcpy(off.dx, dx, 4);
     int rc = launch_lut_interp(img->ptr, img->dtype, img->sy, img->sx, img->sc, img_h, img_w, C, h, w, off, lut, oC, interval,
-                               out->ptr, out->dtype, out->sy, out->sx, out->sc, as_stream(stream));
+                               out->ptr, out->dtype, out->sy, out->sx, out->sc, flags, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();
 }
 

@@ -2,7 +2,7 @@
 // no CUDA compatibility paths.  The C ABI (include/lerf_hip.h) is implemented
 // at the bottom of lerf_api.hip; this file holds the general-purpose kernels:
 //
-//   lut_interp_kernel   one (LUT, pattern) simplex pass        A1  (eval_lut_sr.py:24-470)
+//   (A1, one (LUT, pattern) simplex pass: lerf_lut_interp.hip)
 //   lut_stage_kernel    rotation/mode ensemble + rounding      A2/A3 (eval_lut_sr.py:541-628)
 //   resize_kernel       separable-geometry stage 3 (SR)        A5/A6 (resize_right2d_numpy.py:142-282)
 //   warp_kernel         homography stage 3                     A7/A8 (resize_right2d_numpy.py:284-636)
@@ -15,140 +15,6 @@
 #include "lerf_stage3.h"
 
 namespace lerf {
-
-// ---------------------------------------------------------------------------
-// A1: single LUT pass
-// ---------------------------------------------------------------------------
-// The image operand is uint8 or float32 (the call sites hand over float32 arrays of integer values, resample/eval_lut_sr.py:
-// 549-553; anything else is rounded half-to-even and clipped to 0..255, what `.round().clamp(0, 255)` gave the uint8 kernels
-// before); the result goes out through a plane with SIGNED element strides -- int16 numerators, or float32 / float64 VALUES
-// (numerator / q, exact: q is a power of two) -- so the caller's np.rot90(out, rot, [1, 2]) (:464-468) and the division (:469)
-// are part of the store.  16 x 16 positions per workgroup: rows of 16 elements in either orientation of the result.
-template <typename TIN>
-__device__ __forceinline__ int pixel_value(const TIN* __restrict__ p);
-template <>
-__device__ __forceinline__ int pixel_value<uint8_t>(const uint8_t* __restrict__ p) { return (int)*p; }
-template <>
-__device__ __forceinline__ int pixel_value<float>(const float* __restrict__ p) {
-    return (int)__builtin_rintf(fminf(fmaxf(*p, 0.0f), 255.0f));
-}
-template <typename TOUT>
-__device__ __forceinline__ void store_interp(TOUT* __restrict__ o, int acc, float inv_q);
-template <>
-__device__ __forceinline__ void store_interp<int16_t>(int16_t* __restrict__ o, int acc, float) { *o = (int16_t)acc; }
-template <>
-__device__ __forceinline__ void store_interp<float>(float* __restrict__ o, int acc, float inv_q) { *o = (float)acc * inv_q; }
-template <>
-__device__ __forceinline__ void store_interp<double>(double* __restrict__ o, int acc, float inv_q) { *o = (double)acc * (double)inv_q; }
-
-template <int OC, typename TIN, typename TOUT>
-__global__ void __launch_bounds__(256)
-lut_interp_kernel(const TIN* __restrict__ img, int64_t sy, int64_t sx, int64_t sc,
-                  int img_h, int img_w, int C, int h, int w, Offsets4 off,
-                  const int8_t* __restrict__ lut, TOUT* __restrict__ out, int64_t oy, int64_t ox, int64_t oc_stride, float inv_q) {
-    int x = blockIdx.x * 16 + (threadIdx.x & 15);
-    int y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    int c = blockIdx.z;
-    if (x >= w || y >= h) return;
-    int v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int yy = clampi(y + off.dy[k], 0, img_h - 1);
-        int xx = clampi(x + off.dx[k], 0, img_w - 1);
-        v[k] = pixel_value<TIN>(img + (yy * sy + xx * sx + c * sc));
-    }
-    SimplexPath p = simplex_path(v[0], v[1], v[2], v[3]);
-#pragma unroll
-    for (int oc = 0; oc < OC; ++oc) {
-        int acc = 0;
-#pragma unroll
-        for (int n = 0; n < 5; ++n) acc += p.w[n] * (int)lut[p.idx[n] * OC + oc];
-        store_interp<TOUT>(out + (((int64_t)c * OC + oc) * oc_stride + (int64_t)y * oy + (int64_t)x * ox), acc, inv_q);
-    }
-}
-
-// the same pass for any sampling interval (resample/eval_lut_sr.py:27-28: q = 2^interval, L = 2^(8-interval) + 1);
-// the shipped LUTs and every fused path use interval 4, this one serves the function mirror for the others
-template <int OC, typename TIN, typename TOUT>
-__global__ void __launch_bounds__(256)
-lut_interp_any_kernel(const TIN* __restrict__ img, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C, int h,
-                      int w, Offsets4 off, const int8_t* __restrict__ lut, int interval, TOUT* __restrict__ out, int64_t oy, int64_t ox,
-                      int64_t oc_stride, float inv_q) {
-    int x = blockIdx.x * 16 + (threadIdx.x & 15);
-    int y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    int c = blockIdx.z;
-    if (x >= w || y >= h) return;
-    const int q = 1 << interval, L = (1 << (8 - interval)) + 1;
-    const int stride[4] = {L * L * L, L * L, L, 1};
-    unsigned key[4];
-    int idx = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int yy = clampi(y + off.dy[k], 0, img_h - 1);
-        int xx = clampi(x + off.dx[k], 0, img_w - 1);
-        const int v = pixel_value<TIN>(img + (yy * sy + xx * sx + c * sc));
-        idx += (v >> interval) * stride[k];
-        key[k] = ((unsigned)(v & (q - 1)) << 24) | (unsigned)stride[k];      // L^3 <= 129^3 < 2^24
-    }
-    ce_desc(key[0], key[1]);
-    ce_desc(key[2], key[3]);
-    ce_desc(key[0], key[2]);
-    ce_desc(key[1], key[3]);
-    ce_desc(key[1], key[2]);
-    int f[5], id[5];
-    id[0] = idx;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        f[n] = (int)(key[n] >> 24);
-        id[n + 1] = id[n] + (int)(key[n] & 0xFFFFFFu);
-    }
-    f[4] = 0;
-#pragma unroll
-    for (int oc = 0; oc < OC; ++oc) {
-        int acc = (q - f[0]) * (int)lut[(int64_t)id[0] * OC + oc];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc += (f[n] - f[n + 1]) * (int)lut[(int64_t)id[n + 1] * OC + oc];
-        store_interp<TOUT>(out + (((int64_t)c * OC + oc) * oc_stride + (int64_t)y * oy + (int64_t)x * ox), acc, inv_q);
-    }
-}
-
-template <int OC, typename TIN, typename TOUT>
-static void launch_lut_interp_t(const void* img, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C, int h, int w,
-                                Offsets4 off, const int8_t* lut, int interval, void* out, int64_t oy, int64_t ox, int64_t ocs, hipStream_t st) {
-    dim3 block(256), grid((w + 15) / 16, (h + 15) / 16, C);
-    const float inv_q = 1.0f / (float)(1 << interval);
-    if (interval != 4)
-        hipLaunchKernelGGL((lut_interp_any_kernel<OC, TIN, TOUT>), grid, block, 0, st, (const TIN*)img, sy, sx, sc, img_h, img_w, C, h, w, off, lut,
-                           interval, (TOUT*)out, oy, ox, ocs, inv_q);
-    else
-        hipLaunchKernelGGL((lut_interp_kernel<OC, TIN, TOUT>), grid, block, 0, st, (const TIN*)img, sy, sx, sc, img_h, img_w, C, h, w, off, lut,
-                           (TOUT*)out, oy, ox, ocs, inv_q);
-}
-
-// in_dtype: LERF_U8 / LERF_F32; out_dtype: LERF_I16 (numerators) / LERF_F32 / LERF_F64 (values); strides in ELEMENTS, signed
-int launch_lut_interp(const void* img, int in_dtype, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C,
-                      int h, int w, Offsets4 off, const int8_t* lut, int oC, int interval, void* out, int out_dtype, int64_t oy,
-                      int64_t ox, int64_t ocs, hipStream_t st) {
-    if (interval < 1 || interval > 7) return LERF_EUNSUPPORTED;
-    if (oC != 1 && oC != 3) return LERF_EUNSUPPORTED;
-    if ((in_dtype != LERF_U8 && in_dtype != LERF_F32) || (out_dtype != LERF_I16 && out_dtype != LERF_F32 && out_dtype != LERF_F64))
-        return LERF_EUNSUPPORTED;
-#define LERF_LI(OC, TIN, TOUT) launch_lut_interp_t<OC, TIN, TOUT>(img, sy, sx, sc, img_h, img_w, C, h, w, off, lut, interval, out, oy, ox, ocs, st)
-#define LERF_LI_OUT(OC, TIN)                                   \
-    do {                                                       \
-        if (out_dtype == LERF_I16) LERF_LI(OC, TIN, int16_t);  \
-        else if (out_dtype == LERF_F32) LERF_LI(OC, TIN, float); \
-        else LERF_LI(OC, TIN, double);                         \
-    } while (0)
-    if (oC == 1) {
-        if (in_dtype == LERF_U8) LERF_LI_OUT(1, uint8_t); else LERF_LI_OUT(1, float);
-    } else {
-        if (in_dtype == LERF_U8) LERF_LI_OUT(3, uint8_t); else LERF_LI_OUT(3, float);
-    }
-#undef LERF_LI_OUT
-#undef LERF_LI
-    return LERF_OK;
-}
 
 // ---------------------------------------------------------------------------
 // A2/A3: one LUT stage (sum over modes x 4 rotations, divide, bias, round, clip)

@@ -202,10 +202,15 @@ def lut_interp_i16(img_u8_chw, h, w, dy, dx, lut_i8, interval=4):
     return out
 
 
-def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None):
-    """One LUT pass with the reference's epilogue in the store (lerf_lut_interp, ABI 6): img uint8 or float32 [C,Hp,Wp] (any
+INTERP_ACCUMULATE, INTERP_LDS, INTERP_DIRECT, INTERP_TILE64, INTERP_TILE32 = 1, 2, 4, 8, 16     # LERF_INTERP_* of include/lerf_hip.h
+
+
+def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None, out=None, accumulate=False, kernel=None):
+    """One LUT pass with the reference's epilogue in the store (lerf_lut_interp_ex, ABI 7): img uint8 or float32 [C,Hp,Wp] (any
     strides) -> [C*oC, h', w'] = np.rot90(values, rot, [1, 2]) as float64 (default) / float32 VALUES (numerator / 2^interval),
-    or the int16 numerators.  The rotation costs nothing: the kernel stores through the strides of the rotated view."""
+    or the int16 numerators.  The rotation costs nothing: the kernel stores through the strides of the rotated view.
+    out: a contiguous [C*oC, h', w'] tensor to write into; accumulate=True: out += result (the call sites' `pred += ...`).
+    kernel: None (the library chooses), "lds", "lds64", "lds32" (the LDS kernel, its tile forced) or "direct" (tests, A/B runs)."""
     torch = _torch()
     if img_chw.dtype not in (torch.uint8, torch.float32) or img_chw.dim() != 3:
         raise ValueError("img must be uint8 or float32 [C,H,W]")
@@ -213,7 +218,7 @@ def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None)
         raise ValueError("interval must be 1..7")
     if lut_i8.dtype != torch.int8 or lut_i8.dim() != 2 or lut_i8.shape[0] != (2 ** (8 - int(interval)) + 1) ** 4:
         raise ValueError("lut must be int8 [L^4,oC] with L = 2^(8-interval) + 1")
-    out_dtype = out_dtype or torch.float64
+    out_dtype = out_dtype or (out.dtype if out is not None else torch.float64)
     if out_dtype not in (torch.float64, torch.float32, torch.int16):
         raise ValueError("out_dtype must be float64, float32 or int16")
     lut = lut_i8.contiguous()
@@ -221,7 +226,14 @@ def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None)
     oC = lut.shape[1]
     h, w, rot = int(h), int(w), int(rot) % 4
     oh, ow = (h, w) if rot % 2 == 0 else (w, h)
-    out = torch.empty((Cn * oC, oh, ow), dtype=out_dtype, device=img_chw.device)
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs the tensor to add into (out=)")
+        out = torch.empty((Cn * oC, oh, ow), dtype=out_dtype, device=img_chw.device)
+    elif tuple(out.shape) != (Cn * oC, oh, ow) or out.dtype != out_dtype or not out.is_contiguous() or out.device != img_chw.device:
+        raise ValueError("out must be a contiguous %s tensor of shape %r on the image's device" % (out_dtype, (Cn * oC, oh, ow)))
+    flags = (INTERP_ACCUMULATE if accumulate else 0) | {None: 0, "lds": INTERP_LDS, "lds64": INTERP_LDS | INTERP_TILE64, "lds32": INTERP_LDS | INTERP_TILE32,
+                                                      "direct": INTERP_DIRECT}[kernel]
     # element (y, x) of the un-rotated result lands at R = rot90(A, rot): rot 1: R[w-1-x, y]; 2: R[h-1-y, w-1-x]; 3: R[x, h-1-y]
     sy, sx, off = {0: (ow, 1, 0), 1: (1, -ow, (w - 1) * ow), 2: (-ow, -1, h * w - 1), 3: (-1, ow, ow - 1)}[rot]
     po = _lib.plane(out, sy, sx, oh * ow, offset=off)
@@ -229,8 +241,8 @@ def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None)
     dx = np.ascontiguousarray(dx, dtype=np.int8)
     p = _planes_chw(img_chw)
     with _lib.on_device(out):
-        _lib.check(_lib.lib().lerf_lut_interp(C.byref(p), Hp, Wp, Cn, h, w, dy.ctypes.data, dx.ctypes.data, lut.data_ptr(), oC,
-                                              int(interval), C.byref(po), _lib.current_stream()), "lerf_lut_interp")
+        _lib.check(_lib.lib().lerf_lut_interp_ex(C.byref(p), Hp, Wp, Cn, h, w, dy.ctypes.data, dx.ctypes.data, lut.data_ptr(), oC,
+                                                 int(interval), C.byref(po), flags, _lib.current_stream()), "lerf_lut_interp_ex")
     return out
 
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "liblerf_hip.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.lerf_abi_version() == 6
+    assert lib.lerf_abi_version() == 7
 
 
 def test_error_strings():
