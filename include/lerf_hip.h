@@ -221,8 +221,13 @@ int lerf_lut_interp(const lerf_plane_t* img, int img_h, int img_w, int C, int h,
 #define LERF_INTERP_ACCUMULATE 1
 #define LERF_INTERP_LDS 2
 #define LERF_INTERP_DIRECT 4
-#define LERF_INTERP_TILE64 8       /* A/B runs: force the 64 x 64 / 64 x 32 tile of the LDS kernel (default: by the launch's tile count) */
+#define LERF_INTERP_TILE64 8       /* A/B runs: force the larger (128 x 32) / smaller (128 x 16) tile of the LDS kernel (default: by the launch's tile count) */
 #define LERF_INTERP_TILE32 16
+#define LERF_INTERP_LUT_PLANAR 32  /* `lut` is oC planes of 83 584 bytes (17^4 entries + padding to 64), plane k = channel k of every entry: the
+                                    * LDS kernel's own format (it copies one plane per workgroup; from the reference's [17^4][oC] layout it has to
+                                    * read all oC).  Interval 4 only; LERF_EUNSUPPORTED when the LDS kernel does not cover the call (the caller
+                                    * repeats it with the interleaved table) */
+#define LERF_LUT_PLANE_BYTES 83584
 int lerf_lut_interp_ex(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
                        const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, int flags, void* stream);
 

@@ -192,7 +192,7 @@ int lerf_lut_interp_ex(const lerf_plane_t* img, int img_h, int img_w, int C, int
     if (!plane_ok(img) || (img->dtype != LERF_U8 && img->dtype != LERF_F32) || !lut || !dy || !dx) return LERF_EINVAL;
     if (!out || !out->ptr || (out->dtype != LERF_I16 && out->dtype != LERF_F32 && out->dtype != LERF_F64)) return LERF_EINVAL;
     if (img_h < 1 || img_w < 1 || C < 1 || h < 1 || w < 1) return LERF_EINVAL;
-    if (flags & ~(LERF_INTERP_ACCUMULATE | LERF_INTERP_LDS | LERF_INTERP_DIRECT | LERF_INTERP_TILE64 | LERF_INTERP_TILE32)) return LERF_EINVAL;
+    if (flags & ~(LERF_INTERP_ACCUMULATE | LERF_INTERP_LDS | LERF_INTERP_DIRECT | LERF_INTERP_TILE64 | LERF_INTERP_TILE32 | LERF_INTERP_LUT_PLANAR)) return LERF_EINVAL;
     if ((flags & LERF_INTERP_LDS) && (flags & LERF_INTERP_DIRECT)) return LERF_EINVAL;
     Offsets4 off;
     memcpy(off.dy, dy, 4);

@@ -130,8 +130,8 @@ constexpr int LI_NT = 1024;                 // threads per workgroup: 16 waves, 
 constexpr int LI_NW = LI_NT / 64;
 constexpr int LI_NCW = 12;                  // waves 0..11 walk the current tile,
 constexpr int LI_NLW = LI_NW - LI_NCW;      // waves 12..15 (one per SIMD) stage the next one meanwhile
-constexpr int LI_NI = 4;                    // wave-rows a compute wave runs interleaved (20 gathers in flight)
-constexpr int LI_TL = 64;                   // tile extent along the lane axis
+constexpr int LI_NR = 2;                    // wave-rows a compute wave runs interleaved: 2 rows x 2 positions per lane = 20 gathers in flight
+constexpr int LI_TL = 128;                  // tile extent along the lane axis: a lane owns two adjacent positions (one 16-byte store)
 constexpr int LI_REACH = 3;                 // largest extent of a pattern the LDS tile provides for (s d y: 2, c t: 3)
 constexpr int LI_LH = LI_TL + LI_REACH;
 constexpr int LI_CMAX = 4;
@@ -139,17 +139,19 @@ constexpr int LI_ENTRIES = kL * kL * kL * kL;                 // 83 521
 constexpr int LI_LUT_BYTES = (LI_ENTRIES + 63) / 64 * 64;      // 83 584
 constexpr int LI_ALL = kStrideA + kStrideB + kStrideC + kStrideD;                   // vertex 4 - vertex 0
 
-// TO = tile extent along the other axis (64: fewest halo pixels; 32: twice the tiles, for launches of few tiles per workgroup)
+// TO = tile extent along the other axis (32; 16: twice the tiles, for launches of few tiles per workgroup)
 template <int TO>
 struct LiDims {
     static constexpr int OH = TO + LI_REACH;
+    static constexpr int ROWS_MAX = LI_CMAX * (LI_LH > OH ? LI_LH : OH);             // staged rows of a planar tile
     // pixel tile: staged rows padded to a multiple of 4 bytes with an odd number of dwords (<= 7 bytes of padding per row)
-    static constexpr int PIX_BYTES = (LI_CMAX * LI_LH * OH + 7 * LI_LH * LI_CMAX + 15) / 16 * 16;
+    static constexpr int PIX_BYTES = (LI_CMAX * LI_LH * OH + 7 * ROWS_MAX + 15) / 16 * 16 + 16;      // + the dump slot
     static constexpr int GROUPS_MAX = LI_CMAX * LI_LH * ((OH + 3) / 4) > LI_CMAX * OH * ((LI_LH + 3) / 4)
                                           ? LI_CMAX * LI_LH * ((OH + 3) / 4) : LI_CMAX * OH * ((LI_LH + 3) / 4);   // 4-pixel groups of a tile
     static constexpr int LDS_BYTES = LI_LUT_BYTES + 2 * PIX_BYTES;
-    // tiles whose loads a loader wave keeps in flight: 2 x 10 x 16 bytes per thread for 64 x 32 tiles; a 64 x 64 tile alone is 18 x 16
-    static constexpr int DEPTH = TO == 32 ? 2 : 1;
+    // tiles whose loads a loader wave keeps in flight: 2 x 11 x 16 bytes per thread for 128 x 16 tiles; a 128 x 32 tile alone is 19 x 16
+    static constexpr int DEPTH = TO == 16 ? 2 : 1;
+    static_assert(PIX_BYTES < 65536 && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 enum { LI_LAYOUT_GENERIC = 0, LI_LAYOUT_HWC = 1, LI_LAYOUT_PLANAR = 2 };
@@ -158,7 +160,7 @@ struct LiArgs {
     const void* img; int64_t sy, sx, sc;     // element strides of the image operand [C][img_h][img_w]
     int64_t max_off;                         // largest element offset inside the operand
     int img_h, img_w, C, h, w;
-    const int8_t* lut;
+    const int8_t* lut; int lut_planar;       // [17^4][OC] as the reference stores it, or OC planes of LI_LUT_BYTES bytes (LERF_INTERP_LUT_PLANAR)
     void* out; int64_t ocs;                  // out plane (c * OC + oc) starts at out + (c * OC + oc) * ocs
     int64_t ol, oo;                          // output strides along the lane axis / the other axis
     int lane_is_y;                           // lanes run along y (the output plane is contiguous along y: rot 1, 3)
@@ -172,6 +174,7 @@ struct LiArgs {
     int koff[4];                             // LDS byte offset of pattern pixel k from the position's own tile cell
 #ifdef LERF_LI_STAMPS
     unsigned long long* stamps;              // diagnostic build: 32 s_memrealtime stamps (100 MHz) per workgroup
+    int stamp_slot;
 #endif
 };
 #ifdef LERF_LI_STAMPS
@@ -262,29 +265,43 @@ __device__ __forceinline__ int li_numerator(const LiWalk& W, const LiEntries& E)
     return acc;
 }
 
-#ifdef LERF_LI_NT_STORE
-#define LI_ST(v, o) __builtin_nontemporal_store(v, o)
-#else
-#define LI_ST(v, o) (*(o) = (v))
-#endif
+// the two values of a lane (adjacent along the axis on which the plane is contiguous) leave as ONE store: 16 bytes of float64
+// per lane, 1 KB per wave-instruction (8-byte stores run at ~7 B/clk/CU, the issue rate of the store path; 16-byte ones twice that)
+template <typename TOUT> struct LiPair;
+template <> struct LiPair<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
+template <> struct LiPair<float> { typedef float type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct LiPair<int16_t> { typedef short type __attribute__((ext_vector_type(2), aligned(2))); };
+template <typename TOUT>
+__device__ __forceinline__ TOUT li_value(int acc) {
+    if constexpr (sizeof(TOUT) == 2) return (TOUT)acc;
+    else return (TOUT)((float)acc * 0.0625f);                     // |acc| <= 2 032: exact in float32
+}
+// o: the pair's lower address; (lo, hi) in memory order; both = false: the lower only (the frame's last odd position)
 template <typename TOUT, bool ACC>
-__device__ __forceinline__ void li_store(TOUT* __restrict__ o, int acc) {
-    if constexpr (sizeof(TOUT) == 2) {
-        *o = ACC ? (int16_t)(*o + acc) : (int16_t)acc;
-    } else if constexpr (sizeof(TOUT) == 4) {
-        const float v = (float)acc * 0.0625f;
-        if constexpr (ACC) *o = *o + v; else LI_ST(v, o);
+__device__ __forceinline__ void li_store2(TOUT* __restrict__ o, int lo, int hi, bool both) {
+    typedef typename LiPair<TOUT>::type P;
+    if (both) {
+        P v = {li_value<TOUT>(lo), li_value<TOUT>(hi)};
+        if constexpr (ACC) v += *reinterpret_cast<P*>(o);
+#ifndef LERF_LI_PLAIN_STORE
+        __builtin_nontemporal_store(v, reinterpret_cast<P*>(o));
+#else
+        *reinterpret_cast<P*>(o) = v;
+#endif
     } else {
-        const double v = (double)((float)acc * 0.0625f);          // |acc| <= 2 032: exact in float32
-        if constexpr (ACC) *o = *o + v; else LI_ST(v, o);
+        TOUT v = li_value<TOUT>(lo);
+        if constexpr (ACC) v += *o;
+        *o = v;
     }
 }
 
-// four pixels -> four bytes, rounded half-to-even and clipped like pixel_value<float>
+// four pixels -> four bytes, rounded half-to-even and clipped like pixel_value<float>: v_rndne_f32 + v_cvt_pk_u8_f32 (the
+// saturating convert with byte insert) per pixel
 __device__ __forceinline__ uint32_t li_pack4(const li_v4f& v) {
-    const int a = (int)__builtin_rintf(fminf(fmaxf(v.x, 0.0f), 255.0f)), b = (int)__builtin_rintf(fminf(fmaxf(v.y, 0.0f), 255.0f));
-    const int c = (int)__builtin_rintf(fminf(fmaxf(v.z, 0.0f), 255.0f)), d = (int)__builtin_rintf(fminf(fmaxf(v.w, 0.0f), 255.0f));
-    return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+    uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(v.x), 0u, 0u);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(v.y), 1u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(v.z), 2u, r);
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(v.w), 3u, r);
 }
 
 // What a thread holds of one 4-pixel group between the load and the LDS store.  The loads are inline assembly: issued
@@ -327,59 +344,80 @@ __device__ __forceinline__ LiTile li_tile_of(const LiArgs& A, int t) {
     return T;
 }
 
-// element offset (32 bits: the host checks that the operand spans less than 2^31 elements) of 4-pixel group q of a fast tile;
-// rows of an HWC tile are image rows (thy_magic = 0: c = 0), rows of a planar tile (channel, image row) pairs
-__device__ __forceinline__ int li_group_src(const LiArgs& A, int yl, int xorg, int q) {
-    const int r = (int)(((unsigned)q * A.groups_magic) >> 20), g = q - r * A.groups;
-    const int c = (int)(((unsigned)r * A.thy_magic) >> 20), yy = r - c * A.th_y;
-    const int gy = min(max(yl + yy, 0), A.img_h - 1);
-    return xorg + c * (int)A.sc + gy * (int)A.sy + g * 4;
-}
-
 __device__ __forceinline__ void li_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int PENDING>
 __device__ __forceinline__ void li_wait_loads_but() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PENDING) : "memory"); }
+__device__ __forceinline__ int li_med3(int a, int b, int c) { return min(max(a, b), c); }     // b <= c: clamp (v_med3_i32)
 
-// fast tile -> LDS by NTHR threads (lt = this thread's index among them): every load in flight before the first conversion
-template <typename TIN, int NTHR, int GROUPS_MAX>
+// fast tile -> LDS by NTHR threads (lt = this thread's index among them): every load in flight before the first conversion.
+// plan[i] describes the thread's i-th 4-pixel group, the same for every tile (one register per group, built once):
+//   bits 0..7 staged row inside its plane (yy), 8..9 plane (c; 0 in HWC tiles), 10..17 group inside the row (g),
+//   18..31 dword offset of the group in the LDS tile (threads beyond the tile's last group: the dump slot behind the tile,
+//   and the last group's source)
+template <typename TIN, int NTHR, int TO>
 struct LiStager {
-    static constexpr int N = (GROUPS_MAX + NTHR - 1) / NTHR;
+    using D = LiDims<TO>;
+    static constexpr int N = (D::GROUPS_MAX + NTHR - 1) / NTHR;
     LiGroup<TIN> pf[N];
-    // lt arrives through an opaque asm at every tile: what depends on it (row / group pairs and their addresses) is
-    // recomputed per tile (~10 instructions per group) instead of living in registers -- or in scratch -- across the tile loop
-    __device__ __forceinline__ void issue(const LiArgs& A, const LiTile& T, int lt) {
+    uint32_t plan[N];
+    __device__ __forceinline__ void make_plan(const LiArgs& A, int lt) {
         const int ng = A.rows * A.groups;
-        const TIN* __restrict__ img = (const TIN*)A.img;
-        const int yl = T.y0 + A.miny, xorg = (T.x0 + A.minx) * (int)A.sx;
-        const int cap = T.fast == 1 ? 0x7FFFFFFF : (T.fast ? (int)A.max_off - 3 : 0);      // generic tiles: a harmless load
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            // every lane loads (threads beyond the tile's last group repeat it): an assembly load under a branch leaves its
-            // register undefined on the other path, which the compiler answers with a scratch slot and a wait per load
-            const int q = min(lt + i * NTHR, ng - 1);
-            pf[i].load(img + max(min(li_group_src(A, yl, xorg, q), cap), 0));    // (generic tiles may start left of the operand)
+            const int q = lt + i * NTHR, qc = min(q, ng - 1);
+            const unsigned r = __umul24((unsigned)qc, A.groups_magic) >> 20, g = (unsigned)qc - __umul24(r, (unsigned)A.groups);
+            const unsigned c = __umul24(r, A.thy_magic) >> 20, yy = r - __umul24(c, (unsigned)A.th_y);   // HWC: thy_magic = 0
+            const unsigned lds = q < ng ? __umul24(r, (unsigned)A.pitch) + g * 4u : (unsigned)(D::PIX_BYTES - 16);
+            plan[i] = yy | (c << 8) | (g << 10) | ((lds >> 2) << 18);
         }
+    }
+    // element offset (32 bits; the host checks the operand's extent and strides) of the group described by p
+    template <bool PLANAR>
+    __device__ __forceinline__ static int src(const LiArgs& A, uint32_t p, int yl, int xorg, int cap) {
+        const int gy = li_med3(yl + (int)(p & 255u), 0, A.img_h - 1);               // rows clamp like the pass's coordinates
+        int off = __mul24(gy, (int)A.sy) + xorg + (int)((p >> 10) & 255u) * 4;
+        if constexpr (PLANAR) off += (int)((p >> 8) & 3u) * (int)A.sc;
+        return li_med3(off, 0, cap);
+    }
+    template <bool PLANAR>
+    __device__ __forceinline__ void issue_t(const LiArgs& A, const LiTile& T) {
+        const TIN* __restrict__ img = (const TIN*)A.img;
+        const int yl = T.y0 + A.miny, xorg = (T.x0 + A.minx) * (int)A.sx;
+        // fast = 2: no group beyond the operand's last four elements; generic tiles (which may start left of the operand): a
+        // harmless load.  Every lane loads: an assembly load under a branch leaves its register undefined on the other path,
+        // which the compiler answers with a scratch slot and a wait per load.
+        const int cap = T.fast == 1 ? 0x7FFFFFFF : (T.fast ? (int)A.max_off - 3 : 0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint32_t p = plan[i];
+            asm volatile("" : "+v"(p));        // opaque: or the compiler hoists the fields of all 18 plans out of the tile loop, into scratch
+            pf[i].load(img + src<PLANAR>(A, p, yl, xorg, cap));
+        }
+    }
+    __device__ __forceinline__ void issue(const LiArgs& A, const LiTile& T) {
+        if (A.cs == 1) issue_t<false>(A, T); else issue_t<true>(A, T);
     }
     // PENDING = loads this wave has issued after this tile's (deeper prefetch: the sets of the following tiles)
     template <int PENDING>
-    __device__ __forceinline__ void commit(const LiArgs& A, const LiTile& T, uint8_t* pix, int lt) {
-        const int ng = A.rows * A.groups;
+    __device__ __forceinline__ void commit(LiArgs& A, const LiTile& T, uint8_t* pix) {
         li_wait_loads_but<PENDING>();
-        const int yl = T.y0 + A.miny, xorg = (T.x0 + A.minx) * (int)A.sx;
+#ifdef LERF_LI_STAMPS
+        if ((threadIdx.x == 0 || threadIdx.x == LI_NCW * 64) && A.stamps && A.stamp_slot < 32) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); A.stamps[(size_t)blockIdx.x * 32 + A.stamp_slot] = t_; }
+#endif
+        const uint32_t pix_a = li_lds_addr(pix);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int q = lt + i * NTHR;
             pf[i].landed();
             uint32_t v = pf[i].bytes();
+            uint32_t p = plan[i];
+            asm volatile("" : "+v"(p));
             if (T.fast == 2) {                             // wave-uniform, one tile per launch at most
-                const int off = li_group_src(A, yl, xorg, min(q, ng - 1));
+                const int yl = T.y0 + A.miny, xorg = (T.x0 + A.minx) * (int)A.sx;
+                const int off = A.cs == 1 ? src<false>(A, p, yl, xorg, 0x7FFFFFFF) : src<true>(A, p, yl, xorg, 0x7FFFFFFF);
                 const int sh = off - min(off, (int)A.max_off - 3);
                 v = sh < 4 ? v >> (8 * sh) : 0u;           // the elements beyond the operand are read by no valid position
             }
-            if (q < ng) {
-                const int r = (int)(((unsigned)q * A.groups_magic) >> 20), g = q - r * A.groups;
-                *reinterpret_cast<uint32_t*>(pix + r * A.pitch + g * 4) = v;
-            }
+            *(__attribute__((address_space(3))) uint32_t*)(pix_a + ((p >> 18) << 2)) = v;
         }
     }
 };
@@ -410,13 +448,39 @@ __device__ __forceinline__ void li_stage_generic(const LiArgs& A, const LiTile& 
 
 template <int OC, typename TIN, typename TOUT, bool ACC, int TO>
 __global__ void __launch_bounds__(LI_NT)
-lut_interp_lds_kernel(LiArgs A) {
+lut_interp_lds_kernel(LiArgs A_) {
+    LiArgs A = A_;
     using D = LiDims<TO>;
     extern __shared__ __attribute__((aligned(16))) uint8_t li_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int plane = (int)blockIdx.x % OC, slot = (int)blockIdx.x / OC;
-    const int nslots = ((int)gridDim.x - plane + OC - 1) / OC;
+    // oC = 3: the three workgroups that walk the same tile sequence (one per plane) read the same pixels at the same time.
+    // Workgroups are dealt to the 8 XCDs round-robin (an affinity, nothing depends on it but speed): a triple is made of three
+    // workgroups of ONE XCD, so that the tile is fetched from HBM once and served twice by that XCD's L2; the one or two
+    // workgroups an XCD has left over form triples across XCDs.
+    int plane = 0, slot = (int)blockIdx.x, nslots = (int)gridDim.x;
+    if constexpr (OC == 3) {
+        const int G = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, j = b >> 3;
+        int full_before = 0, left_before = 0, full_all = 0, left_all = 0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int nx = (G - x + 7) >> 3;
+            if (x < xcd) { full_before += nx / 3; left_before += nx % 3; }
+            full_all += nx / 3;
+            left_all += nx % 3;
+        }
+        const int nx = (G - xcd + 7) >> 3, full = nx / 3;
+        nslots = full_all + left_all / 3;
+        if (j < 3 * full) {
+            plane = j % 3;
+            slot = full_before + j / 3;
+        } else {
+            const int L = left_before + (j - 3 * full);
+            plane = L % 3;
+            slot = full_all + L / 3;
+            if (slot >= nslots) return;                          // the last one or two workgroups of the launch make no triple
+        }
+    }
     const int ntiles = A.tiles_x * A.tiles_y;
     LI_STAMP(0);
     int t = slot;
@@ -429,8 +493,8 @@ lut_interp_lds_kernel(LiArgs A) {
         uint4* L128 = reinterpret_cast<uint4*>(li_smem);
         constexpr int NQ = LI_ENTRIES / 16;                          // 5 220 whole 16-entry blocks, + 1 entry
         constexpr int NLQ = (NQ + LI_NT - 1) / LI_NT;                // 6 per thread
-        if constexpr (OC == 1) {
-            const uint4* s = reinterpret_cast<const uint4*>(A.lut);
+        if (OC == 1 || A.lut_planar) {
+            const uint4* s = reinterpret_cast<const uint4*>(A.lut + (size_t)plane * LI_LUT_BYTES);
             uint4 r[NLQ];
 #pragma unroll
             for (int i = 0; i < NLQ; ++i) r[i] = s[min(tid + i * LI_NT, NQ - 1)];
@@ -460,14 +524,15 @@ lut_interp_lds_kernel(LiArgs A) {
                 }
             }
         }
-        if (tid == 0) li_smem[LI_ENTRIES - 1] = (uint8_t)A.lut[(size_t)(LI_ENTRIES - 1) * OC + plane];
+        if (tid == 0) li_smem[LI_ENTRIES - 1] = (uint8_t)(OC == 1 || A.lut_planar ? A.lut[(size_t)plane * LI_LUT_BYTES + LI_ENTRIES - 1] : A.lut[(size_t)(LI_ENTRIES - 1) * OC + plane]);
     };
     if (T.fast) {
-        LiStager<TIN, LI_NT, D::GROUPS_MAX> S0;
-        S0.issue(A, T, tid);
+        LiStager<TIN, LI_NT, TO> S0;
+        S0.make_plan(A, tid);
+        S0.issue(A, T);
         copy_lut();
         LI_STAMP(1);
-        S0.template commit<0>(A, T, pix0, tid);
+        S0.template commit<0>(A, T, pix0);
     } else {
         copy_lut();
         LI_STAMP(1);
@@ -477,81 +542,95 @@ lut_interp_lds_kernel(LiArgs A) {
     LI_STAMP(2);
     const uint32_t lut_a = li_lds_addr(li_smem);
 
-    // ---- the walks of one tile: wave-rows of 64 positions = (channel, other-axis index), LI_NI rows interleaved
+    // ---- the walks of one tile: wave-rows of 128 positions = (channel, other-axis index), two per lane; LI_NR rows interleaved
     const int lstride = A.lane_is_y ? A.pitch : A.xs, ostride = A.lane_is_y ? A.xs : A.pitch;
     const int nl = A.lane_is_y ? A.h : A.w, no = A.lane_is_y ? A.w : A.h;
     TOUT* const outp = (TOUT*)A.out;
     const int nrows = A.C * TO;
+    const bool rev = A.ol < 0;                                             // the plane runs backwards along the lane axis (rot 2, 3)
     auto out_row = [&](int c, int o) { return outp + ((int64_t)(c * OC + plane) * A.ocs + (int64_t)o * A.oo); };
     auto compute = [&](const LiTile& Tc, const uint8_t* pix) {
         const int l0 = A.lane_is_y ? Tc.y0 : Tc.x0, o0 = A.lane_is_y ? Tc.x0 : Tc.y0;
-        const bool lane_ok = l0 + lane < nl;
-        const int lane_out = (int)((int64_t)(l0 + lane) * A.ol);
-        const uint32_t pix_a = li_lds_addr(pix) + (uint32_t)(lane * lstride);
+        const int lpos = l0 + 2 * lane;                                    // this lane's positions: lpos, lpos + 1
+        const bool ok0 = lpos < nl, ok1 = lpos + 1 < nl;
+        // lower address of the pair: position lpos when the plane runs forwards, lpos + 1 when backwards
+        const int lane_out = (int)((int64_t)(rev && ok1 ? lpos + 1 : lpos) * A.ol);
+        const uint32_t pa0 = li_lds_addr(pix) + (uint32_t)(2 * lane * lstride), pa1 = pa0 + (uint32_t)lstride;
         const int ovalid = min(TO, no - o0);                               // rows of the tile inside the frame
+        auto one_row = [&](int c, int o) {
+            const uint32_t s0 = (uint32_t)(c * A.cs + o * ostride);
+            uint32_t p[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { p[0][k] = li_pixel_hi(pa0 + (s0 + A.koff[k])); p[1][k] = li_pixel_hi(pa1 + (s0 + A.koff[k])); }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]), "+v"(p[1][0]), "+v"(p[1][1]), "+v"(p[1][2]), "+v"(p[1][3]));
+            const LiWalk W0 = li_walk(lut_a, p[0][0], p[0][1], p[0][2], p[0][3]);
+            const LiEntries E0 = li_gather(W0);
+            const LiWalk W1 = li_walk(lut_a, p[1][0], p[1][1], p[1][2], p[1][3]);
+            const LiEntries E1 = li_gather(W1);
+            const int n0 = li_numerator(W0, E0), n1 = li_numerator(W1, E1);
+#ifdef LERF_LI_NO_STORE
+            if (n0 == 0x7FFFFFF && ok0)
+#else
+            if (ok0)
+#endif
+                li_store2<TOUT, ACC>(out_row(c, o0 + o) + lane_out, rev && ok1 ? n1 : n0, rev ? n0 : n1, ok1);
+        };
 #pragma unroll 1
-        for (int r0 = wave; r0 < nrows; r0 += LI_NCW * LI_NI) {
-            int c[LI_NI], o[LI_NI];
-            bool ok[LI_NI];
+        for (int r0 = wave; r0 < nrows; r0 += LI_NCW * LI_NR) {
+            int c[LI_NR], o[LI_NR];
             bool all = true;
 #pragma unroll
-            for (int j = 0; j < LI_NI; ++j) {
+            for (int j = 0; j < LI_NR; ++j) {
                 const int r = r0 + j * LI_NCW;
                 c[j] = r / TO;
                 o[j] = r - c[j] * TO;
-                ok[j] = r < nrows && o[j] < ovalid;                        // wave-uniform
-                all = all && ok[j];
+                all = all && r < nrows && o[j] < ovalid;                   // wave-uniform
             }
             if (all) {
-                uint32_t px[LI_NI][4];
+                uint32_t px[LI_NR][2][4];
 #pragma unroll
-                for (int j = 0; j < LI_NI; ++j) {
-                    const uint32_t b = pix_a + (uint32_t)(c[j] * A.cs + o[j] * ostride);
+                for (int j = 0; j < LI_NR; ++j) {
+                    const uint32_t s0 = (uint32_t)(c[j] * A.cs + o[j] * ostride);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) px[j][k] = li_pixel_hi(b + A.koff[k]);
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t sk = s0 + (uint32_t)A.koff[k];      // scalar
+                        px[j][0][k] = li_pixel_hi(pa0 + sk);
+                        px[j][1][k] = li_pixel_hi(pa1 + sk);
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]), "+v"(px[1][0]), "+v"(px[1][1]), "+v"(px[1][2]), "+v"(px[1][3]),
-                               "+v"(px[2][0]), "+v"(px[2][1]), "+v"(px[2][2]), "+v"(px[2][3]), "+v"(px[3][0]), "+v"(px[3][1]), "+v"(px[3][2]), "+v"(px[3][3]));
-                LiWalk W[LI_NI];
-                LiEntries E[LI_NI];
+                             : "+v"(px[0][0][0]), "+v"(px[0][0][1]), "+v"(px[0][0][2]), "+v"(px[0][0][3]), "+v"(px[0][1][0]), "+v"(px[0][1][1]), "+v"(px[0][1][2]), "+v"(px[0][1][3]),
+                               "+v"(px[1][0][0]), "+v"(px[1][0][1]), "+v"(px[1][0][2]), "+v"(px[1][0][3]), "+v"(px[1][1][0]), "+v"(px[1][1][1]), "+v"(px[1][1][2]), "+v"(px[1][1][3]));
+                LiWalk W[LI_NR][2];
+                LiEntries E[LI_NR][2];
 #pragma unroll
-                for (int j = 0; j < LI_NI; ++j) {
+                for (int j = 0; j < LI_NR; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
 #ifdef LERF_LI_NO_WALK
-                    W[j].k0 = px[j][0]; W[j].k1 = px[j][1]; W[j].k2 = px[j][2]; W[j].k3 = px[j][3];
-                    E[j].e0 = px[j][0]; E[j].e1 = px[j][1]; E[j].e2 = px[j][2]; E[j].e3 = px[j][3]; E[j].e4 = px[j][0];
+                        W[j][q].k0 = px[j][q][0]; W[j][q].k1 = px[j][q][1]; W[j][q].k2 = px[j][q][2]; W[j][q].k3 = px[j][q][3];
+                        E[j][q].e0 = px[j][q][0]; E[j][q].e1 = px[j][q][1]; E[j][q].e2 = px[j][q][2]; E[j][q].e3 = px[j][q][3]; E[j][q].e4 = px[j][q][0];
 #else
-                    W[j] = li_walk(lut_a, px[j][0], px[j][1], px[j][2], px[j][3]);
-                    E[j] = li_gather(W[j]);
-                    __builtin_amdgcn_sched_barrier(0);                      // this walk's gathers fly under the next walk
+                        W[j][q] = li_walk(lut_a, px[j][q][0], px[j][q][1], px[j][q][2], px[j][q][3]);
+                        E[j][q] = li_gather(W[j][q]);
+                        __builtin_amdgcn_sched_barrier(0);                  // this walk's gathers fly under the next walk
 #endif
-                }
+                    }
 #pragma unroll
-                for (int j = 0; j < LI_NI; ++j) {
-                    const int nj = li_numerator(W[j], E[j]);
+                for (int j = 0; j < LI_NR; ++j) {
+                    const int n0 = li_numerator(W[j][0], E[j][0]), n1 = li_numerator(W[j][1], E[j][1]);
 #ifdef LERF_LI_NO_STORE                                                     // ablation builds (tools/build_li_variant.sh): never the product
-                    if (nj == 0x7FFFFFF && lane_ok)
+                    if (n0 == 0x7FFFFFF && ok0)
 #else
-                    if (lane_ok)
+                    if (ok0)
 #endif
-                        li_store<TOUT, ACC>(out_row(c[j], o0 + o[j]) + lane_out, nj);
+                        li_store2<TOUT, ACC>(out_row(c[j], o0 + o[j]) + lane_out, rev && ok1 ? n1 : n0, rev ? n0 : n1, ok1);
                 }
             } else {
-#pragma unroll 1
-                for (int j = 0; j < LI_NI; ++j) {
-                    if (!ok[j]) continue;
-                    const uint32_t b = pix_a + (uint32_t)(c[j] * A.cs + o[j] * ostride);
-                    uint32_t p0 = li_pixel_hi(b + A.koff[0]), p1 = li_pixel_hi(b + A.koff[1]), p2 = li_pixel_hi(b + A.koff[2]), p3 = li_pixel_hi(b + A.koff[3]);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
-                    const LiWalk W1 = li_walk(lut_a, p0, p1, p2, p3);
-                    const LiEntries E1 = li_gather(W1);
-                    const int n1 = li_numerator(W1, E1);
-#ifdef LERF_LI_NO_STORE
-                    if (n1 == 0x7FFFFFF && lane_ok)
-#else
-                    if (lane_ok)
-#endif
-                        li_store<TOUT, ACC>(out_row(c[j], o0 + o[j]) + lane_out, n1);
+#pragma unroll
+                for (int j = 0; j < LI_NR; ++j) {
+                    const int r = r0 + j * LI_NCW;
+                    if (r < nrows && o[j] < ovalid) one_row(c[j], o[j]);
                 }
             }
         }
@@ -566,17 +645,24 @@ lut_interp_lds_kernel(LiArgs A) {
 #ifndef LERF_LI_NO_STAGE
         // D::DEPTH register sets: while tile t is walked, tile t + 1 is converted and the loads of tiles t + 2 .. t + 1 + DEPTH
         // are in flight (reads wait microseconds behind the launch's own stores: one tile of lead is not enough)
-        int lt = tid - LI_NCW * 64;
-        using Stager = LiStager<TIN, LI_NLW * 64, D::GROUPS_MAX>;
+#ifndef LERF_LI_NO_PRIO
+        __builtin_amdgcn_s_setprio(3);                                  // one loader wave beside three walking waves per SIMD: it goes first
+#endif
+        const int lt = tid - LI_NCW * 64;
+        using Stager = LiStager<TIN, LI_NLW * 64, TO>;
         Stager S[D::DEPTH];
         LiTile Ts[D::DEPTH];
         int cur = 0;
+        S[0].make_plan(A, lt);
+#pragma unroll
+        for (int d = 1; d < D::DEPTH; ++d)
+#pragma unroll
+            for (int i = 0; i < Stager::N; ++i) S[d].plan[i] = S[0].plan[i];
 #pragma unroll
         for (int d = 0; d < D::DEPTH; ++d) {
             const int td = t + (1 + d) * nslots;
             Ts[d] = li_tile_of(A, td < ntiles ? td : t);
-            asm volatile("" : "+v"(lt));
-            S[d].issue(A, Ts[d], lt);                                   // (a tile of the generic kind loads nothing useful)
+            S[d].issue(A, Ts[d]);                                       // (a tile of the generic kind loads nothing useful)
         }
         bool done = false;
 #pragma unroll 1
@@ -585,12 +671,16 @@ lut_interp_lds_kernel(LiArgs A) {
             for (int d = 0; d < D::DEPTH; ++d) {
                 if (t + nslots >= ntiles) { done = true; break; }
                 uint8_t* nxt = pix0 + (cur ^ 1) * D::PIX_BYTES;
-                asm volatile("" : "+v"(lt));
-                if (Ts[d].fast) S[d].template commit<(D::DEPTH - 1) * Stager::N>(A, Ts[d], nxt, lt);
+#ifdef LERF_LI_STAMPS
+                A.stamp_slot = 14 + 3 * ((stamp_k - 3) / 2);
+#endif
+                if (Ts[d].fast) S[d].template commit<(D::DEPTH - 1) * Stager::N>(A, Ts[d], nxt);
                 else { li_wait_loads(); li_stage_generic<TIN>(A, Ts[d], nxt, lt, LI_NLW * 64); }
+                LI_STAMP_L(15 + 3 * ((stamp_k - 3) / 2));
                 const int tnn = t + (1 + D::DEPTH) * nslots;
                 Ts[d] = li_tile_of(A, tnn < ntiles ? tnn : t);
-                S[d].issue(A, Ts[d], lt);
+                S[d].issue(A, Ts[d]);
+                LI_STAMP_L(16 + 3 * ((stamp_k - 3) / 2));
                 LI_STAMP_L(stamp_k + 1);
                 stamp_k += 2;
                 __syncthreads();
@@ -688,7 +778,7 @@ static int try_lut_interp_lds(const void* img, int in_dtype, int64_t sy, int64_t
     const int64_t span = (int64_t)(h - 1) * (oy < 0 ? -oy : oy) + (int64_t)(w - 1) * (ox < 0 ? -ox : ox);
     if (span >= (1ll << 30) || sy < 0 || sx < 0 || sc < 0) return LERF_EUNSUPPORTED;
     const int64_t max_off = (int64_t)(C - 1) * sc + (int64_t)(img_h - 1) * sy + (int64_t)(img_w - 1) * sx;
-    if (max_off >= (1ll << 31) - 16 || max_off < 3) return LERF_EUNSUPPORTED;
+    if (max_off >= (1ll << 31) - 16 || max_off < 3 || sy >= (1 << 23) || img_h >= (1 << 23)) return LERF_EUNSUPPORTED;
     LiArgs A{};
 #ifdef LERF_LI_STAMPS
     A.stamps = g_li_stamps;
@@ -696,19 +786,20 @@ static int try_lut_interp_lds(const void* img, int in_dtype, int64_t sy, int64_t
     A.img = img; A.sy = sy; A.sx = sx; A.sc = sc;
     A.max_off = (int64_t)(C - 1) * sc + (int64_t)(img_h - 1) * sy + (int64_t)(img_w - 1) * sx;
     A.img_h = img_h; A.img_w = img_w; A.C = C; A.h = h; A.w = w;
-    A.lut = lut; A.out = out; A.ocs = ocs;
+    A.lut = lut; A.lut_planar = (flags & LERF_INTERP_LUT_PLANAR) ? 1 : 0; A.out = out; A.ocs = ocs;
     // lanes run along the axis on which the output plane is contiguous
     A.lane_is_y = ((oy == 1 || oy == -1) && !(ox == 1 || ox == -1)) ? 1 : 0;
     A.ol = A.lane_is_y ? oy : ox;
     A.oo = A.lane_is_y ? ox : oy;
     A.miny = miny; A.minx = minx; A.maxx = maxx;
-    // 64 x 64 tiles, or 64 x 32 when that leaves a workgroup fewer than four tiles (the pipeline of staging under walking
+    // 128 x 32 tiles, or 128 x 16 when that leaves a workgroup fewer than four tiles (the pipeline of staging under walking
     // needs a few, and the last round of a short sequence is the whole tail)
     const int cus = li_cu_count();
-    const int64_t tiles64 = (int64_t)((h + 63) / 64) * ((w + 63) / 64);
-    int TO = tiles64 * oC >= 4ll * cus ? 64 : 32;
-    if (flags & LERF_INTERP_TILE64) TO = 64;
-    if (flags & LERF_INTERP_TILE32) TO = 32;
+    const int nl_ = A.lane_is_y ? h : w, no_ = A.lane_is_y ? w : h;
+    const int64_t tiles32 = (int64_t)((nl_ + LI_TL - 1) / LI_TL) * ((no_ + 31) / 32);
+    int TO = tiles32 * oC >= 4ll * cus ? 32 : 16;
+    if (flags & LERF_INTERP_TILE64) TO = 32;
+    if (flags & LERF_INTERP_TILE32) TO = 16;
     A.tile_h = A.lane_is_y ? LI_TL : TO; A.tile_w = A.lane_is_y ? TO : LI_TL;
     A.th_y = A.tile_h + LI_REACH; A.th_x = A.tile_w + LI_REACH;
     A.tiles_x = (w + A.tile_w - 1) / A.tile_w; A.tiles_y = (h + A.tile_h - 1) / A.tile_h;
@@ -731,7 +822,7 @@ static int try_lut_interp_lds(const void* img, int in_dtype, int64_t sy, int64_t
     int grid = cus;
     if (grid > ntiles * oC) grid = ntiles * oC;
     const bool acc = (flags & LERF_INTERP_ACCUMULATE) != 0;
-#define LERF_LL_T(OC, TIN, TOUT, ACC) (TO == 64 ? li_launch<OC, TIN, TOUT, ACC, 64>(A, grid, st) : li_launch<OC, TIN, TOUT, ACC, 32>(A, grid, st))
+#define LERF_LL_T(OC, TIN, TOUT, ACC) (TO == 32 ? li_launch<OC, TIN, TOUT, ACC, 32>(A, grid, st) : li_launch<OC, TIN, TOUT, ACC, 16>(A, grid, st))
 #define LERF_LL(OC, TIN, TOUT) (acc ? LERF_LL_T(OC, TIN, TOUT, true) : LERF_LL_T(OC, TIN, TOUT, false))
 #define LERF_LL_OUT(OC, TIN) (out_dtype == LERF_I16 ? LERF_LL(OC, TIN, int16_t) : out_dtype == LERF_F32 ? LERF_LL(OC, TIN, float) : LERF_LL(OC, TIN, double))
     if (oC == 1) return in_dtype == LERF_U8 ? LERF_LL_OUT(1, uint8_t) : LERF_LL_OUT(1, float);
@@ -749,10 +840,11 @@ int launch_lut_interp(const void* img, int in_dtype, int64_t sy, int64_t sx, int
     if (oC != 1 && oC != 3) return LERF_EUNSUPPORTED;
     if ((in_dtype != LERF_U8 && in_dtype != LERF_F32) || (out_dtype != LERF_I16 && out_dtype != LERF_F32 && out_dtype != LERF_F64))
         return LERF_EUNSUPPORTED;
+    if ((flags & LERF_INTERP_LUT_PLANAR) && (interval != 4 || (flags & LERF_INTERP_DIRECT))) return LERF_EINVAL;
     if (interval == 4) {
         const int rc = try_lut_interp_lds(img, in_dtype, sy, sx, sc, img_h, img_w, C, h, w, off, lut, oC, out, out_dtype, oy, ox, ocs, flags, st);
         if (rc != LERF_EUNSUPPORTED) return rc;
-        if (flags & LERF_INTERP_LDS) return LERF_EUNSUPPORTED;            // the caller insisted on the LDS kernel
+        if (flags & (LERF_INTERP_LDS | LERF_INTERP_LUT_PLANAR)) return LERF_EUNSUPPORTED;   // the caller insisted on the LDS kernel (a planar LUT is its format)
     }
     const bool acc = (flags & LERF_INTERP_ACCUMULATE) != 0;
 #define LERF_LI(OC, TIN, TOUT)                                                                                                  \

@@ -202,15 +202,28 @@ def lut_interp_i16(img_u8_chw, h, w, dy, dx, lut_i8, interval=4):
     return out
 
 
-INTERP_ACCUMULATE, INTERP_LDS, INTERP_DIRECT, INTERP_TILE64, INTERP_TILE32 = 1, 2, 4, 8, 16     # LERF_INTERP_* of include/lerf_hip.h
+INTERP_ACCUMULATE, INTERP_LDS, INTERP_DIRECT, INTERP_TILE64, INTERP_TILE32, INTERP_LUT_PLANAR = 1, 2, 4, 8, 16, 32     # LERF_INTERP_*
+LUT_PLANE_BYTES = 83584                                                                             # LERF_LUT_PLANE_BYTES
 
 
-def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None, out=None, accumulate=False, kernel=None):
+def lut_planes(lut_i8):
+    """[17^4, oC] int8 -> the LDS kernel's own layout, [oC, 83584] (LERF_INTERP_LUT_PLANAR): a workgroup then copies its plane
+    alone instead of reading all oC interleaved bytes of every entry"""
+    torch = _torch()
+    n, oC = lut_i8.shape
+    planes = torch.zeros((oC, LUT_PLANE_BYTES), dtype=torch.int8, device=lut_i8.device)
+    planes[:, :n] = lut_i8.t()
+    return planes
+
+
+
+def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None, out=None, accumulate=False, kernel=None, planes=None):
     """One LUT pass with the reference's epilogue in the store (lerf_lut_interp_ex, ABI 7): img uint8 or float32 [C,Hp,Wp] (any
     strides) -> [C*oC, h', w'] = np.rot90(values, rot, [1, 2]) as float64 (default) / float32 VALUES (numerator / 2^interval),
     or the int16 numerators.  The rotation costs nothing: the kernel stores through the strides of the rotated view.
     out: a contiguous [C*oC, h', w'] tensor to write into; accumulate=True: out += result (the call sites' `pred += ...`).
-    kernel: None (the library chooses), "lds", "lds64", "lds32" (the LDS kernel, its tile forced) or "direct" (tests, A/B runs)."""
+    kernel: None (the library chooses), "lds", "lds64", "lds32" (the LDS kernel, its tile forced) or "direct" (tests, A/B runs).
+    planes: lut_planes(lut_i8), handed to the LDS kernel when it takes the call (interval 4)."""
     torch = _torch()
     if img_chw.dtype not in (torch.uint8, torch.float32) or img_chw.dim() != 3:
         raise ValueError("img must be uint8 or float32 [C,H,W]")
@@ -241,6 +254,14 @@ def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None,
     dx = np.ascontiguousarray(dx, dtype=np.int8)
     p = _planes_chw(img_chw)
     with _lib.on_device(out):
+        if planes is not None and int(interval) == 4 and kernel != "direct" and oC > 1:
+            if planes.dtype != torch.int8 or tuple(planes.shape) != (oC, LUT_PLANE_BYTES) or not planes.is_contiguous():
+                raise ValueError("planes must be lut_planes(lut_i8)")
+            rc = _lib.lib().lerf_lut_interp_ex(C.byref(p), Hp, Wp, Cn, h, w, dy.ctypes.data, dx.ctypes.data, planes.data_ptr(), oC,
+                                               4, C.byref(po), flags | INTERP_LUT_PLANAR, _lib.current_stream())
+            if rc != -2 or kernel is not None:             # LERF_EUNSUPPORTED: the direct kernel serves the call from the interleaved table
+                _lib.check(rc, "lerf_lut_interp_ex")
+                return out
         _lib.check(_lib.lib().lerf_lut_interp_ex(C.byref(p), Hp, Wp, Cn, h, w, dy.ctypes.data, dx.ctypes.data, lut.data_ptr(), oC,
                                                  int(interval), C.byref(po), flags, _lib.current_stream()), "lerf_lut_interp_ex")
     return out

@@ -30,7 +30,7 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
         lazy_out = False
     as_numpy = not isinstance(img_in, torch.Tensor)
     img = _upload_image(torch, np.asarray(img_in)) if as_numpy else img_in
-    lut = _device_lut(torch, weight, oC, img.device)
+    lut, planes = _device_lut(torch, weight, oC, img.device)
     if img.dtype not in (torch.uint8, torch.float32):
         img = img.to(torch.float32)                    # (float64 / integer images: exact for the 0..255 values of the contract)
     pad = mode_pad_dict[mode]
@@ -38,7 +38,7 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
         raise ValueError("img_in must be padded by {} pixels for mode {}".format(pad, mode))
     # one launch: float32 / uint8 pixels in, float64 values out, already rotated back by `rot` quarter turns and divided by
     # q (:464-469) -- the kernel stores through the strides of the rotated view (lerf_lut_interp, ABI 6)
-    out = ops.lut_interp(img, h, w, dy, dx, lut, interval, rot=int(rot), out_dtype=torch.float64)
+    out = ops.lut_interp(img, h, w, dy, dx, lut, interval, rot=int(rot), out_dtype=torch.float64, planes=planes)
     if lazy_out or (as_numpy and lazy.enabled()):
         return lazy.DeviceArray(out)                   # numpy-shaped, device-backed: the caller's += / clip / round stay in HBM
     return out.cpu().numpy() if as_numpy else out
@@ -62,18 +62,23 @@ _LUTS = {}
 
 
 def _device_lut(torch, weight, oC, device):
+    """-> (int8 [L^4, oC] on the device, its plane form for the LDS kernel or None)"""
+    def planes_of(lut):
+        return ops.lut_planes(lut) if oC > 1 and lut.shape[0] == 17 ** 4 else None
     if isinstance(weight, torch.Tensor):
         lut = weight.to(device).reshape(-1, oC)
-        return lut.round().to(torch.int8) if lut.dtype != torch.int8 else lut
+        lut = lut.round().to(torch.int8) if lut.dtype != torch.int8 else lut
+        return lut, None
     w = np.asarray(weight)
     key = (w.__array_interface__["data"][0], w.shape, w.strides, w.dtype.str, int(oC), str(device))
     hit = _LUTS.get(key)
     if hit is not None and np.array_equal(hit[0], w):
-        return hit[1]
+        return hit[1], hit[3]
     lut = torch.from_numpy(np.ascontiguousarray(w)).to(device).reshape(-1, oC)
     lut = lut.round().to(torch.int8) if lut.dtype != torch.int8 else lut
     _LUTS.pop(key, None)
     if len(_LUTS) >= 32:
         _LUTS.pop(next(iter(_LUTS)))
-    _LUTS[key] = (w.copy(), lut, w)                     # `w` itself keeps the buffer (and with it the key) alive
-    return lut
+    planes = planes_of(lut)
+    _LUTS[key] = (w.copy(), lut, w, planes)             # `w` itself keeps the buffer (and with it the key) alive
+    return lut, planes

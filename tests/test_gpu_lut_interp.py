@@ -133,3 +133,40 @@ def test_lds_kernel_equals_direct_at_1080p_and_accumulates(torch, luts_g, oC):
     with pytest.raises(_lib.LerfError):
         ops.lut_interp(x, h - 1, w - 1, far_dy, far_dx, lut, 4, kernel="lds")
     ops.lut_interp(x, h - 1, w - 1, far_dy, far_dx, lut, 4)
+
+
+def test_lds_kernel_rounds_and_clips_float_pixels_like_the_direct_kernel(torch, luts_g):
+    """non-integer / out-of-range float pixels: rounded half-to-even and clipped to 0..255 in the tile staging (v_rndne +
+    the saturating v_cvt_pk_u8_f32) exactly like pixel_value<float> of the direct kernel"""
+    from lerf_pytorch_amd import _lib, ops
+    lut = _lut(torch, luts_g, 1)
+    vals = torch.tensor([-3.0, 0.5, 1.5, 2.5, 254.5, 255.5, 300.0, 7.49, 1e9, -1e9, 127.5, 128.5, -0.4, 0.49999, 255.49, 1e-30],
+                        device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    idx = torch.randint(0, vals.numel(), (3, 140, 200), device="cuda", generator=g)
+    planar = vals[idx].contiguous()
+    hwc = planar.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    for x in (planar, hwc):
+        for mode in "sct":
+            dy, dx = _lib.mode_offsets(mode, 0)
+            a = ops.lut_interp(x, 137, 197, dy, dx, lut, 4, out_dtype=torch.int16, kernel="lds")
+            b = ops.lut_interp(x, 137, 197, dy, dx, lut, 4, out_dtype=torch.int16, kernel="direct")
+            c = ops.lut_interp(x.round().clamp(0, 255).to(torch.uint8), 137, 197, dy, dx, lut, 4, out_dtype=torch.int16, kernel="lds")
+            assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_planar_lut_form(torch, luts_g):
+    """LERF_INTERP_LUT_PLANAR: the LDS kernel fed its own plane layout == the interleaved table; the direct kernel (small
+    launch, library's choice) is served from the interleaved table as before"""
+    from lerf_pytorch_amd import _lib, ops
+    lut = _lut(torch, luts_g, 3)
+    planes = ops.lut_planes(lut)
+    assert tuple(planes.shape) == (3, 83584)
+    rng = np.random.default_rng(11)
+    for (h, w) in ((300, 500), (20, 30)):
+        x = torch.from_numpy(rng.integers(0, 256, (h + 3, w + 3, 3), dtype=np.uint8)).cuda().to(torch.float32).permute(2, 0, 1)
+        for mode, rot in (("s", 0), ("t", 1)):
+            dy, dx = _lib.mode_offsets(mode, 0)
+            want = ops.lut_interp(x, h, w, dy, dx, lut, 4, rot=rot, kernel="direct")
+            assert torch.equal(ops.lut_interp(x, h, w, dy, dx, lut, 4, rot=rot, planes=planes), want)
+            assert torch.equal(ops.lut_interp(x, h, w, dy, dx, lut, 4, rot=rot, planes=planes, kernel="lds"), want)

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--lib", default=None, help="a variant build of liblerf_hip.so (tools/build_li_variant.sh)")
     ap.add_argument("--kernels", default="lds,direct")
+    ap.add_argument("--oc", default="1,3")
+    ap.add_argument("--no-acc", action="store_true")
+    ap.add_argument("--planes", action="store_true", help="hand the LDS kernel the plane form of the LUT")
     a = ap.parse_args()
     import torch
     import lerf_pytorch_amd as L
@@ -28,8 +31,9 @@ def main():
         _lib.use_library(a.lib)
     rng = np.random.default_rng(0)
     rows = []
-    for oC in (1, 3):
+    for oC in [int(v) for v in a.oc.split(",")]:
         lut = torch.from_numpy(rng.integers(-128, 128, (17 ** 4, oC), dtype=np.int8)).cuda()
+        planes = ops.lut_planes(lut) if a.planes and oC > 1 else None
         for mode in ("s", "c", "t"):
             for rot in (0, 1, 2, 3):
                 if a.quick and not ((mode, rot) in (("s", 0), ("c", 1), ("t", 2))):
@@ -41,16 +45,16 @@ def main():
                 out = torch.empty((3 * oC,) + ((h, w) if rot % 2 == 0 else (w, h)), dtype=torch.float64, device="cuda")
                 row = {"oC": oC, "mode": mode, "rot": rot}
                 for kern in a.kernels.split(","):
-                    for acc in (False, True):
+                    for acc in ((False,) if a.no_acc else (False, True)):
                         if acc:
                             out.zero_()
                         for _ in range(3):
-                            ops.lut_interp(x, h, w, dy, dx, lut, 4, rot=rot, out=out, accumulate=acc, kernel=kern)
+                            ops.lut_interp(x, h, w, dy, dx, lut, 4, rot=rot, out=out, accumulate=acc, kernel=kern, planes=None if kern == "direct" else planes)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         torch.cuda.synchronize()
                         e0.record()
                         for _ in range(a.iters):
-                            ops.lut_interp(x, h, w, dy, dx, lut, 4, rot=rot, out=out, accumulate=acc, kernel=kern)
+                            ops.lut_interp(x, h, w, dy, dx, lut, 4, rot=rot, out=out, accumulate=acc, kernel=kern, planes=None if kern == "direct" else planes)
                         e1.record()
                         torch.cuda.synchronize()
                         row["%s%s_us" % (kern, "_acc" if acc else "")] = round(e0.elapsed_time(e1) * 1000.0 / a.iters, 2)
