@@ -231,6 +231,17 @@ int lerf_lut_interp(const lerf_plane_t* img, int img_h, int img_w, int C, int h,
 int lerf_lut_interp_ex(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4], const int8_t dx[4],
                        const int8_t* lut, int oC, int interval, const lerf_mplane_t* out, int flags, void* stream);
 
+/* ABI 7.  The call sites' epilogue of a LUT stage (resample/eval_lut_sr.py:573-577, 621-628, resample/eval_lut_warp.py:136-140,
+ * 185-191), applied to the int16 NUMERATORS a chain of LERF_INTERP_ACCUMULATE passes has summed (value = numerator / 2^interval):
+ *     np.round(np.clip(pred / avg_factor + bias, 0, norm)).astype(np.float32)
+ * as a program of float64 steps in the caller's order -- each step is numpy's own float64 operation (IEEE division, addition,
+ * minimum / maximum, round-half-even), the result is rounded once to float32: bit for bit what numpy returns for the float64
+ * array acc / 2^interval.  acc: int16 [n]; out: float32 [n] (device, dense). */
+enum { LERF_EPI_DIV = 0, LERF_EPI_MUL = 1, LERF_EPI_ADD = 2, LERF_EPI_CLIP = 3, LERF_EPI_ROUND = 4 };
+#define LERF_EPI_MAX_OPS 8
+typedef struct { int op; double a, b; } lerf_epi_op_t;   /* DIV / MUL / ADD: operand a; CLIP: [a, b]; ROUND: none */
+int lerf_numer_epilogue_f32(const int16_t* acc, int64_t n, int interval, const lerf_epi_op_t* ops, int n_ops, float* out, void* stream);
+
 /* LUT pack for the tile-fused kernel (1..4 modes per stage, any of "sdyct"; oC = 1 or 3): the stage-1
  * LUTs padded to 16-byte multiples, and the stage-2 LUTs as one uint32 per
  * entry holding the oC biased bytes, cut into the pieces the kernel stages (layout in DESIGN.md).  The caller owns

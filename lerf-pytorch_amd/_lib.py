@@ -40,7 +40,7 @@ def pad_mode_code(name, allowed):
 
 EXPORTS = [
     "lerf_abi_version", "lerf_strerror", "lerf_device_count", "lerf_mode_offsets", "lerf_sr_axis_tables", "lerf_sr_axis_tables_f32",
-    "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_lut_interp", "lerf_lut_interp_ex", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
+    "lerf_out_size", "lerf_invert3x3", "lerf_warp_pads", "lerf_lut_interp_i16", "lerf_lut_interp", "lerf_lut_interp_ex", "lerf_numer_epilogue_f32", "lerf_fused_lutpack_bytes", "lerf_fused_lutpack_build",
     "lerf_lut_stages_u8",
     "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_supported", "lerf_sr_fused_u8",
     "lerf_sr_ragged_workspace_bytes", "lerf_sr_fused_ragged_u8", "lerf_stages_ragged_workspace_bytes", "lerf_stages_packed_ragged_u8",
@@ -57,6 +57,10 @@ class LerfError(RuntimeError):
 
 class Plane(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int), ("sy", C.c_int64), ("sx", C.c_int64), ("sc", C.c_int64)]
+
+
+class EpiOp(C.Structure):
+    _fields_ = [("op", C.c_int), ("a", C.c_double), ("b", C.c_double)]
 
 
 class Luts(C.Structure):
@@ -157,6 +161,7 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.c_void_p]
     L.lerf_lut_interp_ex.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.c_int, C.c_void_p]
+    L.lerf_numer_epilogue_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.lerf_fused_lutpack_bytes.restype = C.c_size_t
     L.lerf_fused_lutpack_bytes.argtypes = [C.POINTER(Luts)]
     L.lerf_fused_lutpack_build.argtypes = [C.POINTER(Luts), C.c_void_p, C.c_void_p]

@@ -202,6 +202,12 @@ int lerf_lut_interp_ex(const lerf_plane_t* img, int img_h, int img_w, int C, int
     return rc != LERF_OK ? rc : check_launch();
 }
 
+int lerf_numer_epilogue_f32(const int16_t* acc, int64_t n, int interval, const lerf_epi_op_t* ops, int n_ops, float* out, void* stream) {
+    if (!acc || !out || n < 1 || (n_ops > 0 && !ops)) return LERF_EINVAL;
+    int rc = launch_numer_epilogue(acc, n, interval, ops, n_ops, out, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
 size_t lerf_fused_lutpack_bytes(const lerf_luts_t* luts) { return luts ? fused_lutpack_bytes(luts) : 0; }
 
 int lerf_fused_lutpack_build(const lerf_luts_t* luts, void* buf, void* stream) {

@@ -47,6 +47,7 @@ struct WarpArgs {
 int launch_lut_interp(const void* img, int in_dtype, int64_t sy, int64_t sx, int64_t sc, int img_h, int img_w, int C,
                       int h, int w, Offsets4 off, const int8_t* lut, int oC, int interval, void* out, int out_dtype, int64_t oy,
                       int64_t ox, int64_t ocs, int flags, hipStream_t st);
+int launch_numer_epilogue(const int16_t* acc, int64_t n, int interval, const lerf_epi_op_t* ops, int n_ops, float* out, hipStream_t st);
 int launch_lut_stage(const uint8_t* img, int64_t sy, int64_t sx, int64_t sc, int H, int W, int C,
                      const StageLuts& luts, int oC, int div, int bias,
                      uint8_t* out, int64_t oy, int64_t ox, int64_t ocs, hipStream_t st);

@@ -327,21 +327,37 @@ __device__ __forceinline__ LiTile li_tile_of(const LiArgs& A, int t) {
     T.y0 = ty * A.tile_h;
     T.x0 = tx * A.tile_w;
     // fast staging (16-byte loads in the operand's memory order): rows are clamped to the operand like the pass clamps its
-    // coordinates; columns are not, so every column a position of the frame reads must exist -- columns beyond them hold
-    // whatever follows in memory (read only by positions outside the frame) -- and the last group must end inside the operand
+    // coordinates.  Columns are not: either every column a position of the frame reads exists (columns beyond them hold
+    // whatever follows in memory, read only by positions outside the frame), or the tile is of kind 3: the staged columns left
+    // and right of the operand are filled in LDS afterwards from the operand's first / last column (li_fix_columns).
+    // Kind 2 / 3: the 16-byte groups are loaded no further than the operand's first / last four elements and their bytes
+    // shifted back into place (the frame's corners).
     const int xl = T.x0 + A.minx;
     const int x_need = min(T.x0 + A.tile_w, A.w) + A.maxx;                      // one past the last column a valid position reads
-    const bool fast = A.layout != LI_LAYOUT_GENERIC && xl >= 0 && x_need <= A.img_w;
+    const bool inside = xl >= 0 && x_need <= A.img_w;
+    const int nlo = max(0, -xl), hi0 = min(A.th_x, A.img_w - xl);               // staged columns [nlo, hi0) exist in the operand
     T.fast = 0;
-    if (fast) {
-        // the last group of the last staged row may end beyond the operand (the frame's bottom right corner): such a tile
-        // (fast = 2) loads its groups no further than the operand's last four elements and shifts the bytes back into place
+    if (A.layout != LI_LAYOUT_GENERIC && (inside || nlo < hi0)) {
         const int yl = min(max(T.y0 + A.miny + A.th_y - 1, 0), A.img_h - 1);      // last staged row, clamped
         const int64_t last = (A.layout == LI_LAYOUT_HWC ? 0 : (int64_t)(A.C - 1) * A.sc) + (int64_t)yl * A.sy + (int64_t)xl * A.sx +
                              (int64_t)A.groups * 4 - 1;
-        T.fast = last <= A.max_off ? 1 : 2;
+        T.fast = !inside ? 3 : (last <= A.max_off ? 1 : 2);
     }
     return T;
+}
+
+// kind-3 tiles: the staged columns outside the operand <- the operand's first / last column, in LDS (edge padding = clamped
+// coordinates); by nthr threads, between two barriers
+__device__ __forceinline__ void li_fix_columns(const LiArgs& A, const LiTile& T, uint8_t* pix, int lt, int nthr) {
+    const int xl = T.x0 + A.minx;
+    const int nlo = max(0, -xl), hi0 = min(A.th_x, A.img_w - xl), ncol = nlo + (A.th_x - hi0);
+    const int per = A.cs == 1 ? A.C : 1;                                        // HWC tiles: the channels of a pixel lie side by side
+    const int n = A.rows * ncol * per;
+    for (int i = lt; i < n; i += nthr) {
+        const int c = i % per, j = (i / per) % ncol, r = i / (per * ncol);
+        const int xx = j < nlo ? j : hi0 + (j - nlo), from = j < nlo ? nlo : hi0 - 1;
+        pix[r * A.pitch + xx * A.xs + c] = pix[r * A.pitch + from * A.xs + c];
+    }
 }
 
 __device__ __forceinline__ void li_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -373,11 +389,15 @@ struct LiStager {
     }
     // element offset (32 bits; the host checks the operand's extent and strides) of the group described by p
     template <bool PLANAR>
-    __device__ __forceinline__ static int src(const LiArgs& A, uint32_t p, int yl, int xorg, int cap) {
+    __device__ __forceinline__ static int src_raw(const LiArgs& A, uint32_t p, int yl, int xorg) {
         const int gy = li_med3(yl + (int)(p & 255u), 0, A.img_h - 1);               // rows clamp like the pass's coordinates
         int off = __mul24(gy, (int)A.sy) + xorg + (int)((p >> 10) & 255u) * 4;
         if constexpr (PLANAR) off += (int)((p >> 8) & 3u) * (int)A.sc;
-        return li_med3(off, 0, cap);
+        return off;
+    }
+    template <bool PLANAR>
+    __device__ __forceinline__ static int src(const LiArgs& A, uint32_t p, int yl, int xorg, int cap) {
+        return li_med3(src_raw<PLANAR>(A, p, yl, xorg), 0, cap);
     }
     template <bool PLANAR>
     __device__ __forceinline__ void issue_t(const LiArgs& A, const LiTile& T) {
@@ -411,11 +431,12 @@ struct LiStager {
             uint32_t v = pf[i].bytes();
             uint32_t p = plan[i];
             asm volatile("" : "+v"(p));
-            if (T.fast == 2) {                             // wave-uniform, one tile per launch at most
+            if (T.fast >= 2) {                             // wave-uniform: the frame's corners / left and right border
                 const int yl = T.y0 + A.miny, xorg = (T.x0 + A.minx) * (int)A.sx;
-                const int off = A.cs == 1 ? src<false>(A, p, yl, xorg, 0x7FFFFFFF) : src<true>(A, p, yl, xorg, 0x7FFFFFFF);
-                const int sh = off - min(off, (int)A.max_off - 3);
-                v = sh < 4 ? v >> (8 * sh) : 0u;           // the elements beyond the operand are read by no valid position
+                const int off = A.cs == 1 ? src_raw<false>(A, p, yl, xorg) : src_raw<true>(A, p, yl, xorg);
+                const int sh = off - li_med3(off, 0, (int)A.max_off - 3);          // the load was moved by -sh elements
+                // the elements beyond the operand are read by no valid position (kind 2) or filled by li_fix_columns (kind 3)
+                v = sh >= 0 ? (sh < 4 ? v >> (8 * sh) : 0u) : (sh > -4 ? v << (8 * -sh) : 0u);
             }
             *(__attribute__((address_space(3))) uint32_t*)(pix_a + ((p >> 18) << 2)) = v;
         }
@@ -539,6 +560,10 @@ lut_interp_lds_kernel(LiArgs A_) {
         li_stage_generic<TIN>(A, T, pix0, tid, LI_NT);
     }
     __syncthreads();
+    if (T.fast == 3) {
+        li_fix_columns(A, T, pix0, tid, LI_NT);
+        __syncthreads();
+    }
     LI_STAMP(2);
     const uint32_t lut_a = li_lds_addr(li_smem);
 
@@ -664,12 +689,13 @@ lut_interp_lds_kernel(LiArgs A_) {
             Ts[d] = li_tile_of(A, td < ntiles ? td : t);
             S[d].issue(A, Ts[d]);                                       // (a tile of the generic kind loads nothing useful)
         }
-        bool done = false;
+        bool done = false, fix_now = false;         // (the first tile's columns were filled at start-up)
 #pragma unroll 1
         while (!done) {
 #pragma unroll
             for (int d = 0; d < D::DEPTH; ++d) {
                 if (t + nslots >= ntiles) { done = true; break; }
+                if (fix_now) __syncthreads();                               // the walking waves fill this period's tile's border columns
                 uint8_t* nxt = pix0 + (cur ^ 1) * D::PIX_BYTES;
 #ifdef LERF_LI_STAMPS
                 A.stamp_slot = 14 + 3 * ((stamp_k - 3) / 2);
@@ -686,16 +712,26 @@ lut_interp_lds_kernel(LiArgs A_) {
                 __syncthreads();
                 cur ^= 1;
                 t += nslots;
+                fix_now = li_tile_of(A, t).fast == 3;
             }
         }
+        if (fix_now) __syncthreads();
         li_wait_loads();                                                // nothing of this wave may be in flight at its end
 #else
-        while (t + nslots < ntiles) { __syncthreads(); t += nslots; }
+        bool fix_now = false;
+        while (t + nslots < ntiles) { if (fix_now) __syncthreads(); __syncthreads(); t += nslots; fix_now = li_tile_of(A, t).fast == 3; }
+        if (fix_now) __syncthreads();
 #endif
     } else {
         int cur = 0;
+        bool first = true;
 #pragma unroll 1
         for (;;) {
+            if (!first && T.fast == 3) {
+                li_fix_columns(A, T, pix0 + cur * D::PIX_BYTES, tid, LI_NCW * 64);
+                __syncthreads();
+            }
+            first = false;
             compute(T, pix0 + cur * D::PIX_BYTES);
             LI_STAMP(stamp_k);
             stamp_k += 2;
@@ -830,6 +866,60 @@ static int try_lut_interp_lds(const void* img, int in_dtype, int64_t sy, int64_t
 #undef LERF_LL_OUT
 #undef LERF_LL
 #undef LERF_LL_T
+}
+
+// ---------------------------------------------------------------------------
+// the call sites' epilogue of a LUT stage on the summed NUMERATORS (resample/eval_lut_sr.py:573-577, 621-628):
+//   np.round(np.clip(pred / avg_factor + bias, 0, norm)).astype(np.float32)
+// pred = numerators / q (exact in float64); every step is the float64 operation numpy performs, in numpy's order, no
+// contraction -- the float32 array the caller gets is bit for bit numpy's.  The steps come as a small program.
+// ---------------------------------------------------------------------------
+struct EpiProgram { int n; int op[LERF_EPI_MAX_OPS]; double a[LERF_EPI_MAX_OPS], b[LERF_EPI_MAX_OPS]; };
+
+__global__ void __launch_bounds__(256)
+numer_epilogue_kernel(const int16_t* __restrict__ acc, int64_t n, double inv_q, EpiProgram P, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    int16_t v[4] = {0, 0, 0, 0};
+    const bool full = i0 + 4 <= n && (reinterpret_cast<uintptr_t>(acc) & 7) == 0;
+    if (full) {
+        const uint2 w = *reinterpret_cast<const uint2*>(acc + i0);
+        v[0] = (int16_t)(w.x & 0xFFFFu); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFFu); v[3] = (int16_t)(w.y >> 16);
+    } else {
+        for (int k = 0; k < 4; ++k) if (i0 + k < n) v[k] = acc[i0 + k];
+    }
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double x = (double)v[k] * inv_q;                       // exact: q is a power of two
+        for (int j = 0; j < P.n; ++j) {
+            switch (P.op[j]) {
+                case LERF_EPI_DIV: x = x / P.a[j]; break;
+                case LERF_EPI_MUL: x = x * P.a[j]; break;
+                case LERF_EPI_ADD: x = x + P.a[j]; break;
+                case LERF_EPI_CLIP: x = fmin(fmax(x, P.a[j]), P.b[j]); break;
+                default: x = __builtin_rint(x); break;          // LERF_EPI_ROUND: half to even, np.round
+            }
+        }
+        r[k] = (float)x;                                       // astype(np.float32): round to nearest even
+    }
+    if (full && (reinterpret_cast<uintptr_t>(out) & 15) == 0) *reinterpret_cast<float4*>(out + i0) = make_float4(r[0], r[1], r[2], r[3]);
+    else for (int k = 0; k < 4; ++k) if (i0 + k < n) out[i0 + k] = r[k];
+}
+
+int launch_numer_epilogue(const int16_t* acc, int64_t n, int interval, const lerf_epi_op_t* ops, int n_ops, float* out, hipStream_t st) {
+    if (n_ops < 0 || n_ops > LERF_EPI_MAX_OPS || interval < 1 || interval > 7) return LERF_EINVAL;
+    EpiProgram P{};
+    P.n = n_ops;
+    for (int j = 0; j < n_ops; ++j) {
+        if (ops[j].op < LERF_EPI_DIV || ops[j].op > LERF_EPI_ROUND) return LERF_EINVAL;
+        P.op[j] = ops[j].op; P.a[j] = ops[j].a; P.b[j] = ops[j].b;
+    }
+    const int64_t blocks = (n + 1023) / 1024;
+    if (blocks > 0x7FFFFFFF) return LERF_EUNSUPPORTED;
+    hipLaunchKernelGGL(numer_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, acc, n, 1.0 / (double)(1 << interval), P, out);
+    return LERF_OK;
 }
 
 // in_dtype: LERF_U8 / LERF_F32; out_dtype: LERF_I16 (numerators) / LERF_F32 / LERF_F64 (values); strides in ELEMENTS, signed

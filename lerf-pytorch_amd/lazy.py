@@ -17,6 +17,9 @@ never different.  `set_enabled(False)` restores plain numpy results.
 """
 from __future__ import annotations
 
+import sys
+import weakref
+
 import numpy as np
 
 _ENABLED = True
@@ -283,6 +286,7 @@ class DeviceArray(object):
 
     def __setitem__(self, idx, value):
         torch = _torch()
+        _flush_dependents(self._vc)                                             # pending results that READ this storage run first
         ti = self._index(idx)
         v = value
         if isinstance(v, DeviceArray):
@@ -336,6 +340,23 @@ class DeviceArray(object):
         return NotImplemented
 
     def _bin(self, other, ufunc, op, reflected=False, inplace=False):
+        if isinstance(other, LazyArray) and other.pending and ufunc is np.add:
+            r = other._fold_into_add(self, reflected, inplace)                  # `pred += FourSimplexInterpFaster(...)`: one launch
+            if r is not None:
+                return r
+        if isinstance(self, LazyArray) and self.pending and self._recipe:
+            if reflected and ufunc is np.add and isinstance(other, (int, float)) and not isinstance(other, bool) and other == 0 \
+                    and self._recipe[0] == "interp" and sys.getrefcount(self) <= _TEMP_REFS:
+                # `pred = 0; pred += F(...)`: 0 + x is x for every value the pass produces (no negative zeros) and the temporary
+                # has no other owner (CPython reference count, calibrated at import): the pass becomes the sum's first term
+                return self._start_sum()
+            if not inplace and self._recipe[0] in ("sum", "expr") and isinstance(other, (int, float)) and not isinstance(other, bool) \
+                    and ufunc in _EPI_UFUNCS and (not reflected or ufunc in (np.add, np.multiply)):
+                r = self._extend(_EPI_UFUNCS[ufunc], float(other))
+                if r is not None:
+                    return r
+        if inplace:
+            _flush_dependents(self._vc)
         rd = _result_dtype(ufunc, other, self) if reflected else _result_dtype(ufunc, self, other)
         if rd is None or _np_to_torch_dtype(rd) is None or not isinstance(other, (DeviceArray, np.ndarray, np.generic) + _PY_SCALARS) \
                 or rd.kind not in "fiub" or (rd.kind != "f" and ufunc is np.true_divide):
@@ -484,6 +505,234 @@ class DeviceArray(object):
         return func(*_host(args), **_host(kwargs))
 
 
+_PENDING = {}                         # id -> weak reference: LazyArrays that have not run yet (arrays are unhashable, like numpy's)
+
+
+def _temp_refcount():
+    """what sys.getrefcount reports inside _bin for an operand that only the running statement holds (`x = 0; x += f()`),
+    measured on this interpreter with the same call depth (__radd__ -> _bin) instead of assumed"""
+    seen = []
+
+    class Probe(object):
+        def _bin(self, o):
+            seen.append(sys.getrefcount(self))
+            return self
+
+        def __radd__(self, o):
+            return self._bin(o)
+    x = 0
+    x += Probe()
+    return seen[0]
+
+
+_TEMP_REFS = _temp_refcount()
+
+
+def _flush_dependents(vc):
+    """a storage is about to be written: every pending result that reads it runs first (numpy would have computed it already)"""
+    if not _PENDING:
+        return
+    for ref in list(_PENDING.values()):
+        lz = ref()
+        if lz is not None and lz.pending and any(d._vc is vc for d in lz._deps):
+            lz.t
+
+
+class LazyArray(DeviceArray):
+    """A DeviceArray whose tensor does not exist yet: shape and dtype are known, `make()` produces the tensor when anything
+    asks for it (`.t`).  Two kinds are made, both of the call sites' statement sequence (resample/eval_lut_sr.py:549-564):
+
+      np.rot90(img, r) -> np.pad(..., ((0, p), (0, p), (0, 0)), mode="edge") -> .transpose((2, 0, 1))
+          recipe ("rot" | "rotpad" | "rotpad_chw", base, k, ph, pw): FourSimplexInterpFaster recognises the chain and runs the
+          pass on `base` itself with the pattern's offsets rotated k times and clamped coordinates -- no rotated, no padded copy;
+      FourSimplexInterpFaster(...)  recipe ("interp", run): `pred += result` launches the pass ONCE, adding into pred's planes
+          (lerf_lut_interp_ex, LERF_INTERP_ACCUMULATE) instead of a launch, a 50 / 150 MB result and an add kernel.
+
+    Used in any other way it materialises and is an ordinary DeviceArray from then on (the old statement-by-statement path, same
+    values).  `deps`: the DeviceArrays whose storage `make` reads -- a write to one of them runs every pending reader first."""
+
+    def __init__(self, shape, np_dtype, deps, make, recipe=None):
+        self._t = None
+        self._shape = tuple(int(v) for v in shape)
+        self._dtype = np.dtype(np_dtype)
+        self._deps = list(deps)
+        self._make = make
+        self._recipe = recipe
+        self._np = None
+        self._np_ver = -1
+        self._vc = [0]
+        key = id(self)
+        _PENDING[key] = weakref.ref(self, lambda _r, k=key: _PENDING.pop(k, None))
+
+    pending = property(lambda self: self._t is None)
+
+    def _get_t(self):
+        if self._t is None:
+            t = self._make()
+            self._t, self._make, self._deps = t, None, []
+            _PENDING.pop(id(self), None)
+        return self._t
+
+    def _set_t(self, v):
+        self._t = v
+    t = property(_get_t, _set_t)
+    shape = property(lambda self: self._shape if self._t is None else tuple(self._t.shape))
+    ndim = property(lambda self: len(self._shape) if self._t is None else self._t.dim())
+    size = property(lambda self: int(np.prod(self._shape)) if self._t is None else self._t.numel())
+    dtype = property(lambda self: self._dtype if self._t is None else np.dtype(_torch_to_np_dtype(self._t.dtype)))
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError("len() of unsized object")
+        return self.shape[0]
+
+    def transpose(self, *axes):
+        if len(axes) == 1 and isinstance(axes[0], (tuple, list)):
+            axes = tuple(axes[0])
+        if self.pending and self._recipe and self._recipe[0] == "rchain" and tuple(axes) == (1, 2, 0) and len(self._shape) == 3:
+            r = self._rchain("hwc", (self._shape[1], self._shape[2], self._shape[0]))
+            if r is not None:
+                return r
+        if self.pending and self._recipe and self._recipe[0] == "rotpad" and tuple(axes) == (2, 0, 1):
+            _, base, k, ph, pw = self._recipe
+            me = self
+            return LazyArray((self._shape[2], self._shape[0], self._shape[1]), self._dtype, self._deps,
+                             lambda: me.t.permute(2, 0, 1), ("rotpad_chw", base, k, ph, pw))
+        return DeviceArray.transpose(self, *axes)
+
+    # ---- the sum of passes and the stage epilogue (resample/eval_lut_sr.py:547-577): int16 numerators until the caller's
+    #      `.astype(np.float32)`, one fused launch for `np.round(np.clip(pred / n + bias, 0, norm)).astype(np.float32)`
+    def _start_sum(self):
+        """pending pass -> pending sum holding its int16 numerators (value * 2^interval): 2 bytes per element instead of 8"""
+        torch = _torch()
+        _, run, interval, dev = self._recipe
+        acc = torch.empty(self._shape, dtype=torch.int16, device=dev)
+        run(acc, False)
+        return _sum_array(acc, interval, 127 << interval)
+
+    def _extend(self, op, *operands):
+        """pending sum / expression + one more float64 step of the epilogue grammar -> pending expression; None: not ours"""
+        kind = self._recipe[0]
+        acc, interval = self._recipe[1], self._recipe[2]
+        steps = list(self._recipe[3]) if kind == "expr" else []
+        if len(steps) >= 8:
+            return None
+        steps.append((op,) + tuple(float(v) for v in operands))
+        return _expr_array(acc, interval, steps)
+
+    # ---- the worker's last statement on a resampler result (resample/eval_lut_sr.py:663-665):
+    #      np.clip(np.round(out).transpose((1, 2, 0)), 0, norm).astype(np.uint8)
+    def _rchain(self, step, shape=None):
+        root, steps = (self, ()) if self._recipe[0] == "resize" else (self._recipe[1], self._recipe[2])
+        steps = steps + (step,)
+        if steps != _RESIZE_TAIL[:len(steps)]:
+            return None
+        return LazyArray(shape or self._shape, np.float64, [root], lambda: _apply_tail(root, steps).t, ("rchain", root, steps))
+
+    def clip(self, min=None, max=None, out=None, **kw):
+        if self.pending and self._recipe and self._recipe[0] == "rchain" and out is None and not kw and (min, max) == (0, 255) \
+                and all(isinstance(v, int) and not isinstance(v, bool) for v in (min, max)):
+            r = self._rchain("clip")
+            if r is not None:
+                return r
+        if self.pending and self._recipe and self._recipe[0] in ("sum", "expr") and out is None and not kw \
+                and all(isinstance(v, (int, float)) and not isinstance(v, bool) for v in (min, max)):
+            r = self._extend("clip", min, max)
+            if r is not None:
+                return r
+        return DeviceArray.clip(self, min, max, out=out, **kw)
+
+    def round(self, decimals=0, out=None):
+        if self.pending and self._recipe and self._recipe[0] == "resize" and decimals == 0 and out is None:
+            r = self._rchain("round")
+            if r is not None:
+                return r
+        if self.pending and self._recipe and self._recipe[0] in ("sum", "expr") and decimals == 0 and out is None:
+            r = self._extend("round")
+            if r is not None:
+                return r
+        return DeviceArray.round(self, decimals, out)
+
+    def astype(self, dtype, *a, **k):
+        if self.pending and self._recipe and self._recipe[0] == "rchain" and self._recipe[2] == _RESIZE_TAIL and not a and not k \
+                and np.dtype(dtype) == np.uint8 and self._recipe[1].pending:
+            return DeviceArray(self._recipe[1]._recipe[1]())
+        if self.pending and self._recipe and self._recipe[0] in ("sum", "expr") and not a and not k and np.dtype(dtype) == np.float32:
+            from . import ops
+            kind, acc, interval = self._recipe[0], self._recipe[1], self._recipe[2]
+            steps = self._recipe[3] if kind == "expr" else []
+            code = {"div": ops.EPI_DIV, "mul": ops.EPI_MUL, "add": ops.EPI_ADD, "clip": ops.EPI_CLIP, "round": ops.EPI_ROUND}
+            return DeviceArray(ops.numer_epilogue(acc, interval, [(code[st[0]],) + tuple(st[1:]) for st in steps]))
+        return DeviceArray.astype(self, dtype, *a, **k)
+
+    def _fold_into_add(self, target, reflected, inplace):
+        """`target += self` / `target + self` for a pending pass: run it into (a copy of) target's planes; None = not this case"""
+        if not (self._recipe and self._recipe[0] == "interp") or not isinstance(target, DeviceArray) or target is self:
+            return None
+        torch = _torch()
+        if isinstance(target, LazyArray) and target.pending and target._recipe and target._recipe[0] == "sum":
+            # the sum is still int16 numerators: add this pass's numerators (same interval, no overflow: |n| <= 127 q per pass)
+            _, acc, interval, bound = target._recipe
+            mine = self._recipe[2]
+            if inplace and mine == interval and tuple(acc.shape) == self._shape and bound + (127 << interval) <= 32767 \
+                    and self._recipe[1](acc, True):
+                target._recipe = ("sum", acc, interval, bound + (127 << interval))
+                return target
+        tt = target.t
+        if tt.dtype != torch.float64 or tuple(tt.shape) != self._shape or not tt.is_cuda or not tt.is_contiguous():
+            return None
+        run = self._recipe[1]
+        if inplace:
+            _flush_dependents(target._vc)
+            if not run(tt, True):
+                return None
+            target._touch()
+            return target
+        out = tt.clone()
+        return DeviceArray(out) if run(out, True) else None
+
+
+_EPI_UFUNCS = {np.true_divide: "div", np.multiply: "mul", np.add: "add"}
+_RESIZE_TAIL = ("round", "hwc", "clip")
+
+
+def _apply_tail(root, steps):
+    """the steps of the worker's last statement one at a time on the float64 result (the statement-by-statement path)"""
+    x = DeviceArray(root.t)
+    for st in steps:
+        x = DeviceArray.round(x) if st == "round" else (DeviceArray.transpose(x, 1, 2, 0) if st == "hwc" else DeviceArray.clip(x, 0, 255))
+    return x
+
+
+
+def _sum_array(acc, interval, bound):
+    """pending float64 array = acc / 2^interval (exact), kept as the int16 numerators"""
+    torch = _torch()
+    return LazyArray(acc.shape, np.float64, [], lambda: acc.to(torch.float64) / float(1 << interval), ("sum", acc, interval, bound))
+
+
+def _apply_steps(x, steps):
+    """the float64 steps one at a time through the ordinary DeviceArray operations (the statement-by-statement path)"""
+    for st in steps:
+        if st[0] == "div":
+            x = x / st[1]
+        elif st[0] == "mul":
+            x = x * st[1]
+        elif st[0] == "add":
+            x = x + st[1]
+        elif st[0] == "clip":
+            x = DeviceArray.clip(x, st[1], st[2])
+        else:
+            x = DeviceArray.round(x)
+    return x
+
+
+def _expr_array(acc, interval, steps):
+    torch = _torch()
+    return LazyArray(acc.shape, np.float64, [],
+                     lambda: _apply_steps(DeviceArray(acc.to(torch.float64) / float(1 << interval)), steps).t, ("expr", acc, interval, steps))
+
+
 for _n, _f in (("_add", "add"), ("_sub", "sub"), ("_mul", "mul"), ("_div", "true_divide")):
     setattr(DeviceArray, _n, staticmethod(DeviceArray._t(_f)))
 del DeviceArray._t
@@ -530,11 +779,31 @@ def _transpose(a, axes=None):
 
 @_implements(np.rot90)
 def _rot90(m, k=1, axes=(0, 1)):
-    """a fresh array (numpy returns a view: a write through the rotated array does not reach `m` here)"""
+    """a fresh array (numpy returns a view: a write through the rotated array does not reach `m` here).  [H, W, C] images rotated
+    in their first two axes come back lazy (LazyArray): the call sites only ever pad them and hand them to the LUT pass."""
     if not isinstance(m, DeviceArray):
         return NotImplemented
     torch = _torch()
-    return DeviceArray(torch.rot90(m.t, int(k), [int(axes[0]), int(axes[1])]))
+    k, ax = int(k), (int(axes[0]), int(axes[1]))
+    if m.ndim == 3 and ax == (0, 1) and not (isinstance(m, LazyArray) and m.pending) and m.t.is_cuda:
+        H, W, Cn = m.shape
+        shape = (H, W, Cn) if k % 2 == 0 else (W, H, Cn)
+        return LazyArray(shape, m.dtype, [m], lambda: torch.rot90(m.t, k, [0, 1]), ("rot", m, k % 4, 0, 0))
+    return DeviceArray(torch.rot90(m.t, k, [ax[0], ax[1]]))
+
+
+def _pad_now(t, pw, mode):
+    torch = _torch()
+    if mode == "edge":
+        for d in range(t.dim()):
+            lo, hi = int(pw[d, 0]), int(pw[d, 1])
+            if lo or hi:
+                idx = torch.arange(-lo, t.shape[d] + hi, device=t.device).clamp_(0, t.shape[d] - 1)
+                t = t.index_select(d, idx)
+        return t
+    out = torch.zeros([t.shape[d] + int(pw[d, 0]) + int(pw[d, 1]) for d in range(t.dim())], dtype=t.dtype, device=t.device)
+    out[tuple(slice(int(pw[d, 0]), int(pw[d, 0]) + t.shape[d]) for d in range(t.dim()))] = t
+    return out
 
 
 @_implements(np.pad)
@@ -542,25 +811,28 @@ def _pad(array, pad_width, mode="constant", **kw):
     """edge / constant(0) padding by index selection (the call sites pad bottom / right with mode="edge", :551-553)"""
     if not isinstance(array, DeviceArray) or kw or mode not in ("edge", "constant"):
         return NotImplemented
-    torch = _torch()
-    t = array.t
     pw = np.asarray(pad_width)
+    nd = array.ndim
     if pw.ndim == 0:
-        pw = np.tile(pw, (t.dim(), 2))
+        pw = np.tile(pw, (nd, 2))
     elif pw.ndim == 1:
-        pw = np.tile(pw.reshape(1, -1), (t.dim(), 1)) if pw.size == 2 else None
-    if pw is None or pw.shape != (t.dim(), 2) or (pw < 0).any():
+        pw = np.tile(pw.reshape(1, -1), (nd, 1)) if pw.size == 2 else None
+    if pw is None or pw.shape != (nd, 2) or (pw < 0).any():
         return NotImplemented
-    if mode == "edge":
-        for d in range(t.dim()):
-            lo, hi = int(pw[d, 0]), int(pw[d, 1])
-            if lo or hi:
-                idx = torch.arange(-lo, t.shape[d] + hi, device=t.device).clamp_(0, t.shape[d] - 1)
-                t = t.index_select(d, idx)
-        return DeviceArray(t)
-    out = torch.zeros([t.shape[d] + int(pw[d, 0]) + int(pw[d, 1]) for d in range(t.dim())], dtype=t.dtype, device=t.device)
-    out[tuple(slice(int(pw[d, 0]), int(pw[d, 0]) + t.shape[d]) for d in range(t.dim()))] = t
-    return DeviceArray(out)
+    if mode == "edge" and nd == 3 and not pw[:, 0].any() and pw[2, 1] == 0:
+        # the call sites' form: [H, W, C] padded at the bottom / right only -- lazy, see LazyArray
+        if isinstance(array, LazyArray) and array.pending and array._recipe and array._recipe[0] == "rot":
+            base, k = array._recipe[1], array._recipe[2]
+        elif not (isinstance(array, LazyArray) and array.pending) and array.t.is_cuda:
+            base, k = array, 0
+        else:
+            base = None
+        if base is not None:
+            ph, pww = int(pw[0, 1]), int(pw[1, 1])
+            shape = (array.shape[0] + ph, array.shape[1] + pww, array.shape[2])
+            src = array
+            return LazyArray(shape, array.dtype, [base], lambda: _pad_now(src.t, pw, "edge"), ("rotpad", base, k, ph, pww))
+    return DeviceArray(_pad_now(array.t, pw, mode))
 
 
 @_implements(np.shape)
@@ -603,6 +875,7 @@ _STAGE = {}          # size class -> [slots, next]; a slot = [pinned tensor, its
 _STAGE_LOCK = __import__("threading").Lock()      # the rings are shared by every caller of the process
 _STAGE_MIN = 1 << 20
 _STAGE_MAX_BYTES = 256 << 20
+_STAGE_CHUNK = 4 << 20
 
 
 def _size_class(n):
@@ -639,8 +912,19 @@ def upload(a):
         ring[1] += 1
         if slot[2] is not None:
             slot[2].synchronize()
-        np.copyto(slot[1][:a.nbytes], a.reshape(-1).view(np.uint8))
-        d = slot[0][:a.nbytes].cuda(non_blocking=True).view(tdt).reshape(a.shape)
+        src = a.reshape(-1).view(np.uint8)
+        if a.nbytes >= 4 * _STAGE_CHUNK:
+            # in pieces: the DMA of piece k runs under the host copy of piece k + 1 (a 25-MB frame: 0.9 ms of np.copyto + 0.45 ms of
+            # DMA become ~1.0 ms)
+            d8 = torch.empty(a.nbytes, dtype=torch.uint8, device="cuda")
+            for lo in range(0, a.nbytes, _STAGE_CHUNK):
+                hi = min(lo + _STAGE_CHUNK, a.nbytes)
+                np.copyto(slot[1][lo:hi], src[lo:hi])
+                d8[lo:hi].copy_(slot[0][lo:hi], non_blocking=True)
+            d = d8.view(tdt).reshape(a.shape)
+        else:
+            np.copyto(slot[1][:a.nbytes], src)
+            d = slot[0][:a.nbytes].cuda(non_blocking=True).view(tdt).reshape(a.shape)
         ev = torch.cuda.Event()
         ev.record()
         slot[2] = ev

@@ -267,6 +267,25 @@ def lut_interp(img_chw, h, w, dy, dx, lut_i8, interval=4, rot=0, out_dtype=None,
     return out
 
 
+EPI_DIV, EPI_MUL, EPI_ADD, EPI_CLIP, EPI_ROUND = 0, 1, 2, 3, 4     # LERF_EPI_* of include/lerf_hip.h
+
+
+def numer_epilogue(acc_i16, interval, steps):
+    """int16 numerators (value * 2^interval) -> float32, through a program of float64 steps [(EPI_*, a, b), ...] in numpy's
+    order (lerf_numer_epilogue_f32): np.round(np.clip(pred / n + bias, 0, norm)).astype(np.float32) of the call sites"""
+    torch = _torch()
+    if acc_i16.dtype != torch.int16 or not acc_i16.is_contiguous() or len(steps) > 8:
+        raise ValueError("acc must be a contiguous int16 tensor, at most 8 steps")
+    out = torch.empty(acc_i16.shape, dtype=torch.float32, device=acc_i16.device)
+    prog = (_lib.EpiOp * max(len(steps), 1))()
+    for k, st in enumerate(steps):
+        prog[k].op, prog[k].a, prog[k].b = int(st[0]), float(st[1]) if len(st) > 1 else 0.0, float(st[2]) if len(st) > 2 else 0.0
+    with _lib.on_device(out):
+        _lib.check(_lib.lib().lerf_numer_epilogue_f32(acc_i16.data_ptr(), acc_i16.numel(), int(interval), C.addressof(prog), len(steps),
+                                                      out.data_ptr(), _lib.current_stream()), "lerf_numer_epilogue_f32")
+    return out
+
+
 # --------------------------------------------------------------------------- A2/A3
 def lut_stages(img_u8_hwc, luts):
     """uint8 [H,W,C] -> (feat uint8 [H,W,C], hq uint8 [H,W,C,oC])."""
@@ -410,7 +429,10 @@ def resize_planar(feat, hypers, geo: SrGeometry, kind="gauss", max_sigma=10.0, o
     feat = feat.contiguous().float()
     nh = {"gauss": 3, "linear": 1}.get(kind, 0)
     N, H, W = feat.shape
-    o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
+    if out == "u8_hwc":          # clip(rne(value), 0, 255) as uint8 [oH, oW, N]: the caller's last three statements in the store
+        o = torch.empty((geo.out_hw[0], geo.out_hw[1], N), dtype=torch.uint8, device=feat.device)
+    else:
+        o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
     pf = _planes_chw(feat)
     if nh:
         hypers = [h.contiguous().float() for h in hypers[:nh]]
@@ -420,7 +442,7 @@ def resize_planar(feat, hypers, geo: SrGeometry, kind="gauss", max_sigma=10.0, o
         ph, _keep = _hyper_planes(hypers, "planar", nh)
     else:
         ph = None
-    po = _planes_chw(o)
+    po = _planes_hwc(o) if out == "u8_hwc" else _planes_chw(o)
     _lib.check(_lib.lib().lerf_resize(C.byref(pf), ph, H, W, N, geo.ref(), KINDS[kind], float(max_sigma),
                                       C.byref(po), _lib.current_stream()), "lerf_resize")
     return o

@@ -24,24 +24,68 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
     dy, dx = _lib.mode_offsets(mode, 0)            # ValueError("Mode x not implemented.")
     torch = _lib.require_gpu()
     from .. import lazy
+    pad = mode_pad_dict[mode]
+    h, w, rot = int(h), int(w), int(rot)
+    if isinstance(img_in, lazy.LazyArray) and img_in.pending and img_in._recipe and img_in._recipe[0] == "rotpad_chw":
+        r = _interp_of_rotpad(torch, lazy, weight, img_in, h, w, interval, rot, mode, oC, pad)
+        if r is not None:
+            return r
     if isinstance(img_in, lazy.DeviceArray):           # a result of an earlier call, still in HBM (lazy.py)
-        img_in, lazy_out = img_in.t, True
+        src, img_in, lazy_out = img_in, img_in.t, True
     else:
-        lazy_out = False
+        src, lazy_out = None, False
     as_numpy = not isinstance(img_in, torch.Tensor)
     img = _upload_image(torch, np.asarray(img_in)) if as_numpy else img_in
     lut, planes = _device_lut(torch, weight, oC, img.device)
     if img.dtype not in (torch.uint8, torch.float32):
         img = img.to(torch.float32)                    # (float64 / integer images: exact for the 0..255 values of the contract)
-    pad = mode_pad_dict[mode]
     if img.shape[1] < h + pad or img.shape[2] < w + pad:
         raise ValueError("img_in must be padded by {} pixels for mode {}".format(pad, mode))
     # one launch: float32 / uint8 pixels in, float64 values out, already rotated back by `rot` quarter turns and divided by
-    # q (:464-469) -- the kernel stores through the strides of the rotated view (lerf_lut_interp, ABI 6)
-    out = ops.lut_interp(img, h, w, dy, dx, lut, interval, rot=int(rot), out_dtype=torch.float64, planes=planes)
+    # q (:464-469) -- the kernel stores through the strides of the rotated view (lerf_lut_interp_ex, ABI 7)
     if lazy_out or (as_numpy and lazy.enabled()):
-        return lazy.DeviceArray(out)                   # numpy-shaped, device-backed: the caller's += / clip / round stay in HBM
+        # the pass itself is deferred (lazy.LazyArray): `pred += FourSimplexInterpFaster(...)` (:555, :564) then runs it ONCE,
+        # adding into pred's planes; any other use runs it into planes of its own, as before.  The operand is a private upload
+        # or a DeviceArray (whose writes flush pending readers): what the pass reads cannot change before it runs.
+        Cn = img.shape[0]
+        oh, ow = (h, w) if rot % 2 == 0 else (w, h)
+        return _deferred(torch, lazy, (Cn * oC, oh, ow), [src] if src is not None else [],
+                         lambda out, acc: ops.lut_interp(img, h, w, dy, dx, lut, interval, rot=rot, planes=planes, out=out, accumulate=acc),
+                         interval, img.device)
+    out = ops.lut_interp(img, h, w, dy, dx, lut, interval, rot=rot, out_dtype=torch.float64, planes=planes)
     return out.cpu().numpy() if as_numpy else out
+
+
+def _deferred(torch, lazy, shape, deps, launch, interval, device):
+    """the pass as a lazy.LazyArray: make() runs it into fresh float64 planes; recipe ("interp", run, interval, device) lets
+    `pred += result` run it into the sum instead (float64 planes, or the int16 numerators lazy.py keeps while it can)"""
+    def run(out, accumulate):
+        launch(out, accumulate)
+        return True
+    return lazy.LazyArray(shape, np.float64, deps, lambda: launch(None, False), ("interp", run, int(interval), device))
+
+
+def _interp_of_rotpad(torch, lazy, weight, chw, h, w, interval, rot, mode, oC, pad):
+    """img_in = np.pad(np.rot90(base, k), ((0, p), (0, p), (0, 0)), mode="edge").transpose((2, 0, 1)), still lazy: the pass over it
+    == the pass over `base` itself with the pattern's offsets rotated k times and clamped coordinates (what the tile-fused
+    stages do, csrc/lerf_common.h mode_offsets), its result turned by k + rot quarter turns -- no rotated or padded copy exists.
+    None: not that case (the caller proceeds on the materialised array)."""
+    _, base, k, ph, pw = chw._recipe
+    Cn, Hp, Wp = chw.shape
+    if (h, w) != (Hp - ph, Wp - pw) or ph < pad or pw < pad or not 1 <= interval <= 7:
+        return None
+    bt = base.t                                          # [H, W, C]
+    if not bt.is_cuda or bt.dim() != 3 or bt.dtype not in (torch.uint8, torch.float32):
+        return None
+    dy, dx = _lib.mode_offsets(mode, k)
+    lut, planes = _device_lut(torch, weight, oC, bt.device)
+    H, W = int(bt.shape[0]), int(bt.shape[1])
+    img = bt.permute(2, 0, 1)
+    turn = (k + rot) % 4
+    oh, ow = (H, W) if turn % 2 == 0 else (W, H)
+    return _deferred(torch, lazy, (Cn * oC, oh, ow), [base],
+                     lambda out, acc: ops.lut_interp(img, H, W, dy, dx, lut, interval, rot=turn, planes=planes, out=out, accumulate=acc),
+                     interval, bt.device)
 
 
 def _upload_image(torch, a):

@@ -104,8 +104,18 @@ class Resize2dNumpy(object):
         if list(x.shape) != list(self.in_shape):
             raise ValueError("input shape {} does not match set_shape({})".format(list(x.shape), self.in_shape))
         hs = [_to_dev(h) for h in hypers]
+        from .. import lazy
+        ins = [input] + list(hypers)
+        if (lazy.enabled() or any(isinstance(a, lazy.DeviceArray) for a in ins)) and self._pad_code == 0 and kind in ("gauss", "linear"):
+            # deferred (lazy.LazyArray): the caller's `np.clip(np.round(out).transpose((1, 2, 0)), 0, 255).astype(np.uint8)`
+            # (resample/eval_lut_sr.py:663-665) then runs the resampler ONCE with uint8 HWC output (float32 production arithmetic
+            # + the float64 tie guard: the same bytes) instead of 199 MB of float64 and three more passes; any other use: float64
+            geo = self.geo
+            return lazy.LazyArray((x.shape[0], geo.out_hw[0], geo.out_hw[1]), np.float64, [a for a in ins if isinstance(a, lazy.DeviceArray)],
+                                  lambda: ops.resize_planar(x, hs, geo, kind, max_sigma, out="f64"),
+                                  ("resize", lambda: ops.resize_planar(x, hs, geo, kind, max_sigma, out="u8_hwc")))
         out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f64")
-        return _result(out, [input] + list(hypers))
+        return _result(out, ins)
 
 
 class SteeringGaussianResize2dNumpy(Resize2dNumpy):
