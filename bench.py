@@ -267,6 +267,51 @@ def recorded_traffic(cfg, S, Cn, scale, frames, input_kind, sha):
         tj.get("kernel_src_sha16"), sha), None
 
 
+def psnr_delta_block(torch, L):
+    """The second half of BASELINE.json's metric ("...; PSNR delta vs ref"): the Set5 tables of the reference's scripts.sh:33-47
+    (SR x2 / x3 / x4 by Y-PSNR with shave = scale, common/utils.py:138-151; homographic warps isc / osc by masked mPSNR,
+    :168-175) through LerfEngine.sr_many / warp_many and the device metric kernels (lerf_metric_*), beside the reference's own
+    per-image values (tests/golden/g5_set5.json, generated by importing the reference: tests/golden/gen_golden.py).  The
+    images are the reference's test data (tests/data/Set5); nothing here reads /root/reference."""
+    from PIL import Image
+    from lerf_pytorch_amd import metrics
+    data = os.path.join(ROOT, "tests", "data", "Set5")
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "g5_set5.json")))
+    names = ["baby", "bird", "butterfly", "head", "woman"]
+    t0 = time.perf_counter()
+    gts = {n: np.array(Image.open(os.path.join(data, "HR", n + ".png"))) for n in names}
+    out = {"unit": "dB", "tables": {}, "max_abs_delta_db": 0.0,
+           "published_scripts_sh": {"lerf-g": "35.71 32.02 30.15 | 33.81 27.89", "lerf-l": "34.84 30.72 29.13 | 32.90 27.13"}}
+    worst = 0.0
+    for model in ("lerf-g", "lerf-l"):
+        eng = L.LerfEngine.shipped(model)
+        jobs = [(s, n) for s in (2, 3, 4) for n in names]
+        lrs = [np.array(Image.open(os.path.join(data, "LR_bicubic/rrLR_X%.2f_%.2f" % (s, s), n + ".png"))) for s, n in jobs]
+        srs = eng.sr_many([eng._dev(a)[0] for a in lrs], [(float(s), float(s)) for s, _ in jobs])
+        row = {}
+        for s in (2, 3, 4):
+            got = [metrics.psnr_y(gts[n], o, s) for (sj, n), o in zip(jobs, srs) if sj == s]
+            want = [ref["sr"]["%s/x%d/%s" % (model, s, n)]["psnr_y"] for n in names]
+            d = max(abs(g - w) for g, w in zip(got, want))
+            worst = max(worst, d)
+            row["sr_x%d" % s] = {"psnr_y": round(float(np.mean(got)), 4), "reference": round(float(np.mean(want)), 4), "max_abs_delta": round(d, 6)}
+        for p in ("isc", "osc"):
+            lw = [np.array(Image.open(os.path.join(data, p, n + ".png"))) for n in names]
+            Ms = [np.array(ref["warp"]["%s/%s/%s" % (model, p, n)]["matrix"]) for n in names]
+            ws = eng.warp_many([eng._dev(a)[0] for a in lw], Ms, [gts[n].shape[:2] for n in names])
+            got = [metrics.mpsnr(o, gts[n], m) for n, (o, m) in zip(names, ws)]
+            want = [ref["warp"]["%s/%s/%s" % (model, p, n)]["mpsnr"] for n in names]
+            d = max(abs(g - w) for g, w in zip(got, want))
+            worst = max(worst, d)
+            row["warp_%s" % p] = {"mpsnr": round(float(np.mean(got)), 4), "reference": round(float(np.mean(want)), 4), "max_abs_delta": round(d, 6)}
+        out["tables"][model] = row
+    torch.cuda.synchronize()
+    out["max_abs_delta_db"] = round(worst, 6)
+    out["images"] = "Set5 (5 images) x {x2, x3, x4, isc, osc} x {lerf-g, lerf-l} = 50 outputs"
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    return out
+
+
 def other_config_legs(torch, L, ops, steps=20, warmup=5):
     """every BASELINE configuration on the driver's record.  Short legs beside the headline (never `value`): config 1
     (the 256 x 256 CPU-plumbing tile, product path beside one core of the C port), config 3
@@ -449,6 +494,7 @@ def parse():
                          "sites of eltr._worker (24 FourSimplexInterpFaster calls + set_shape + resize through the mirrors, host numpy in, "
                          "uint8 numpy out); classes-torch: the torch resampler twins on device tensors (training / validation shapes)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer-in / host-buffer-out legs (config 2)")
+    ap.add_argument("--no-psnr", action="store_true", help="skip the Set5 PSNR-delta-vs-reference block of the default line (config 2)")
     ap.add_argument("--unfused", action="store_true", help="config 2: time the 3-launch direct path instead")
     ap.add_argument("--scale", type=float, default=None, help="config 2: scale factor (default 2; > 4.9 takes the general kernels)")
     ap.add_argument("--channels", type=int, choices=[1, 3, 4], default=3, help="config 2: channels per pixel (1 / 4: general kernels)")
@@ -693,6 +739,11 @@ def main():
             extra["end_to_end"] = end_to_end_legs(torch, L, eng, host[0], list(scale), B_local)
         except Exception as e:                                  # a secondary leg must never cost the headline line
             extra["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if single and cfg == 2 and not args.unfused and C == 3 and not args.no_psnr:
+        try:
+            extra["psnr_delta_vs_ref_db"] = psnr_delta_block(torch, L)
+        except Exception as e:
+            extra["psnr_delta_vs_ref_db"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if single and cfg == 3:
         s2, o2, (oh2, ow2), _ = make_sr((2.0, 2.0))
         d2, _ = timed(s2, max(5, args.steps // 2), 2)
@@ -829,6 +880,9 @@ def main():
                 res["cpu_baseline_half_budget"] = cbh
             cb, cpu_out, n_cpu = cpu_baseline_sr(host, model, scale[0], scale[1], budget_s=budget, S=S)
             res["cpu_baseline"] = cb
+            # the OTHER baseline, quoted beside the port: the reference's own numpy path cannot run here (its files do not travel);
+            # it was timed on this frame size in the 8-vCPU build container (692 s per 1080p frame)
+            cb["reference_numpy_mpix_s"] = {"value": 0.0120, "unit": "Mpix/s", "where": "8-vCPU build container, single-threaded numpy, 692 s per 1080p -> 4K frame (SURVEY.md section 6)"}
             if cfg == 2 and S == 2:
                 cb["scaling"] = {"threads_1_mpix_s": res["cpu_baseline_single_thread"]["value"],
                                  "threads_%d_mpix_s" % res["cpu_baseline_half_budget"]["cores"]: res["cpu_baseline_half_budget"]["value"],

@@ -117,11 +117,20 @@ class DeviceArray(object):
     Not an `np.ndarray` subclass (`isinstance(x, np.ndarray)` is False -- INTEGRATION.md section 2)."""
     __array_priority__ = 1000.0
 
-    def __init__(self, t, base=None):
+    def __init__(self, t, base=None, u8=None):
         self.t = t
         self._np = None
         self._np_ver = -1
         self._vc = base._vc if base is not None else [0]      # version cell shared by all views of one storage
+        # provenance: (uint8 tensor, scale, storage version) with self == uint8 / scale exactly (the stage outputs: feat = an
+        # integer 0..255, hyper = numerator / 255); lets a resampler fed with them take the uint8 production kernels.  Valid only
+        # while the storage has not been written since (exact_u8()).
+        self._u8 = (u8[0], float(u8[1]), self._vc[0]) if u8 is not None else None
+
+    def exact_u8(self):
+        """(uint8 tensor of this array's shape, scale) with array == uint8 / scale exactly, or None"""
+        u = getattr(self, "_u8", None)
+        return (u[0], u[1]) if u is not None and u[2] == self._vc[0] else None
 
     # ---- ndarray surface
     shape = property(lambda self: tuple(self.t.shape))
@@ -204,7 +213,8 @@ class DeviceArray(object):
             axes = tuple(axes[0])
         if not axes or axes == (None,):
             axes = tuple(reversed(range(self.t.dim())))
-        return DeviceArray(self.t.permute(*axes), base=self)
+        u = self.exact_u8()
+        return DeviceArray(self.t.permute(*axes), base=self, u8=(u[0].permute(*axes), u[1]) if u else None)
 
     def reshape(self, *shape, **kw):
         if kw:
@@ -282,7 +292,8 @@ class DeviceArray(object):
             return self.numpy()[_host(idx)]                                     # numpy's own error for a bad index
         if r.dim() == 0 and ti[1] and not _has_ellipsis_or_none(idx):
             return self.dtype.type(r.item())                                    # a[i, j, k] is a scalar in numpy
-        return DeviceArray(r, base=self if ti[1] else None)
+        u = self.exact_u8()
+        return DeviceArray(r, base=self if ti[1] else None, u8=(u[0][ti[0]], u[1]) if u else None)
 
     def __setitem__(self, idx, value):
         torch = _torch()
@@ -379,9 +390,15 @@ class DeviceArray(object):
             return self
         a = self.t.to(_np_to_torch_dtype(rd))
         try:
-            return DeviceArray(op(o, a) if reflected else op(a, o))
+            res = DeviceArray(op(o, a) if reflected else op(a, o))
         except RuntimeError:
             return self._host_bin(other, ufunc, reflected, inplace)
+        if ufunc is np.true_divide and not reflected and isinstance(other, (int, float)) and not isinstance(other, bool) and other == 255 \
+                and rd == np.float32:
+            u = self.exact_u8()                                                 # hyper = numerators / 255 (:628)
+            if u is not None and u[1] == 1.0:
+                res._u8 = (u[0], 255.0, res._vc[0])
+        return res
 
     def _host_bin(self, other, ufunc, reflected, inplace):
         if inplace:
@@ -662,7 +679,12 @@ class LazyArray(DeviceArray):
             kind, acc, interval = self._recipe[0], self._recipe[1], self._recipe[2]
             steps = self._recipe[3] if kind == "expr" else []
             code = {"div": ops.EPI_DIV, "mul": ops.EPI_MUL, "add": ops.EPI_ADD, "clip": ops.EPI_CLIP, "round": ops.EPI_ROUND}
-            return DeviceArray(ops.numer_epilogue(acc, interval, [(code[st[0]],) + tuple(st[1:]) for st in steps]))
+            f = ops.numer_epilogue(acc, interval, [(code[st[0]],) + tuple(st[1:]) for st in steps])
+            kinds = [st[0] for st in steps[-2:]]
+            clip = [st for st in steps[-2:] if st[0] == "clip"]
+            if sorted(kinds) == ["clip", "round"] and clip[0][1] >= 0 and clip[0][2] <= 255:
+                return DeviceArray(f, u8=(f.to(_torch().uint8), 1.0))           # integers 0..255: the stage's uint8 output, exactly
+            return DeviceArray(f)
         return DeviceArray.astype(self, dtype, *a, **k)
 
     def _fold_into_add(self, target, reflected, inplace):

@@ -429,10 +429,7 @@ def resize_planar(feat, hypers, geo: SrGeometry, kind="gauss", max_sigma=10.0, o
     feat = feat.contiguous().float()
     nh = {"gauss": 3, "linear": 1}.get(kind, 0)
     N, H, W = feat.shape
-    if out == "u8_hwc":          # clip(rne(value), 0, 255) as uint8 [oH, oW, N]: the caller's last three statements in the store
-        o = torch.empty((geo.out_hw[0], geo.out_hw[1], N), dtype=torch.uint8, device=feat.device)
-    else:
-        o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
+    o = torch.empty((N, geo.out_hw[0], geo.out_hw[1]), dtype=_out_dtype(out), device=feat.device)
     pf = _planes_chw(feat)
     if nh:
         hypers = [h.contiguous().float() for h in hypers[:nh]]
@@ -442,9 +439,28 @@ def resize_planar(feat, hypers, geo: SrGeometry, kind="gauss", max_sigma=10.0, o
         ph, _keep = _hyper_planes(hypers, "planar", nh)
     else:
         ph = None
-    po = _planes_hwc(o) if out == "u8_hwc" else _planes_chw(o)
+    po = _planes_chw(o)
     _lib.check(_lib.lib().lerf_resize(C.byref(pf), ph, H, W, N, geo.ref(), KINDS[kind], float(max_sigma),
                                       C.byref(po), _lib.current_stream()), "lerf_resize")
+    return o
+
+
+def resize_planar_u8(feat_u8, hq_u8, geo: SrGeometry, kind="gauss", max_sigma=10.0):
+    """stage 3 on planar uint8 maps: feat [N,H,W] (any strides), hq = list of uint8 numerator maps [N,H,W] with identical
+    strides (hyper = hq / 255) -> uint8 [oH,oW,N] = clip(rne(value), 0, 255): the production arithmetic of the fused path"""
+    torch = _torch()
+    nh = {"gauss": 3, "linear": 1}[kind]
+    N, H, W = feat_u8.shape
+    hq = [h.contiguous() for h in hq_u8[:nh]]
+    if feat_u8.dtype != torch.uint8 or any(h.dtype != torch.uint8 or h.shape != feat_u8.shape for h in hq):
+        raise ValueError("uint8 maps of the input's shape")
+    o = torch.empty((geo.out_hw[0], geo.out_hw[1], N), dtype=torch.uint8, device=feat_u8.device)
+    pf = _planes_chw(feat_u8)
+    ph, _keep = _hyper_planes(hq, "planar", nh)
+    po = _planes_hwc(o)
+    with _lib.on_device(o):
+        _lib.check(_lib.lib().lerf_resize(C.byref(pf), ph, H, W, N, geo.ref(), KINDS[kind], float(max_sigma),
+                                          C.byref(po), _lib.current_stream()), "lerf_resize")
     return o
 
 

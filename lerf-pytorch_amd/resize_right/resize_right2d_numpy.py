@@ -106,14 +106,18 @@ class Resize2dNumpy(object):
         hs = [_to_dev(h) for h in hypers]
         from .. import lazy
         ins = [input] + list(hypers)
-        if (lazy.enabled() or any(isinstance(a, lazy.DeviceArray) for a in ins)) and self._pad_code == 0 and kind in ("gauss", "linear"):
-            # deferred (lazy.LazyArray): the caller's `np.clip(np.round(out).transpose((1, 2, 0)), 0, 255).astype(np.uint8)`
-            # (resample/eval_lut_sr.py:663-665) then runs the resampler ONCE with uint8 HWC output (float32 production arithmetic
-            # + the float64 tie guard: the same bytes) instead of 199 MB of float64 and three more passes; any other use: float64
-            geo = self.geo
+        tags = [a.exact_u8() if isinstance(a, lazy.DeviceArray) else None for a in ins]
+        if self._pad_code == 0 and kind in ("gauss", "linear") and all(t is not None for t in tags) and tags[0][1] == 1.0 \
+                and all(t[1] == 255.0 for t in tags[1:]):
+            # every operand is a stage output known exactly as uint8 (feat) / uint8 numerators over 255 (hyper): deferred
+            # (lazy.LazyArray) -- the caller's `np.clip(np.round(out).transpose((1, 2, 0)), 0, 255).astype(np.uint8)`
+            # (resample/eval_lut_sr.py:663-665) then runs the resampler ONCE on the uint8 maps with uint8 HWC output (float32
+            # production arithmetic + the float64 tie guard: the same bytes) instead of 199 MB of float64 and three more passes
+            # over them; any other use of the result: the float64 kernel, as before
+            geo, f8, h8 = self.geo, tags[0][0], [t[0] for t in tags[1:]]
             return lazy.LazyArray((x.shape[0], geo.out_hw[0], geo.out_hw[1]), np.float64, [a for a in ins if isinstance(a, lazy.DeviceArray)],
                                   lambda: ops.resize_planar(x, hs, geo, kind, max_sigma, out="f64"),
-                                  ("resize", lambda: ops.resize_planar(x, hs, geo, kind, max_sigma, out="u8_hwc")))
+                                  ("resize", lambda: ops.resize_planar_u8(f8, h8, geo, kind, max_sigma)))
         out = ops.resize_planar(x, hs, self.geo, kind, max_sigma, out="f64")
         return _result(out, ins)
 
