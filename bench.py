@@ -47,9 +47,10 @@ M_OSC = [[4.1, 0.4, 30.0], [0.5, 3.8, 25.0], [8e-5, 1.2e-4, 1.0]]
 
 
 # --------------------------------------------------------------------------------------------- synthetic inputs
-def synth_frames(kind, n, seed, H, W):
+def synth_frames(kind, n, seed, H, W, channels=None):
     """SURVEY.md 8(d) inputs.  'noise': uniform uint8 (worst case for LUT locality);
-    'natural': low-pass field (box blur radius 8, 3 passes) + 5 % uniform noise."""
+    'natural': low-pass field (box blur radius 8, 3 passes) + 5 % uniform noise.  channels: default = the run's (--channels)."""
+    C = globals()["C"] if channels is None else int(channels)
     rng = np.random.default_rng(seed)
     if kind == "noise":
         return rng.integers(0, 256, (n, H, W, C), dtype=np.uint8)
@@ -250,8 +251,8 @@ def end_to_end_legs(torch, L, eng, frame_u8, scale, B):
 
 
 def recorded_traffic(cfg, S, Cn, scale, frames, input_kind, sha):
-    """(bytes per launch, where from) of profiles/hbm_traffic.json for a workload, only when it was measured on exactly these
-    kernel sources; (None, why not) otherwise"""
+    """(bytes per launch, where from, the recorded entry) of profiles/hbm_traffic.json for a workload, only when it was measured on
+    exactly these kernel sources; (None, why not, None) otherwise"""
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     key = traffic_key(cfg, S, Cn, scale, frames, input_kind)
     try:
@@ -318,8 +319,6 @@ def other_config_legs(torch, L, ops, steps=20, warmup=5):
     (LeRF-L x1.5/x2.0), config 4 (LeRF-G warp, isc matrix), config 5 (4K -> 8K, 4 frames on one GPU) and config 2 at S = 4 --
     `warmup` + `steps` steps each, HIP events around every step, the product output of the last step compared with the C port of
     the oracle on one frame (bytes), and the workload's own recorded HBM traffic.  A failing leg reports its error and nothing else."""
-    global C
-    C = 3
     sha = kernel_source_sha()
     from oracle import c_oracle
     c_oracle.set_threads(host_cpu_budget()[0])
@@ -366,10 +365,10 @@ def other_config_legs(torch, L, ops, steps=20, warmup=5):
             eng = L.LerfEngine.shipped(model, support=S, max_sigma=10.0)
             kind = "linear" if model == "lerf-l" else "gauss"
             if input_kind == "natural":
-                two = synth_frames("natural", 2, 1000, H, W)
+                two = synth_frames("natural", 2, 1000, H, W, channels=3)
                 host = np.ascontiguousarray(np.tile(two, (B // 2 + 1, 1, 1, 1))[:B])
             else:
-                host = synth_frames("noise", B, 1000, H, W)
+                host = synth_frames("noise", B, 1000, H, W, channels=3)
             frames = torch.from_numpy(host).cuda()
             ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, 3, B)), dtype=torch.uint8, device="cuda")
             if cfg == 4:

@@ -15,4 +15,4 @@ for g, nm in ((geo.with_flags(_lib.GEO_NO_PERSIST), "per-tile kernel"), (geo, "p
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(30): ops.sr_fused_u8(x, eng.luts, g, "gauss", 10.0, out=a)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 30
-    print("%s %s: %.3f ms per step" % (os.environ.get("LERF_HIP_LIB", "default"), nm, dt * 1e3))
+    print("%s %s: %.3f ms per step" % (os.path.basename(_lib.LIB_PATH), nm, dt * 1e3))

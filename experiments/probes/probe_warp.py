@@ -21,4 +21,4 @@ def T(f, n=20):
     return a.elapsed_time(b) / n
 ts = T(lambda: ops.stages_packed(x, eng.luts, workspace=ws))
 tw = T(lambda: ops.warp_packed(packed, geo, "gauss", 10.0, out=out))
-print("%s: stages (s1 + EMIT) %.3f ms, packed warp %.3f ms, step %.3f ms = %.1f Gpix/s" % (os.path.basename(os.environ.get("LERF_HIP_LIB", "product")), ts, tw, ts + tw, 8 * 2160 * 3840 / (ts + tw) / 1e6))
+print("%s: stages (s1 + EMIT) %.3f ms, packed warp %.3f ms, step %.3f ms = %.1f Gpix/s" % (os.path.basename(_lib.LIB_PATH), ts, tw, ts + tw, 8 * 2160 * 3840 / (ts + tw) / 1e6))

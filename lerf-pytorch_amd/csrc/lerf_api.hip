@@ -20,21 +20,6 @@ inline int check_launch() { return launch_status(); }
 
 inline bool plane_ok(const lerf_plane_t* p) { return p && p->ptr; }
 
-// float32 rounding of a float64 distance that keeps its class for the
-// amplified-linear kernel's hard masks (resize_right2d_numpy.py:233-235)
-inline int dclass(double x) { return (x >= -1.0 && x < 0.0) ? 1 : ((x >= 0.0 && x <= 1.0) ? 2 : 0); }
-inline int fclass(float x) { return (x >= -1.0f && x < 0.0f) ? 1 : ((x >= 0.0f && x <= 1.0f) ? 2 : 0); }
-
-float class_preserving_f32(double d) {
-    float f = (float)d;
-    int want = dclass(d);
-    if (fclass(f) == want) return f;
-    float up = nextafterf(f, INFINITY), dn = nextafterf(f, -INFINITY);
-    if (fclass(up) == want) return up;
-    if (fclass(dn) == want) return dn;
-    return f;
-}
-
 int build_stage_luts(const lerf_luts_t* L, int stage, StageLuts* out) {
     int n = stage == 1 ? L->n_modes1 : L->n_modes2;
     if (n < 1 || n > LERF_MAX_MODES) return LERF_EINVAL;
@@ -83,95 +68,20 @@ int lerf_mode_offsets(char mode, int rot, int8_t dy[4], int8_t dx[4]) {
     return mode_offsets(mode, rot, dy, dx) ? LERF_OK : LERF_EINVAL;
 }
 
-int lerf_out_size(int n_in, double scale) { return (int)ceil(scale * (double)n_in); }
+int lerf_out_size(int n_in, double scale) { return host::out_size(n_in, scale); }
 
-int lerf_sr_axis_tables(int n_in, int n_out, double scale, int S, int32_t* left, double* dis64, float* dis32,
-                        int32_t* pads) {
-#pragma clang fp contract(off)
-    if (n_in < 1 || n_out < 1 || !(scale > 0.0) || S < 1 || S > LERF_MAX_SUPPORT || !left || !dis64) return LERF_EINVAL;
-    // g = i/s + (n_in-1)/2 - (n_out-1)/(2s)            resize_right2d_numpy.py:70-79
-    const double a = (double)(n_in - 1) / 2;
-    const double b = (double)(n_out - 1) / (2 * scale);
-    int pad_lo = 0;
-    for (int i = 0; i < n_out; ++i) {
-        double g = (double)i / scale + a - b;
-        int l = left_boundary(g, S);                    // :85-90
-        if (i == 0) pad_lo = -l;                        // :101
-        left[i] = l;
-        double gp = g + (double)pad_lo;                 // :103
-        for (int k = 0; k < S; ++k) {
-            double d = gp - (double)(l + pad_lo + k);   // :131-134
-            dis64[i * S + k] = d;
-            if (dis32) dis32[i * S + k] = class_preserving_f32(d);
-        }
-    }
-    if (pads) {
-        pads[0] = pad_lo;
-        pads[1] = left[n_out - 1] + S - 1 - n_in + 1;   // :101
-    }
-    return LERF_OK;
+int lerf_sr_axis_tables(int n_in, int n_out, double scale, int S, int32_t* left, double* dis64, float* dis32, int32_t* pads) {
+    return host::sr_axis_tables(n_in, n_out, scale, S, left, dis64, dis32, pads);
 }
 
 int lerf_sr_axis_tables_f32(int n_in, int n_out, double scale, int S, int32_t* left, float* dis32, int32_t* pads) {
-#pragma clang fp contract(off)
-    if (n_in < 1 || n_out < 1 || !(scale > 0.0) || S < 1 || S > LERF_MAX_SUPPORT || !left || !dis32) return LERF_EINVAL;
-    // Resize2dTorch.get_projected_grid2d / get_field_of_view2d / cal_pad_sz / get_distance
-    // (resize_right/resize_right2d_torch.py:48-103): every tensor op is float32, the python scalars are float64
-    // expressions rounded to float32 when they meet the tensor.
-    const float sf = (float)scale;
-    const float a = (float)((double)(n_in - 1) / 2);
-    const float b = (float)((double)(n_out - 1) / (2 * scale));
-    const float half = (float)((double)S / 2);
-    int pad_lo = 0;
-    for (int i = 0; i < n_out; ++i) {
-        float g = (float)i / sf;                        // :60
-        g = g + a;
-        g = g - b;
-        float t = g - half;                             // :69
-        t = t - kEps32;
-        const int l = (int)ceilf(t);
-        if (i == 0) pad_lo = -l;                        // :81
-        left[i] = l;
-        const float gp = g + (float)pad_lo;             // :83
-        for (int k = 0; k < S; ++k) dis32[i * S + k] = gp - (float)(l + pad_lo + k);      // :98
-    }
-    if (pads) {
-        pads[0] = pad_lo;
-        pads[1] = left[n_out - 1] + S - 1 - n_in + 1;   // :81
-    }
-    return LERF_OK;
+    return host::sr_axis_tables_f32(n_in, n_out, scale, S, left, dis32, pads);
 }
 
-int lerf_invert3x3(const double m[9], double out[9]) {
-    if (!m || !out) return LERF_EINVAL;
-    double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
-    double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    if (det == 0.0) return LERF_EINVAL;
-    out[0] = c00 / det;
-    out[1] = (m[2] * m[7] - m[1] * m[8]) / det;
-    out[2] = (m[1] * m[5] - m[2] * m[4]) / det;
-    out[3] = c01 / det;
-    out[4] = (m[0] * m[8] - m[2] * m[6]) / det;
-    out[5] = (m[2] * m[3] - m[0] * m[5]) / det;
-    out[6] = c02 / det;
-    out[7] = (m[1] * m[6] - m[0] * m[7]) / det;
-    out[8] = (m[0] * m[4] - m[1] * m[3]) / det;
-    return LERF_OK;
-}
+int lerf_invert3x3(const double m[9], double out[9]) { return host::invert3x3(m, out); }
 
 int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_w, int S, int32_t pads[4]) {
-    if (!minv || !pads || in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1 || S < 1) return LERF_EINVAL;
-    double gr, gc;
-    project_point(minv, 0, 0, in_h, in_w, &gr, &gc);
-    int l0r = left_boundary(gr, S), l0c = left_boundary(gc, S);
-    project_point(minv, out_h - 1, out_w - 1, in_h, in_w, &gr, &gc);
-    int l1r = left_boundary(gr, S), l1c = left_boundary(gc, S);
-    // calc_pad_sz: (max(-fov[0,0],0), max(fov[-1,-1]-in+1,0)), fov[-1,-1] = left + S-1   (:363-366)
-    pads[0] = -l0r > 0 ? -l0r : 0;
-    pads[1] = (l1r + S - 1 - in_h + 1) > 0 ? (l1r + S - 1 - in_h + 1) : 0;
-    pads[2] = -l0c > 0 ? -l0c : 0;
-    pads[3] = (l1c + S - 1 - in_w + 1) > 0 ? (l1c + S - 1 - in_w + 1) : 0;
-    return LERF_OK;
+    return host::warp_pads(minv, in_h, in_w, out_h, out_w, S, pads);
 }
 
 int lerf_lut_interp_i16(const lerf_plane_t* img, int img_h, int img_w, int C, int h, int w, const int8_t dy[4],

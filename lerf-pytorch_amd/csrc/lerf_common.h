@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include "lerf_hip.h"
+#include "lerf_host_geometry.h"
 
 namespace lerf {
 
@@ -16,34 +17,6 @@ constexpr int kStrideA = kL * kL * kL; // 4913: first sampled pixel = slowest LU
 constexpr int kStrideB = kL * kL;      // 289
 constexpr int kStrideC = kL;           // 17
 constexpr int kStrideD = 1;
-constexpr float kEps32 = 1.1920928955078125e-07f;  // np.finfo(np.float32).eps
-
-// Sampling patterns of resample/eval_lut_sr.py:30-81, (dy, dx) of pixels a,b,c,d.
-__host__ __device__ inline bool mode_pattern(char mode, int8_t dy[4], int8_t dx[4]) {
-    dy[0] = 0; dx[0] = 0;
-    switch (mode) {
-        case 's': dy[1] = 0; dx[1] = 1; dy[2] = 1; dx[2] = 0; dy[3] = 1; dx[3] = 1; return true;
-        case 'd': dy[1] = 0; dx[1] = 2; dy[2] = 2; dx[2] = 0; dy[3] = 2; dx[3] = 2; return true;
-        case 'y': dy[1] = 1; dx[1] = 1; dy[2] = 1; dx[2] = 2; dy[3] = 2; dx[3] = 1; return true;
-        case 'c': dy[1] = 0; dx[1] = 1; dy[2] = 0; dx[2] = 2; dy[3] = 0; dx[3] = 3; return true;
-        case 't': dy[1] = 1; dx[1] = 1; dy[2] = 2; dx[2] = 2; dy[3] = 3; dx[3] = 3; return true;
-        default: return false;
-    }
-}
-
-// np.rot90(img, r) + bottom/right edge pad + pattern + rot90 back
-// == offsets rotated r times by (dy,dx)->(dx,-dy) with clamped coordinates.
-__host__ __device__ inline bool mode_offsets(char mode, int rot, int8_t dy[4], int8_t dx[4]) {
-    if (!mode_pattern(mode, dy, dx)) return false;
-    rot &= 3;
-    for (int k = 0; k < 4; ++k)
-        for (int r = 0; r < rot; ++r) {
-            int8_t t = dy[k];
-            dy[k] = dx[k];
-            dx[k] = (int8_t)(-t);
-        }
-    return true;
-}
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8; an affinity, not a guarantee -- nothing
 // depends on it but speed).  xcd_contiguous() hands every XCD a CONTIGUOUS eighth of a launch's block sequence instead of
@@ -158,28 +131,6 @@ __host__ __device__ inline int pad_index(int i, int n, int mode, bool* zero) {
     if (mode == 4) return ((i % n) + n) % n;                          // wrap / circular
     *zero = true;                                                     // constant (0)
     return i < 0 ? 0 : n - 1;
-}
-
-// Homography projection of output pixel (row i, col j) in float64, operation
-// order of resize_right/resize_right2d_numpy.py:321-339 (no FMA contraction).
-__host__ __device__ inline void project_point(const double* m, int i, int j, int H, int W, double* gr, double* gc) {
-#pragma clang fp contract(off)
-    double x = (double)j, y = (double)i;
-    double X = m[0] * x + m[1] * y + m[2];
-    double Y = m[3] * x + m[4] * y + m[5];
-    double Wh = m[6] * x + m[7] * y + m[8];
-    X = X / Wh;
-    Y = Y / Wh;
-    double r = Y, c = X;
-    r = r < 0.0 ? 0.0 : (r > (double)H ? (double)H : r);
-    c = c < 0.0 ? 0.0 : (c > (double)W ? (double)W : c);
-    *gr = r;
-    *gc = c;
-}
-
-__host__ __device__ inline int left_boundary(double g, int S) {
-#pragma clang fp contract(off)
-    return (int)ceil(g - (double)S / 2 - (double)kEps32);
 }
 
 }  // namespace lerf

@@ -38,7 +38,9 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
     img = _upload_image(torch, np.asarray(img_in)) if as_numpy else img_in
     lut, planes = _device_lut(torch, weight, oC, img.device)
     if img.dtype not in (torch.uint8, torch.float32):
-        img = img.to(torch.float32)                    # (float64 / integer images: exact for the 0..255 values of the contract)
+        # float64 images are rounded and clipped in float64 first (a value within float32's epsilon of x.5 must not round twice);
+        # integer images are exact in float32 for the 0..255 values of the contract
+        img = (img.round().clamp(0, 255) if img.dtype == torch.float64 else img).to(torch.float32)
     if img.shape[1] < h + pad or img.shape[2] < w + pad:
         raise ValueError("img_in must be padded by {} pixels for mode {}".format(pad, mode))
     # one launch: float32 / uint8 pixels in, float64 values out, already rotated back by `rot` quarter turns and divided by

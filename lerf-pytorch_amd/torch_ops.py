@@ -24,6 +24,10 @@ from . import _lib
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblerf_torch.so")
 if not os.path.exists(LIB_PATH):
     raise _lib.LerfError("liblerf_torch.so not found at %s -- build it with `python __graft_entry__.py`" % LIB_PATH)
+if os.path.abspath(_lib.LIB_PATH) != os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblerf_hip.so"):
+    # liblerf_torch.so links against the product liblerf_hip.so next to it: with a variant build selected (_lib.use_library)
+    # the process would hold BOTH builds and the ops would silently run the product kernels
+    raise _lib.LerfError("torch_ops: a variant library is selected (%s); the dispatcher ops exist for the product build only" % _lib.LIB_PATH)
 _lib.lib()                                   # liblerf_hip.so first (the op library links against it)
 torch.ops.load_library(LIB_PATH)
 

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "liblerf_oracle.so")
+LIB = os.environ.get("LERF_ORACLE_LIB") or os.path.join(_HERE, "liblerf_oracle.so")     # (the sanitizer build: oracle/Makefile `asan`)
 _lib = None
 
 
