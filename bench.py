@@ -74,9 +74,9 @@ def synth_frames(kind, n, seed, H, W, channels=None):
     return out
 
 
-def traffic_key(cfg, S, C, scale, frames, input_kind):
+def traffic_key(cfg, S, C, scale, frames, input_kind, variant=""):
     """key of a workload in profiles/hbm_traffic.json (tools/summarize_profile.py writes it, bench.py looks it up)"""
-    return "config%d_S%d_C%d_x%gx%g_f%d_%s" % (cfg, S, C, scale[0], scale[1], frames, input_kind)
+    return "config%d_S%d_C%d_x%gx%g_f%d_%s%s" % (cfg, S, C, scale[0], scale[1], frames, input_kind, ("_" + variant) if variant else "")
 
 
 def kernel_source_sha():
@@ -250,11 +250,11 @@ def end_to_end_legs(torch, L, eng, frame_u8, scale, B):
     return out
 
 
-def recorded_traffic(cfg, S, Cn, scale, frames, input_kind, sha):
+def recorded_traffic(cfg, S, Cn, scale, frames, input_kind, sha, variant=""):
     """(bytes per launch, where from, the recorded entry) of profiles/hbm_traffic.json for a workload, only when it was measured on
     exactly these kernel sources; (None, why not, None) otherwise"""
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    key = traffic_key(cfg, S, Cn, scale, frames, input_kind)
+    key = traffic_key(cfg, S, Cn, scale, frames, input_kind, variant)
     try:
         tj = json.load(open(tfile)).get("entries", {}).get(key)
     except Exception as e:
@@ -493,6 +493,7 @@ def parse():
                          "sites of eltr._worker (24 FourSimplexInterpFaster calls + set_shape + resize through the mirrors, host numpy in, "
                          "uint8 numpy out); classes-torch: the torch resampler twins on device tensors (training / validation shapes)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer-in / host-buffer-out legs (config 2)")
+    ap.add_argument("--warp-fused", action="store_true", help="config 4: the tile-fused warp (lerf_warp_fused_u8: no packed stage outputs in HBM) instead of the three-launch path")
     ap.add_argument("--no-psnr", action="store_true", help="skip the Set5 PSNR-delta-vs-reference block of the default line (config 2)")
     ap.add_argument("--unfused", action="store_true", help="config 2: time the 3-launch direct path instead")
     ap.add_argument("--scale", type=float, default=None, help="config 2: scale factor (default 2; > 4.9 takes the general kernels)")
@@ -652,7 +653,14 @@ def main():
         outs = torch.empty((B_local, out_hw[0], out_hw[1], C), dtype=torch.uint8, device="cuda")
         ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(H, W, C, B_local)), dtype=torch.uint8, device="cuda")
 
+        fused = args.warp_fused and ops.warp_fused_supported(frames, eng.luts, geo, kind, ms)
+        if fused:
+            geo.tile_boxes(frames.device)                                          # (host pass over the output, once per homography)
+
         def step(x=frames, o=outs):
+            if fused:
+                ops.warp_fused_u8(x, eng.luts, geo, kind, ms, out=o, workspace=ws)   # s1_kernel + stage 2 / warp per source tile
+                return
             packed = ops.stages_packed(x, eng.luts, workspace=ws)                  # one launch pair for the batch
             ops.warp_packed(packed, geo, kind, ms, out=o)                          # one launch for the batch (shared homography)
         return step, outs, out_hw, frames
@@ -772,7 +780,7 @@ def main():
     traffic, tsrc, binding = None, None, None
     sha = kernel_source_sha()
     if not args.unfused and world == 1:
-        traffic, tsrc, tj = recorded_traffic(cfg, S, C, scale, B_local, input_kind, sha)
+        traffic, tsrc, tj = recorded_traffic(cfg, S, C, scale, B_local, input_kind, sha, "warpfused" if (cfg == 4 and args.warp_fused) else "")
         if tj is not None:
             binding = {k: tj[k] for k in ("valu_instr_per_cu_cycle", "valu_busy", "lds_array_busy", "lds_bank_conflict_share",
                                           "l2_hit_rate", "kernel_trace_avg_us") if k in tj}
@@ -800,7 +808,8 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
         "vs_baseline": None, "dtype": "i32+f32 (u8 io)", "data": "synthetic",
         "config": {"workload": names[cfg][1], "baseline_config": cfg, "frames_per_step_per_gpu": B_local, "input": input_kind,
-                   "path": "unfused-3-launch" if args.unfused else ("stages_packed + warp_packed" if cfg == 4 else "sr_fused_u8"),
+                   "path": "unfused-3-launch" if args.unfused else (("warp_fused_u8 (tile-fused: s1_kernel + stage 2 / warp per source tile)" if args.warp_fused
+                                                                     else "stages_packed + warp_packed") if cfg == 4 else "sr_fused_u8"),
                    "mode": mode if strips else "frames", "parallelism": par, "ranks_reported_by_rccl": rccl_ranks,
                    "backend": ("gloo (ranks share one GPU: test hook, not a measurement)" if share_gpu else ("nccl" if world > 1 else None)),
                    "channels": C, "scale": list(scale),

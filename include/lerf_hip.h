@@ -302,6 +302,25 @@ int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* 
 int lerf_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, int W, int C, const lerf_warp_geo_t* geo,
                      int kind, double max_sigma, const lerf_mplane_t* out, int64_t out_sn, void* stream);
 
+/* ABI 7.  The whole warp path of the harness (resample/eval_lut_warp.py:100-222: stage 1, stage 2, SteeringGaussianWarp2dNumpy /
+ * AmplifiedLinearWarp2dNumpy.warp, resize_right/resize_right2d_numpy.py:516-636) for `n` RGB frames that share one homography,
+ * TILE-FUSED: stage 1 runs once per pixel into the workspace (as in lerf_sr_fused_u8); the second launch runs stage 2 per 64 x 64
+ * source tile and evaluates, from the tile's packed stage outputs in LDS, the output pixels that tile OWNS -- those whose 2 x 2
+ * support (clamped into the frame) has its last tap row / column inside the tile; pixels projected outside the frame are clipped
+ * onto its border like the reference clips its grid (:338-339) and belong to the border tiles.  No packed maps travel through
+ * HBM (lerf_stages_packed_u8 + lerf_warp_packed write and re-read 12 bytes per source pixel); same bytes as that path.
+ *   lerf_warp_tile_boxes   host: boxes[t] = {i0, i1, j0, j1}, the output rows x columns that bound what tile t (row-major,
+ *                          ceil(H / 64) x ceil(W / 64) tiles) owns; one pass over the output per homography.  The caller uploads
+ *                          them (int32 [tiles][4]) and passes the device pointer as `tile_boxes`.
+ *   workspace              device scratch of at least lerf_sr_fused_workspace_bytes(H, W, C, n) bytes (required).
+ * RGB frames, S = 2, the shipped pattern set "sct" / "sct", constant padding, max_sigma <= 13, out_h * out_w < 2^26:
+ * lerf_warp_fused_supported says so; everything else: lerf_stages_packed_u8 + lerf_warp_packed. */
+int lerf_warp_tile_boxes(const lerf_warp_geo_t* geo, int H, int W, int32_t* boxes);
+int lerf_warp_fused_supported(int C, const lerf_luts_t* luts, const lerf_warp_geo_t* geo, int H, int W, int kind, double max_sigma);
+int lerf_warp_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts, const lerf_warp_geo_t* geo,
+                       const int32_t* tile_boxes, int kind, double max_sigma, uint8_t* out, int64_t out_sn, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* Whole SR path of eltr._worker (resample/eval_lut_sr.py:541-665) for a batch of `n` frames (batch strides
  * in_sn / out_sn in elements): uint8 HWC in -> uint8 HWC out.
  * workspace != NULL (`workspace_bytes` >= lerf_sr_fused_workspace_bytes(H, W, C, n) bytes of device memory, LERF_EINVAL

@@ -45,6 +45,7 @@ EXPORTS = [
     "lerf_resize", "lerf_warp", "lerf_sr_fused_workspace_bytes", "lerf_sr_fused_supported", "lerf_sr_fused_u8",
     "lerf_sr_ragged_workspace_bytes", "lerf_sr_fused_ragged_u8", "lerf_stages_ragged_workspace_bytes", "lerf_stages_packed_ragged_u8",
     "lerf_stages_packed_u8", "lerf_unpack_stages", "lerf_warp_packed", "lerf_rect_copy_u8",
+    "lerf_warp_tile_boxes", "lerf_warp_fused_supported", "lerf_warp_fused_u8",
     "lerf_metric_y_sse_u8", "lerf_metric_ssim_y_u8", "lerf_metric_masked_sse_u8",
     "lerf_swf2lut_interp_f32", "lerf_swf2lut_interp_bwd_f32", "lerf_resize_bwd_f32",
     "lerf_srnet_weight_floats", "lerf_srnet_to_lut", "lerf_ubench_lds_gather",
@@ -162,6 +163,10 @@ def lib():
     L.lerf_lut_interp_ex.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.c_int, C.c_void_p]
     L.lerf_numer_epilogue_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lerf_warp_tile_boxes.argtypes = [C.POINTER(WarpGeo), C.c_int, C.c_int, C.c_void_p]
+    L.lerf_warp_fused_supported.argtypes = [C.c_int, C.POINTER(Luts), C.POINTER(WarpGeo), C.c_int, C.c_int, C.c_int, C.c_double]
+    L.lerf_warp_fused_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Luts), C.POINTER(WarpGeo), C.c_void_p,
+                                     C.c_int, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     L.lerf_fused_lutpack_bytes.restype = C.c_size_t
     L.lerf_fused_lutpack_bytes.argtypes = [C.POINTER(Luts)]
     L.lerf_fused_lutpack_build.argtypes = [C.POINTER(Luts), C.c_void_p, C.c_void_p]

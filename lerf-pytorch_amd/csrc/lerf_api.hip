@@ -252,6 +252,43 @@ int lerf_stages_packed_ragged_u8(const lerf_stage_item_t* items, int n, int C, c
     return check_launch();
 }
 
+int lerf_warp_tile_boxes(const lerf_warp_geo_t* geo, int H, int W, int32_t* boxes) {
+    if (!geo || geo->S != 2) return LERF_EINVAL;
+    return host::warp_tile_boxes(geo->minv, geo->pad_r_lo, geo->pad_c_lo, H, W, geo->out_h, geo->out_w, 64, boxes);
+}
+
+static void warp_fused_args(FusedArgs& f, WarpGeo& wg, int n, int H, int W, int C, const lerf_luts_t* luts, const lerf_warp_geo_t* geo, int kind,
+                            double max_sigma) {
+    wg.S = geo->S; wg.oH = geo->out_h; wg.oW = geo->out_w;
+    memcpy(wg.minv, geo->minv, sizeof(wg.minv));
+    wg.pad_r_lo = geo->pad_r_lo; wg.pad_r_hi = geo->pad_r_hi; wg.pad_c_lo = geo->pad_c_lo; wg.pad_c_hi = geo->pad_c_hi;
+    wg.pad_mode = geo->pad_mode;
+    f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts; f.S = geo->S; f.oH = geo->out_h; f.oW = geo->out_w;
+    f.kind = kind; f.max_sigma = (float)max_sigma; f.wgeo = &wg;
+}
+
+int lerf_warp_fused_supported(int C, const lerf_luts_t* luts, const lerf_warp_geo_t* geo, int H, int W, int kind, double max_sigma) {
+    if (!luts || !geo || H < 1 || W < 1) return 0;
+    FusedArgs f{};
+    WarpGeo wg{};
+    warp_fused_args(f, wg, 1, H, W, C, luts, geo, kind, max_sigma);
+    return warp_fused_supported(f) ? 1 : 0;
+}
+
+int lerf_warp_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, int C, const lerf_luts_t* luts, const lerf_warp_geo_t* geo,
+                       const int32_t* tile_boxes, int kind, double max_sigma, uint8_t* out, int64_t out_sn, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!img || !luts || !geo || !tile_boxes || !out || !workspace || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
+    if (workspace_bytes < lerf_sr_fused_workspace_bytes(H, W, C, n)) return LERF_EINVAL;
+    FusedArgs f{};
+    WarpGeo wg{};
+    warp_fused_args(f, wg, n, H, W, C, luts, geo, kind, max_sigma);
+    f.img = img; f.in_sn = in_sn; f.out = out; f.out_sn = out_sn; f.workspace = workspace; f.workspace_bytes = workspace_bytes;
+    f.wboxes = tile_boxes;
+    int rc = launch_warp_fused(f, as_stream(stream));
+    return rc != LERF_OK ? rc : check_launch();
+}
+
 int lerf_unpack_stages(const uint32_t* packed, int64_t n_pxch, int oC, uint8_t* feat, uint8_t* hq, void* stream) {
     if (!packed || n_pxch < 1 || (!feat && !hq)) return LERF_EINVAL;
     int rc = launch_unpack_stages(packed, n_pxch, oC, feat, hq, as_stream(stream));

@@ -97,7 +97,6 @@ __device__ __forceinline__ SimplexPath simplex_path(int v0, int v1, int v2, int 
     return p;
 }
 
-__host__ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Launch errors are what hipGetLastError() reports after the launches of an entry point -- but the thread's error state also
 // carries what the CALLER's HIP traffic left there (PyTorch polls its events: hipErrorNotReady).  Entry points drop stale

@@ -9,6 +9,7 @@
 // AmplifiedLinearResize2dNumpy, resize_right/resize_right2d_numpy.py:142-282).
 #define LERF_FUSED_NS fused
 #define LERF_FUSED_CH 3
+#define LERF_FUSED_WITH_WARP 1      // this instance also carries the tile-fused warp (launch_warp_fused)
 #include "lerf_fused_impl.h"
 
 namespace lerf {
@@ -98,6 +99,24 @@ int launch_sr_fused(const FusedArgs& a, hipStream_t st) {
     if (th == 32) return launch_sr_fused_h32(a, st);
     if (th == 16) return launch_sr_fused_h16(a, st);
     return fused_fast(a) ? fused::launch_sr<false>(a, st) : launch_sr_fused_g3(a, st);
+}
+
+// the whole warp path of a batch of RGB frames that share one homography: s1_kernel, then stage 2 + the warp per source tile
+// (sr_fused_kernel<.., LERF_FUSED_WARP>): no packed maps travel through HBM
+bool warp_fused_supported(const FusedArgs& a) {
+    const lerf_luts_t* L = a.luts;
+    if (!luts_packable(L) || !L->fused_pack || a.C != 3 || a.S != 2 || a.items != nullptr || !a.wgeo) return false;
+    if (L->n_modes1 != 3 || L->n_modes2 != 3 || memcmp(L->modes1, "sct", 3) != 0 || memcmp(L->modes2, "sct", 3) != 0) return false;
+    if ((a.kind == LERF_KIND_GAUSS && L->oC != 3) || (a.kind == LERF_KIND_LINEAR && L->oC != 1)) return false;
+    if (a.kind != LERF_KIND_GAUSS && a.kind != LERF_KIND_LINEAR) return false;
+    if (a.kind == LERF_KIND_GAUSS && !(a.max_sigma <= s3::kNoShiftMaxSigma)) return false;
+    if (a.wgeo->pad_mode != LERF_PAD_CONSTANT || a.wgeo->S != 2) return false;
+    return (int64_t)a.wgeo->oH * a.wgeo->oW < (1ll << 26);                             // the tile boxes' index division
+}
+
+int launch_warp_fused(const FusedArgs& a, hipStream_t st) {
+    if (!warp_fused_supported(a)) return LERF_EUNSUPPORTED;
+    return fused::launch_warp(a, st);
 }
 
 // stages 1+2 only: packed (hq0,hq1,hq2,feat) dwords per pixel-channel

@@ -49,6 +49,7 @@
 
 #include "lerf_kernels.h"
 #include "lerf_stage3.h"
+#include "lerf_warp_px.h"
 
 namespace lerf {
 namespace LERF_FUSED_NS {
@@ -190,6 +191,7 @@ struct Params {
     int pad_mode;                    // LERF_PAD_* of the image operand of stage 3 at the true frame borders
     int host_input;                  // the input frames live in (pinned) HOST memory: read every pixel once (LDS tile), never 39 times
     int out_pitch;                   // bytes per output row (lerf_sr_geo_t.out_row_pitch; 0 = dense rows of oW * CH bytes)
+    WarpGeo wgeo; const int32_t* wboxes;   // tile-fused warp (LERF_FUSED_WARP): homography + per-tile output boxes {i0, i1, j0, j1}
 };
 
 #ifdef LERF_STAMPS
@@ -952,9 +954,47 @@ __device__ __forceinline__ FrameView frame_view(const Params& P, const std::cond
     return F;
 }
 
-template <int S, int KIND, bool EMIT, bool FROM_FEAT = false, bool GEN = false>
+// The warp of one source tile (tile-fused warp, lerf_warp_fused_u8): every output pixel of the tile's box is projected (float64,
+// Warp2dNumpy's operation order) and kept when this tile owns it (host::warp_owner_key: last tap row / column inside the tile);
+// its 2 x 2 taps are packed dwords (hq0 | hq1 << 8 | hq2 << 16 | feat << 24) of the tile's stage-2 region Dt (origin
+// (hy0, hx0), pitch HP dwords) -- the per-pixel arithmetic is warp_px_value_u8, the packed warp kernel's own.
+template <int KIND, int HP>
+__device__ __forceinline__ void warp_tile(const Params& P, const uint32_t* Dt, int hy0, int hx0, int ty0, int tx0, int H, int W, int tile,
+                                          uint8_t* __restrict__ outp, int tid) {
+    const WarpGeo& g = P.wgeo;
+    const int i0 = P.wboxes[4 * tile], i1 = P.wboxes[4 * tile + 1], j0 = P.wboxes[4 * tile + 2], j1 = P.wboxes[4 * tile + 3];
+    const int bw = j1 - j0, n = (i1 - i0) * bw;
+    if (n <= 0) return;
+    const float gsc = KIND == LERF_KIND_GAUSS ? s3::gauss_scale(P.max_sigma) : 1.0f;
+    const unsigned inv_bw = (unsigned)((0xFFFFFFFFull / (unsigned)bw) + 1ull);          // q / bw for q < 2^26 (checked by the launcher)
+    for (int q = tid; q < n; q += NT) {
+        int di = (int)__umulhi((unsigned)q, inv_bw);
+        int dj = q - di * bw;
+        if (dj < 0) { --di; dj += bw; } else if (dj >= bw) { ++di; dj -= bw; }
+        const int i = i0 + di, j = j0 + dj;
+        const WarpPx2 G = warp_px_geometry(g, i, j, H, W);
+        const int kr = min(G.rrow[0] + 1, H - 1), kc = min(G.rcol[0] + 1, W - 1);
+        if (kr < ty0 || kr >= ty0 + TH || kc < tx0 || kc >= tx0 + TW) continue;
+        const float dxs[2] = {G.dx[0] * gsc, G.dx[1] * gsc}, dys[2] = {G.dy[0] * gsc, G.dy[1] * gsc};
+        uint8_t* dst = outp + ((int64_t)i * g.oW + j) * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            auto tap = [&](int r, int cc) -> uint32_t { return Dt[(r - hy0) * HP + (cc - hx0) * CH + c]; };
+            float res;
+            if (warp_px_value_u8<KIND>(G, g, H, W, P.max_sigma, dxs, dys, tap, dst + c, &res)) continue;
+            dst[c] = s3::to_u8(res);
+        }
+    }
+}
+
+// KINDW = LERF_KIND_* (| LERF_FUSED_WARP: stage 3 is the homographic warp of the tile's own output pixels, warp_tile())
+constexpr int LERF_FUSED_WARP = 16;
+template <int S, int KINDW, bool EMIT, bool FROM_FEAT = false, bool GEN = false>
 __global__ void __launch_bounds__(NT)
 sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
+    constexpr int KIND = KINDW & 15;
+    constexpr bool WARP = (KINDW & LERF_FUSED_WARP) != 0;
+    static_assert(!WARP || (!EMIT && S == 2 && CH == 3 && !GEN), "tile-fused warp: RGB, 2 x 2 support, specialised kernel");
     using D = Dims<S, GEN, EMIT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -1025,7 +1065,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
     //      s1_kernel was tried here too -- 72 x 72 positions per tile -- and did not pay: 0.191 vs 0.184 ms per 1080 x 960
     //      block; this kernel's stage 1 shares the CU with nothing else that uses the LDS less.)
     const int cphase = load_input_tile<D::IY, D::IPB, D::IP>(smem + D::OFF_C, img, H, W, iy0, ix0, interior, tid,
-                                                             [&]() { if (D::GEO_EARLY && !EMIT) geo_search(); });
+                                                             [&]() { if (D::GEO_EARLY && !EMIT && !WARP) geo_search(); });
 
     // ---- stage 1: three byte LUTs, 4 rotations each (eval_lut_sr.py:541-577)
     {
@@ -1035,7 +1075,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         const int div1 = kQ * 3;
         copy16<LERF_LUT_ENTRIES>(smem + D::OFF_LUT, P.pack + 0 * LUT_PAD, tid);
         __syncthreads();
-        if (D::GEO_EARLY && !EMIT) geo_stage();            // search results are in ctl; its loads hide behind phase s
+        if (D::GEO_EARLY && !EMIT && !WARP) geo_stage();            // search results are in ctl; its loads hide behind phase s
         LERF_STAMP(1);
         // the next LUT rides in registers behind the lookups (explicit scalars: an array/struct that lives
         // across the position loop ends up in scratch)
@@ -1104,7 +1144,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 const int ry = p / RD;
                 v[k] = __builtin_nontemporal_load(&src[(int64_t)ry * rowdw + (p - ry * RD)]);
             }
-            if (D::GEO_EARLY && !EMIT) geo_search();
+            if (D::GEO_EARLY && !EMIT && !WARP) geo_search();
 #pragma unroll
             for (int k = 0; k < KD; ++k) {
                 const int p = tid + k * NT;
@@ -1122,7 +1162,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 const int gy = clampi(fy0 + ry, 0, H - 1), gx = clampi(fx0 + rx, 0, W - 1);
                 v[k] = fsrc[((int64_t)gy * W + gx) * CH + (r3 - rx * CH)];
             }
-            if (D::GEO_EARLY && !EMIT) geo_search();
+            if (D::GEO_EARLY && !EMIT && !WARP) geo_search();
 #pragma unroll
             for (int k = 0; k < KI; ++k) {
                 const int p = tid + k * NT;
@@ -1130,7 +1170,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
             }
         }
         __syncthreads();
-        if (D::GEO_EARLY && !EMIT) geo_stage();
+        if (D::GEO_EARLY && !EMIT && !WARP) geo_stage();
         LERF_STAMP(6);
     }
 
@@ -1551,7 +1591,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         }
     }
 
-    if (!EMIT && KIND == LERF_KIND_GAUSS && Hc >= 0) {
+    if (!EMIT && !WARP && KIND == LERF_KIND_GAUSS && Hc >= 0) {
         // fill_outside: out-of-frame positions of the hyper region = the clamped position's hyper bytes, image byte 0
         __syncthreads();
         for (int p = tid; p < D::NH; p += NT) {
@@ -1563,6 +1603,12 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
         }
     }
 
+    if constexpr (WARP) {
+        // ---- stage 3 of the warp: the output pixels this tile owns, taps from the tile's packed dwords in LDS
+        __syncthreads();
+        warp_tile<KIND, D::HP>(P, Dt, hy0, hx0, ty0, tx0, H, W, tyi * F.tiles_x + txi, outp, tid);
+        return;
+    }
     if (EMIT) {
         __syncthreads();
         uint32_t* eo = F.emit;
@@ -2583,6 +2629,11 @@ static int launch_fused_t(const FusedArgs& a, hipStream_t st) {
         }
     P.emit = (uint32_t*)a.emit; P.emit_sn = a.emit_sn;
     P.feat = nullptr; P.feat_sn = 0;
+    if constexpr ((KIND & LERF_FUSED_WARP) != 0) {
+        if (!a.wgeo || !a.wboxes || a.workspace == nullptr || a.roi_h > 0 || a.items != nullptr) return LERF_EINVAL;
+        P.wgeo = *a.wgeo;
+        P.wboxes = a.wboxes;
+    }
     auto set_s1off = [&](Params& Q, int pitch_kind) {          // stage-1 pattern offsets in the input tile of the kernel that runs it
         for (int m = 0; m < Q.n1; ++m)
             for (int r = 0; r < 4; ++r) {
@@ -2698,6 +2749,13 @@ static int launch_sr(const FusedArgs& a, hipStream_t st) {
     }
     return LERF_EUNSUPPORTED;
 }
+#ifdef LERF_FUSED_WITH_WARP
+static int launch_warp(const FusedArgs& a, hipStream_t st) {
+    if (a.kind == LERF_KIND_GAUSS) return launch_fused_t<2, LERF_KIND_GAUSS | LERF_FUSED_WARP, false, false>(a, st);
+    if (a.kind == LERF_KIND_LINEAR) return launch_fused_t<2, LERF_KIND_LINEAR | LERF_FUSED_WARP, false, false>(a, st);
+    return LERF_EUNSUPPORTED;
+}
+#endif
 template <bool GEN>
 static int launch_stages(const FusedArgs& a, hipStream_t st) {
     if (a.luts->oC == 3) return launch_fused_t<2, LERF_KIND_GAUSS, true, GEN>(a, st);

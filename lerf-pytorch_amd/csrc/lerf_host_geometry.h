@@ -20,6 +20,8 @@ namespace lerf {
 
 constexpr float kEps32 = 1.1920928955078125e-07f;  // np.finfo(np.float32).eps
 
+LERF_HD inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
 // Sampling patterns of resample/eval_lut_sr.py:30-81, (dy, dx) of pixels a,b,c,d.
 LERF_HD inline bool mode_pattern(char mode, int8_t dy[4], int8_t dx[4]) {
     dy[0] = 0; dx[0] = 0;
@@ -176,6 +178,48 @@ inline int warp_pads(const double minv[9], int in_h, int in_w, int out_h, int ou
     pads[1] = (l1r + S - 1 - in_h + 1) > 0 ? (l1r + S - 1 - in_h + 1) : 0;
     pads[2] = -l0c > 0 ? -l0c : 0;
     pads[3] = (l1c + S - 1 - in_w + 1) > 0 ? (l1c + S - 1 - in_w + 1) : 0;
+    return LERF_OK;
+}
+
+// Tile-fused warp (lerf_warp_fused_u8): a source tile of 64 x 64 pixels OWNS the output pixels whose support (2 x 2 taps,
+// clamped into the frame like the reference clips its field of view, resize_right2d_numpy.py:396-398) has its LAST tap row /
+// column inside the tile: key = min(first tap + 1, n - 1).  Both taps then lie in the tile or in the ring of one pixel above /
+// left of it, which the tile's stage-2 region holds.  (Pixels projected outside the frame are clipped onto its border and belong
+// to the border tiles.)
+LERF_HD inline void warp_owner_key(const double minv[9], int pad_r_lo, int pad_c_lo, int i, int j, int H, int W, int* key_r, int* key_c) {
+    double gr, gc;
+    project_point(minv, i, j, H, W, &gr, &gc);
+    const int lr = left_boundary(gr, 2) + pad_r_lo, lc = left_boundary(gc, 2) + pad_c_lo;
+    const int r0 = clampi(clampi(lr, 0, H - 1) - pad_r_lo, 0, H - 1), c0 = clampi(clampi(lc, 0, W - 1) - pad_c_lo, 0, W - 1);
+    *key_r = r0 + 1 < H - 1 ? r0 + 1 : H - 1;
+    *key_c = c0 + 1 < W - 1 ? c0 + 1 : W - 1;
+}
+
+// boxes[t] = {i0, i1, j0, j1}: output rows [i0, i1) x columns [j0, j1) that contain every pixel tile t (row-major tiles of
+// `tile` x `tile` source pixels) owns, widened by 2 pixels (the kernel decides ownership itself, pixel by pixel, with the
+// same formula; the boxes only bound its search).  One pass over the output on the host, once per homography.
+inline int warp_tile_boxes(const double minv[9], int pad_r_lo, int pad_c_lo, int H, int W, int oH, int oW, int tile, int32_t* boxes) {
+    if (!minv || !boxes || H < 1 || W < 1 || oH < 1 || oW < 1 || tile < 1) return LERF_EINVAL;
+    const int ty = (H + tile - 1) / tile, tx = (W + tile - 1) / tile;
+    for (int t = 0; t < ty * tx; ++t) { boxes[4 * t] = oH; boxes[4 * t + 1] = -1; boxes[4 * t + 2] = oW; boxes[4 * t + 3] = -1; }
+    for (int i = 0; i < oH; ++i)
+        for (int j = 0; j < oW; ++j) {
+            int kr, kc;
+            warp_owner_key(minv, pad_r_lo, pad_c_lo, i, j, H, W, &kr, &kc);
+            int32_t* b = boxes + 4 * ((kr / tile) * tx + kc / tile);
+            if (i < b[0]) b[0] = i;
+            if (i > b[1]) b[1] = i;
+            if (j < b[2]) b[2] = j;
+            if (j > b[3]) b[3] = j;
+        }
+    for (int t = 0; t < ty * tx; ++t) {
+        int32_t* b = boxes + 4 * t;
+        if (b[1] < 0) { b[0] = b[1] = b[2] = b[3] = 0; continue; }
+        b[0] = b[0] - 2 > 0 ? b[0] - 2 : 0;
+        b[1] = b[1] + 3 < oH ? b[1] + 3 : oH;
+        b[2] = b[2] - 2 > 0 ? b[2] - 2 : 0;
+        b[3] = b[3] + 3 < oW ? b[3] + 3 : oW;
+    }
     return LERF_OK;
 }
 

@@ -22,4 +22,8 @@ int lerf_invert3x3(const double m[9], double out[9]) { return host::invert3x3(m,
 int lerf_warp_pads(const double minv[9], int in_h, int in_w, int out_h, int out_w, int S, int32_t pads[4]) {
     return host::warp_pads(minv, in_h, in_w, out_h, out_w, S, pads);
 }
+int lerf_warp_tile_boxes(const lerf_warp_geo_t* geo, int H, int W, int32_t* boxes) {
+    if (!geo || geo->S != 2) return LERF_EINVAL;
+    return host::warp_tile_boxes(geo->minv, geo->pad_r_lo, geo->pad_c_lo, H, W, geo->out_h, geo->out_w, 64, boxes);
+}
 }

@@ -78,6 +78,7 @@ struct FusedArgs {
     int flags;                            // lerf_sr_geo_t.flags (LERF_GEO_*)
     int out_pitch;                        // lerf_sr_geo_t.out_row_pitch (bytes; 0 = dense)
     const FusedItem* items; int n_items;  // ragged launch (general kernels): frames of different sizes; img/out/H/W/... above unused
+    const WarpGeo* wgeo; const int32_t* wboxes;   // launch_warp_fused: the homography and the per-tile output boxes (device)
 };
 bool fused_supported(const FusedArgs& a);          // some tile-fused kernel covers the configuration
 size_t fused_workspace_bytes(const FusedArgs& a);  // what the two-launch path parks in the workspace
@@ -86,6 +87,8 @@ int fused_lutpack_build(const lerf_luts_t* L, void* buf, hipStream_t st);
 int launch_sr_fused(const FusedArgs& a, hipStream_t st);
 bool fused_stages_supported(const FusedArgs& a);
 int launch_stages_fused(const FusedArgs& a, hipStream_t st);
+bool warp_fused_supported(const FusedArgs& a);
+int launch_warp_fused(const FusedArgs& a, hipStream_t st);    // stage 1 -> workspace, then stage 2 + the warp per source tile
 // the general kernels (any patterns, scale <= 8, ragged frames) per channel count, one translation unit each
 int launch_sr_fused_g3(const FusedArgs& a, hipStream_t st);
 int launch_stages_fused_g3(const FusedArgs& a, hipStream_t st);

@@ -13,6 +13,7 @@
 // lives in lerf_fused.hip.
 #include "lerf_kernels.h"
 #include "lerf_stage3.h"
+#include "lerf_warp_px.h"
 
 namespace lerf {
 
@@ -161,18 +162,6 @@ struct TapAcc {
         }
     }
 };
-
-// amplified-linear 1-D factor (resize_right2d_numpy.py:233-241), cls = class of
-// the float64 distance: 0 outside [-1,1], 1 for [-1,0), 2 for [0,1]
-template <typename A>
-__device__ __forceinline__ A lin_factor(A alpha, A x, int cls) {
-    A f = cls == 1 ? alpha * x + (A)1 : (cls == 2 ? (A)1 - alpha * x : (A)0);
-    return f < (A)0 ? (A)0 : f;
-}
-template <typename A>
-__device__ __forceinline__ int dist_class(A x) {
-    return (x >= (A)-1 && x < (A)0) ? 1 : ((x >= (A)0 && x <= (A)1) ? 2 : 0);
-}
 
 // ---------------------------------------------------------------------------
 // A5/A6: SR with separable geometry tables
@@ -452,39 +441,6 @@ static int launch_resize_fixed(const ResizeArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // A7/A8: homographic warp, geometry per output pixel in float64
 // ---------------------------------------------------------------------------
-// Tie guard of the uint8 warps: an output within kTieEps of a half-integer is re-evaluated in float64 with the
-// reference's dtype chain (s3::eval64), like the SR kernels do; `tap(r, c)` returns (k0 | k1<<8 | k2<<16 | val<<24)
-// of the clamped source pixel.
-template <int KIND, int S, typename F>
-__device__ __forceinline__ double warp_eval64(int H, int W, const WarpGeo& g, int lr, int lc, double gr, double gc,
-                                              float max_sigma, F tap) {
-    uint32_t dd[S * S];
-    double dx[S], dy[S];
-#pragma unroll
-    for (int b = 0; b < S; ++b) dx[b] = gr - (double)clampi(lr + b, 0, H - 1);
-#pragma unroll
-    for (int a = 0; a < S; ++a) dy[a] = gc - (double)clampi(lc + a, 0, W - 1);
-#pragma unroll
-    for (int a = 0; a < S; ++a)
-#pragma unroll
-        for (int b = 0; b < S; ++b) {
-            const int sr = clampi(lr + b, 0, H - 1) - g.pad_r_lo, sc_ = clampi(lc + a, 0, W - 1) - g.pad_c_lo;
-            const int rcl = clampi(sr, 0, H - 1), ccl = clampi(sc_, 0, W - 1);
-            const uint32_t d = tap(rcl, ccl);
-            dd[a * S + b] = ((sr == rcl) && (sc_ == ccl)) ? d : (d & 0x00FFFFFFu);      // zero image outside the frame
-        }
-    return s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx, dy, max_sigma);
-}
-
-template <int KIND, typename F>
-__device__ __forceinline__ bool warp_tie_guard(float res, int S, int H, int W, const WarpGeo& g, int lr, int lc, double gr,
-                                               double gc, float max_sigma, F tap, uint8_t* dst) {
-    if (!(KIND == LERF_KIND_GAUSS || KIND == LERF_KIND_LINEAR) || !s3::near_tie(res)) return false;
-    if (S == 2) *dst = s3::to_u8_d(warp_eval64<KIND, 2>(H, W, g, lr, lc, gr, gc, max_sigma, tap));
-    else if (S == 4) *dst = s3::to_u8_d(warp_eval64<KIND, 4>(H, W, g, lr, lc, gr, gc, max_sigma, tap));
-    else return false;
-    return true;
-}
 template <typename TI, typename TH, typename TO, typename A, int KIND>
 __global__ void __launch_bounds__(256)
 warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
@@ -692,41 +648,19 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed0, int64_t packed_sn, i
     const int i = b / gx;
     const int j = (b - i * gx) * 256 + (int)threadIdx.x;
     if (j >= g.oW) return;
-    double gr, gc;
-    project_point(g.minv, i, j, H, W, &gr, &gc);
-    const int lr = left_boundary(gr, S) + g.pad_r_lo;
-    const int lc = left_boundary(gc, S) + g.pad_c_lo;
-    gr += (double)g.pad_r_lo;
-    gc += (double)g.pad_c_lo;
+    const WarpPx2 G = warp_px_geometry(g, i, j, H, W);
+    const int lr = G.lr, lc = G.lc;
+    const double gr = G.gr, gc = G.gc;
     int64_t pos[S * S];
     float dx[S], dy[S];
     int cx[S], cy[S];
     bool in_r[S], in_c[S];
-    int rrow[S], rcol[S];
 #pragma unroll
-    for (int b = 0; b < S; ++b) {
-        const int pr = clampi(lr + b, 0, H - 1);
-        const double d = gr - (double)pr;
-        dx[b] = (float)d;
-        cx[b] = dist_class(d);
-        const int sr = pr - g.pad_r_lo;
-        rrow[b] = clampi(sr, 0, H - 1);
-        in_r[b] = sr == rrow[b];
-    }
-#pragma unroll
-    for (int a = 0; a < S; ++a) {
-        const int pc = clampi(lc + a, 0, W - 1);
-        const double d = gc - (double)pc;
-        dy[a] = (float)d;
-        cy[a] = dist_class(d);
-        const int sc_ = pc - g.pad_c_lo;
-        rcol[a] = clampi(sc_, 0, W - 1);
-        in_c[a] = sc_ == rcol[a];
-    }
+    for (int b = 0; b < S; ++b) { dx[b] = G.dx[b]; cx[b] = G.cx[b]; in_r[b] = G.in_r[b]; dy[b] = G.dy[b]; cy[b] = G.cy[b]; in_c[b] = G.in_c[b]; }
 #pragma unroll
     for (int a = 0; a < S; ++a)
 #pragma unroll
-        for (int b = 0; b < S; ++b) pos[a * S + b] = ((int64_t)rrow[b] * W + rcol[a]) * C;
+        for (int b = 0; b < S; ++b) pos[a * S + b] = ((int64_t)G.rrow[b] * W + G.rcol[a]) * C;
     float dxs[S], dys[S];
     const float gsc = (PROD && KIND == LERF_KIND_GAUSS) ? s3::gauss_scale(max_sigma) : 1.0f;
     const float ms255 = max_sigma * (1.0f / 255.0f);
@@ -744,32 +678,11 @@ warp_packed_px_kernel(const uint32_t* __restrict__ packed0, int64_t packed_sn, i
 #pragma unroll
         for (int t = 0; t < S * S; ++t) d[t] = packed[pos[t] + c];
         if constexpr (PROD) {
-            float e[S * S], v[S * S];
-#pragma unroll
-            for (int a = 0; a < S; ++a)
-#pragma unroll
-                for (int b = 0; b < S; ++b) {
-                    const uint32_t q = d[a * S + b];
-                    if (KIND == LERF_KIND_GAUSS) {
-                        e[a * S + b] = s3::gauss_form_u8((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), dxs[b], dys[a]);
-                    } else {
-                        const float alpha = s3::lin_alpha_u8((float)(q & 0xFFu), ms255);
-                        e[a * S + b] = s3::lin_factor(alpha, dx[b], cx[b]) * s3::lin_factor(alpha, dy[a], cy[a]);
-                    }
-                    v[a * S + b] = (in_r[b] && in_c[a]) ? (float)(q >> 24) : 0.0f;
-                }
-            float res = s3::finish<KIND == LERF_KIND_GAUSS, S * S, true, true, false>(e, v);
-            if (KIND == LERF_KIND_GAUSS) {
-                // every weight underflows in the reference's float64 (exp(-e/2) = 0 for e/2 > 745.2): its 0/0 = NaN; in the
-                // pre-scaled units e' = 0.5 log2(e) e that is e' > 1075.1
-                const float emin = fminf(fminf(e[0], e[1]), fminf(e[2], e[3]));
-                if (emin > 1075.1f) res = __builtin_nanf("");
-            }
+            static_assert(sizeof(TO) == 1, "production arithmetic: uint8 outputs");
             TO* dst = out + i * oy + j * ox + c * oc;
-            if (sizeof(TO) == 1) {
-                auto tap = [&](int rcl, int ccl) -> uint32_t { return packed[((int64_t)rcl * W + ccl) * C + c]; };
-                if (warp_tie_guard<KIND>(res, S, H, W, g, lr, lc, gr, gc, max_sigma, tap, reinterpret_cast<uint8_t*>(dst))) continue;
-            }
+            auto tap = [&](int rcl, int ccl) -> uint32_t { return packed[((int64_t)rcl * W + ccl) * C + c]; };
+            float res;
+            if (warp_px_value_u8<KIND>(G, g, H, W, max_sigma, dxs, dys, tap, reinterpret_cast<uint8_t*>(dst), &res)) continue;
             Storer<TO>::put(dst, res);
             continue;
         }

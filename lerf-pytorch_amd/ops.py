@@ -162,6 +162,20 @@ class WarpGeometry:
     def ref(self):
         return C.byref(self.struct)
 
+    def tile_boxes(self, device):
+        """int32 [tiles][4] on `device`: the output rows x columns that bound what each 64 x 64 source tile owns in the
+        tile-fused warp (lerf_warp_tile_boxes: one host pass over the output per homography, kept with the geometry)"""
+        torch = _torch()
+        key = str(device)
+        cache = self.__dict__.setdefault("_boxes", {})
+        if key not in cache:
+            H, W = self.in_hw
+            nt = ((H + 63) // 64) * ((W + 63) // 64)
+            b = np.zeros((nt, 4), dtype=np.int32)
+            _lib.check(_lib.lib().lerf_warp_tile_boxes(self.ref(), H, W, b.ctypes.data), "lerf_warp_tile_boxes")
+            cache[key] = (torch.from_numpy(b).to(device), b)
+        return cache[key][0]
+
 
 # --------------------------------------------------------------------------- helpers
 def _planes_chw(t):
@@ -382,6 +396,40 @@ def warp_packed(packed, geo: "WarpGeometry", kind="gauss", max_sigma=10.0, out="
     po = _lib.plane(o, o.stride(1), o.stride(2), o.stride(3))
     _lib.check(_lib.lib().lerf_warp_packed(p.data_ptr(), p.stride(0), N, H, W, Cn, geo.ref(), KINDS[kind], float(max_sigma),
                                            C.byref(po), o.stride(0), _lib.current_stream()), "lerf_warp_packed")
+    return o[0] if squeeze else o
+
+
+def warp_fused_supported(img_u8, luts, geo: "WarpGeometry", kind="gauss", max_sigma=10.0):
+    H, W, Cn = img_u8.shape[-3:]
+    return bool(_lib.lib().lerf_warp_fused_supported(Cn, luts.ref(), geo.ref(), H, W, KINDS[kind], float(max_sigma)))
+
+
+def warp_fused_u8(img_u8, luts, geo: "WarpGeometry", kind="gauss", max_sigma=10.0, out=None, workspace=None):
+    """The whole warp path tile-fused (lerf_warp_fused_u8): uint8 [H,W,3] or a batch [N,H,W,3] sharing the homography ->
+    uint8 [.., oH, oW, 3]; stage 1 into the workspace, then stage 2 + the warp per source tile -- no packed maps in HBM."""
+    torch = _torch()
+    if img_u8.dtype != torch.uint8:
+        raise ValueError("img must be uint8")
+    squeeze = img_u8.dim() == 3
+    img = (img_u8.unsqueeze(0) if squeeze else img_u8).contiguous()
+    N, H, W, Cn = img.shape
+    oshape = (N, geo.out_hw[0], geo.out_hw[1], Cn)
+    if out is None:
+        o = torch.empty(oshape, dtype=torch.uint8, device=img.device)
+    else:
+        o = out.unsqueeze(0) if (squeeze and out.dim() == 3) else out
+        if tuple(o.shape) != oshape or o.dtype != torch.uint8 or not o.is_contiguous() or o.device != img.device:
+            raise ValueError("out must be a contiguous uint8 tensor of shape %s on the input's device" % (oshape,))
+    need = int(_lib.lib().lerf_sr_fused_workspace_bytes(H, W, Cn, N))
+    if workspace is None:
+        workspace = fused_workspace(H, W, Cn, N, img.device)
+    elif workspace.dtype != torch.uint8 or workspace.numel() < need or not workspace.is_cuda or not workspace.is_contiguous():
+        raise ValueError("workspace must be a contiguous uint8 device tensor of at least %d bytes" % need)
+    boxes = geo.tile_boxes(img.device)
+    with _lib.on_device(o):
+        _lib.check(_lib.lib().lerf_warp_fused_u8(img.data_ptr(), img.stride(0), N, H, W, Cn, luts.ref(), geo.ref(), boxes.data_ptr(),
+                                                 KINDS[kind], float(max_sigma), o.data_ptr(), o.stride(0), workspace.data_ptr(),
+                                                 workspace.numel(), _lib.current_stream()), "lerf_warp_fused_u8")
     return o[0] if squeeze else o
 
 

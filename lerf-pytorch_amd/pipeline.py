@@ -27,6 +27,9 @@ class LerfEngine:
         self.support = 2 if self.linear else int(support)
         self.max_sigma = 1.0 if self.linear else float(max_sigma)
         self._sr_geo = {}
+        # warp(): True = the tile-fused kernel where it applies (no packed maps in HBM: traffic 1/3, but 15 % more time per batch and a
+        # host pass over the output per homography); False (default) = stages + packed-map warp, three launches
+        self.fused_warp = False
 
     @classmethod
     def shipped(cls, name="lerf-g", **kw):
@@ -104,7 +107,9 @@ class LerfEngine:
         x, as_np = self._dev(img)
         H, W, Cn = x.shape
         geo = ops.WarpGeometry((H, W), matrix, out_hw, self.support)
-        if self._fused_stages_ok(x) and out == "u8":
+        if out == "u8" and self.fused_warp and self._fused_stages_ok(x) and ops.warp_fused_supported(x, self.luts, geo, self.kind, self.max_sigma):
+            o = ops.warp_fused_u8(x, self.luts, geo, self.kind, self.max_sigma)        # tile-fused: no packed maps in HBM
+        elif self._fused_stages_ok(x) and out == "u8":
             o = ops.warp_packed(ops.stages_packed(x, self.luts), geo, self.kind, self.max_sigma, out=out)
         else:
             # float outputs: float64 arithmetic in the direct kernel (f32 = rounded once at the store)

@@ -113,7 +113,8 @@ if "--no-json" not in sys.argv:
     cfgd = bench["config"]
     cfg = cfgd["baseline_config"]
     S = 4 if "S=4" in cfgd["workload"] else 2
-    key = B.traffic_key(cfg, S, cfgd.get("channels", 3), cfgd.get("scale", [2.0, 2.0]), cfgd["frames_per_step_per_gpu"], cfgd["input"])
+    key = B.traffic_key(cfg, S, cfgd.get("channels", 3), cfgd.get("scale", [2.0, 2.0]), cfgd["frames_per_step_per_gpu"], cfgd["input"],
+                        "warpfused" if "warp_fused_u8" in cfgd.get("path", "") else "")
     path = os.path.join(dst, "hbm_traffic.json")
     try:
         allj = json.load(open(path))
