@@ -494,6 +494,7 @@ def parse():
                          "uint8 numpy out); classes-torch: the torch resampler twins on device tensors (training / validation shapes)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer-in / host-buffer-out legs (config 2)")
     ap.add_argument("--warp-fused", action="store_true", help="config 4: the tile-fused warp (lerf_warp_fused_u8: no packed stage outputs in HBM) instead of the three-launch path")
+    ap.add_argument("--overlap-halo", action="store_true", help="blocks mode: launch the block's interior under the halo exchange, its border after it (dist.OverlappedBlock)")
     ap.add_argument("--no-psnr", action="store_true", help="skip the Set5 PSNR-delta-vs-reference block of the default line (config 2)")
     ap.add_argument("--unfused", action="store_true", help="config 2: time the 3-launch direct path instead")
     ap.add_argument("--scale", type=float, default=None, help="config 2: scale factor (default 2; > 4.9 takes the general kernels)")
@@ -576,7 +577,9 @@ def main():
     S = args.support if cfg == 2 else 2
     kind = "linear" if model == "lerf-l" else "gauss"
     input_kind = args.input or ("natural" if cfg == 4 else "noise")
-    mode = args.mode or ("strips" if (cfg == 5 and world > 1) else "frames")
+    # config 5 over N > 1 GPUs: 2-D blocks by default (one round of tiles per rank; emulated per-rank time 97 % of the ideal for the
+    # 8-frame batch against 84 % for strips, profiles/r05_8k_blocks.txt); --mode strips / frames choose otherwise
+    mode = args.mode or ("blocks" if (cfg == 5 and world > 1) else "frames")
     strips = mode in ("strips", "blocks") and world > 1          # any partition of the FRAME over the ranks
     blocks = mode == "blocks" and world > 1
     if strips and cfg == 4:
@@ -616,7 +619,13 @@ def main():
             lh, lw = plan.local_hw
             wsb = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(lh, lw, C, B_local)), dtype=torch.uint8, device="cuda")
 
+            ovl = ldist.OverlappedBlock(eng, plan, geo) if args.overlap_halo else None
+
             def step(o=out):
+                if ovl is not None:
+                    # interior part launched under the halo transfers, border parts after them (dist.OverlappedBlock)
+                    ovl.step(buf, o, workspace=wsb if B_local > 1 else False)
+                    return
                 ext = buf.exchange()
                 # one frame per launch: ONE launch without the stage-1 pass (255 tiles fill the chip once); a batch: two launches
                 # over the region of interest (stage 1 once per pixel over block + 4 px, round 4)

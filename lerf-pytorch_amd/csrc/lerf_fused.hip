@@ -56,7 +56,8 @@ bool fused_supported(const FusedArgs& a) {
         return true;
     }
     if (roi && (a.roi_y < 0 || a.roi_x < 0 || a.roi_y + a.roi_h > a.H || a.roi_x + a.roi_w > a.W)) return false;
-    return shape_ok(a.H, a.W, a.oH, a.oW);
+    // a region of interest lists the outputs of the REGION (a block, or one part of it: dist.block_parts): the up-sampling test is the region's
+    return shape_ok(roi ? a.roi_h : a.H, roi ? a.roi_w : a.W, a.oH, a.oW);
 }
 
 size_t fused_workspace_bytes(const FusedArgs& a) {

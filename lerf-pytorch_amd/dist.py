@@ -432,6 +432,85 @@ def sr_block(engine, ext, plan: BlockPlan, geo, out=None, workspace="auto"):
     return ops.sr_fused_u8(ext, engine.luts, block_geometry(geo, plan), engine.kind, engine.max_sigma, out=out, workspace=workspace)
 
 
+def block_parts(plan: BlockPlan, left_r, left_c, border=64):
+    """The owned block cut into an INTERIOR rectangle and up to four BORDER rectangles (top / bottom strips over the block's
+    whole width, left / right strips between them), `border` pixels thick (one tile) on the sides that have a neighbour.
+    Nothing the interior's outputs read lies outside the owned block (border >= halo): its launch does not depend on the halo
+    exchange and runs under it; the border rectangles follow once the halo is in.  Each part: dict(name, rect = (ya, yb, xa, xb)
+    global LR pixels, out = (ia, ib, ja, jb) global output pixels by the block rule -- support centre inside the rectangle).
+    The parts' output rectangles partition the block's own."""
+    gy, gx = plan.grid
+    if border < plan.halo:
+        raise ValueError("the border must cover the halo (%d pixels)" % plan.halo)
+    top = border if plan.ry > 0 else 0
+    bot = border if plan.ry < gy - 1 else 0
+    lft = border if plan.rx > 0 else 0
+    rgt = border if plan.rx < gx - 1 else 0
+    if plan.y1 - plan.y0 <= top + bot or plan.x1 - plan.x0 <= lft + rgt:
+        return [dict(name="block", rect=(plan.y0, plan.y1, plan.x0, plan.x1), out=(plan.i0, plan.i1, plan.j0, plan.j1), interior=False)]
+    ya, yb, xa, xb = plan.y0 + top, plan.y1 - bot, plan.x0 + lft, plan.x1 - rgt
+    kr = np.asarray(left_r, dtype=np.int64) + plan.S // 2
+    kc = np.asarray(left_c, dtype=np.int64) + plan.S // 2
+
+    def rows(a, b):
+        return (plan.i0 if a == plan.y0 else int(np.searchsorted(kr, a, side="left")),
+                plan.i1 if b == plan.y1 else int(np.searchsorted(kr, b, side="left")))
+
+    def cols(a, b):
+        return (plan.j0 if a == plan.x0 else int(np.searchsorted(kc, a, side="left")),
+                plan.j1 if b == plan.x1 else int(np.searchsorted(kc, b, side="left")))
+    parts = [dict(name="interior", rect=(ya, yb, xa, xb), out=rows(ya, yb) + cols(xa, xb), interior=True)]
+    for name, r in (("top", (plan.y0, ya, plan.x0, plan.x1)), ("bottom", (yb, plan.y1, plan.x0, plan.x1)),
+                    ("left", (ya, yb, plan.x0, xa)), ("right", (ya, yb, xb, plan.x1))):
+        if r[0] < r[1] and r[2] < r[3]:
+            parts.append(dict(name=name, rect=r, out=rows(r[0], r[1]) + cols(r[2], r[3]), interior=False))
+    return parts
+
+
+def part_geometry(geo, plan: BlockPlan, part):
+    """the GLOBAL SrGeometry rebased to the rank's local frame, tiles laid over one part of the owned block"""
+    lh, lw = plan.local_hw
+    ya, yb, xa, xb = part["rect"]
+    ia, ib, ja, jb = part["out"]
+    return geo.block_slice(plan.ylo, lh, ia, ib, plan.xlo, lw, ja, jb, roi=(ya - plan.ylo, xa - plan.xlo, yb - ya, xb - xa))
+
+
+class OverlappedBlock:
+    """One part (frame or batch) per step with the halo exchange UNDER the interior's kernels: post() the transfers, launch the
+    interior part (reads the owned block only), finish() the transfers, launch the border parts.  The geometry slices are built
+    once.  Same bytes as sr_block on the whole block (tests/test_gpu_fullsize.py)."""
+
+    def __init__(self, engine, plan: BlockPlan, geo, border=64):
+        self.engine, self.plan = engine, plan
+        self.parts = block_parts(plan, geo.host["left_r"], geo.host["left_c"], border)
+        self.geos = [part_geometry(geo, plan, p) for p in self.parts]
+
+    def _launch(self, k, ext, out, workspace):
+        from . import ops
+        p = self.parts[k]
+        ia, ib, ja, jb = p["out"]
+        if ib <= ia or jb <= ja:
+            return
+        view = out[..., ia - self.plan.i0:ib - self.plan.i0, ja - self.plan.j0:jb - self.plan.j0, :]
+        ops.sr_fused_u8(ext, self.engine.luts, self.geos[k], self.engine.kind, self.engine.max_sigma, out=view, workspace=workspace)
+
+    def step(self, buf: "BlockBuffer", out, group=None, workspace="auto"):
+        """buf.own holds this step's pixels; out: block_output(plan, ...).  Returns out."""
+        ext = buf.ext
+        if isinstance(workspace, str):
+            workspace = None if ext.shape[0] > 1 else False
+        works = buf.post(group) if self.plan.world > 1 else None
+        first = [k for k, p in enumerate(self.parts) if p["interior"]]
+        for k in first:
+            self._launch(k, ext, out, workspace)
+        if works is not None:
+            buf.finish(works)
+        for k in range(len(self.parts)):
+            if k not in first:
+                self._launch(k, ext, out, workspace)
+        return out
+
+
 def block_output(plan: BlockPlan, N, C, device):
     """Output tensor [N, i1-i0, j1-j0, C] of a rank's block as a VIEW of rows padded to a multiple of 16 bytes.  The blocks at
     the frame's left / right edge own 1919 / 1921 output columns at x2 (the half-pixel shift of the grid): dense rows of 5757

@@ -135,3 +135,28 @@ def test_gloo_block_halo_exchange_and_stitch(tmp_path, oracle, luts_g, H, W, sca
     for r in range(world):
         assert np.load(tmp_path / ("ok_%d.npy" % r)).all()
         assert np.array_equal(np.load(tmp_path / ("whole_%d.npy" % r)), full)
+
+
+@pytest.mark.parametrize("H,W,grid,S,scale", [(2160, 3840, (2, 4), 2, 2.0), (1080, 1920, (2, 2), 2, 1.5), (540, 700, (1, 3), 4, 3.0), (300, 300, (2, 2), 2, 2.0)])
+def test_block_parts_partition_the_block(oracle, H, W, grid, S, scale):
+    """dist.block_parts: interior + border rectangles tile the owned block, their output rectangles tile the block's output, the
+    interior reads nothing outside the owned block (its launch can run under the halo exchange), small blocks stay whole"""
+    lr = oracle.sr_axis_tables(H, oracle.out_size(H, scale), scale, S)[0]
+    lc = oracle.sr_axis_tables(W, oracle.out_size(W, scale), scale, S)[0]
+    for rank in range(grid[0] * grid[1]):
+        plan = ldist.BlockPlan(H, W, grid, rank, S, lr, lc)
+        parts = ldist.block_parts(plan, lr, lc, 64)
+        own = np.zeros((plan.y1 - plan.y0, plan.x1 - plan.x0), int)
+        out = np.zeros((plan.i1 - plan.i0, plan.j1 - plan.j0), int)
+        for p in parts:
+            ya, yb, xa, xb = p["rect"]
+            ia, ib, ja, jb = p["out"]
+            own[ya - plan.y0:yb - plan.y0, xa - plan.x0:xb - plan.x0] += 1
+            out[ia - plan.i0:ib - plan.i0, ja - plan.j0:jb - plan.j0] += 1
+            if p["interior"] and ib > ia and jb > ja:
+                r12 = 6
+                lo_r, hi_r = lr[ia:ib].min() - r12, lr[ia:ib].max() + S - 1 + r12
+                lo_c, hi_c = lc[ja:jb].min() - r12, lc[ja:jb].max() + S - 1 + r12
+                assert max(lo_r, 0) >= plan.y0 and min(hi_r, H - 1) < plan.y1 and max(lo_c, 0) >= plan.x0 and min(hi_c, W - 1) < plan.x1
+        assert (own == 1).all() and (out == 1).all()
+        assert sum(p["interior"] for p in parts) <= 1

@@ -104,3 +104,42 @@ print("8 frames x 8 blocks (two-launch ROI) stitched == whole frames:", bool(tor
 print("8 frames, one rank's BLOCKS, two launches over the region of interest: %.3f ms max, %.3f ms mean (single launch, stage 1 per tile halo: %.3f ms) "
       "vs 1/8 of the whole-frame batch %.3f ms -> strong-scaling efficiency of the compute part %.0f %% (single launch %.0f %%; strips %.0f %%)"
       % (max(tb2) * 1e3, np.mean(tb2) * 1e3, max(tb1) * 1e3, full8 / 8 * 1e3, 100 * full8 / 8 / max(tb2), 100 * full8 / 8 / max(tb1), 100 * full8 / 8 / d8))
+
+# ---- round 6: the same 8-frame blocks as interior + border parts (dist.OverlappedBlock): the interior pair of launches does not
+#      need the halo and runs UNDER the exchange, the (up to four) border parts after it -- emulated per-rank compute time of all
+#      parts against the single region-of-interest pair above (what the overlap costs in launches), and the interior's share
+#      (the time available to hide the exchange in); one frame per step likewise
+tov, tin = [], []
+tov1, tin1 = [], []
+st2 = torch.zeros((8, 4320, 7680, 3), dtype=torch.uint8, device="cuda")
+for r in range(8):
+    plan = ldist.BlockPlan(2160, 3840, (2, 4), r, 2, lr_, lc_)
+    ext8 = x8[:, plan.ylo:plan.yhi, plan.xlo:plan.xhi].contiguous()
+    ovl = ldist.OverlappedBlock(eng, plan, geo)
+    o = ldist.block_output(plan, 8, 3, ext8.device)
+    ws = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(ext8.shape[1], ext8.shape[2], 3, 8)), dtype=torch.uint8, device="cuda")
+
+    def run(e, oo, w):
+        for k in range(len(ovl.parts)): ovl._launch(k, e, oo, w)
+    run(ext8, o, ws)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): run(ext8, o, ws)
+    torch.cuda.synchronize(); tov.append((time.perf_counter() - t) / 5)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): ovl._launch(0, ext8, o, ws)
+    torch.cuda.synchronize(); tin.append((time.perf_counter() - t) / 5)
+    i0, i1, j0, j1 = plan.out_rect()
+    st2[:, i0:i1, j0:j1] = o
+    o1 = ldist.block_output(plan, 1, 3, ext8.device)
+    run(ext8[:1], o1, False)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): run(ext8[:1], o1, False)
+    torch.cuda.synchronize(); tov1.append((time.perf_counter() - t) / 10)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): ovl._launch(0, ext8[:1], o1, False)
+    torch.cuda.synchronize(); tin1.append((time.perf_counter() - t) / 10)
+print("8 frames x 8 blocks as interior + border parts stitched == whole frames:", bool(torch.equal(st2, whole8)))
+print("8 frames per rank, interior + border parts (%d launches pairs): %.3f ms max (region-of-interest pair: %.3f ms); the interior alone %.3f ms = the window the "
+      "halo exchange hides in" % (len(ovl.parts), max(tov) * 1e3, max(tb2) * 1e3, max(tin) * 1e3))
+print("1 frame per rank, interior + border parts: %.3f ms max (one region-of-interest launch: %.3f ms); the interior alone %.3f ms"
+      % (max(tov1) * 1e3, max(tb) * 1e3, max(tin1) * 1e3))
