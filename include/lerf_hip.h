@@ -148,6 +148,14 @@ typedef struct {
     double minv[9];          /* inverse of the 3x3 matrix, row major */
     int pad_r_lo, pad_r_hi, pad_c_lo, pad_c_hi;
     int pad_mode;            /* LERF_PAD_*; non-constant modes: float outputs of lerf_warp only */
+    /* ---- ABI 7 (zero = the behaviour of ABI 6): one RECTANGLE of the output from a BAND of the source, for partitions of a warp over
+     * ranks (lerf-pytorch_amd/dist.py WarpRowPlan).  out_h / out_w are then the rectangle's size, `out` its first pixel; the pixel
+     * (i, j) of the rectangle is the output pixel (out_y0 + i, out_x0 + j) -- the offsets enter the projection as integers, so the
+     * float64 arithmetic is the whole frame's, bit for bit -- and pad_* stay those of the WHOLE output (lerf_warp_pads).  The source
+     * operands (feat / hyper planes, packed maps) hold the frame's rows from src_y0 on: row r of the frame is row r - src_y0 of the
+     * operand; H, W stay the frame's.  The caller guarantees that every tap of the rectangle lies in the rows it passes.
+     * lerf_warp_fused_u8 takes whole outputs only (offsets must be zero). */
+    int out_y0, out_x0, src_y0;
 } lerf_warp_geo_t;
 
 /* ---------------------------------------------------------------- host side */

@@ -113,6 +113,7 @@ class WarpGeo(C.Structure):
         ("minv", C.c_double * 9),
         ("pad_r_lo", C.c_int), ("pad_r_hi", C.c_int), ("pad_c_lo", C.c_int), ("pad_c_hi", C.c_int),
         ("pad_mode", C.c_int),
+        ("out_y0", C.c_int), ("out_x0", C.c_int), ("src_y0", C.c_int),       # ABI 7: a rectangle of the output from a band of the source
     ]
 
 

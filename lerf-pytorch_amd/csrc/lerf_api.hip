@@ -200,6 +200,18 @@ int lerf_warp(const lerf_plane_t* feat, const lerf_plane_t hyper[3], int H, int 
     a.geo.pad_r_lo = geo->pad_r_lo; a.geo.pad_r_hi = geo->pad_r_hi;
     a.geo.pad_c_lo = geo->pad_c_lo; a.geo.pad_c_hi = geo->pad_c_hi;
     a.geo.pad_mode = geo->pad_mode;
+    a.geo.oy0 = geo->out_y0; a.geo.ox0 = geo->out_x0;
+    if (geo->out_y0 < 0 || geo->out_x0 < 0 || geo->src_y0 < 0 || geo->src_y0 >= H) return LERF_EINVAL;
+    if (geo->src_y0 > 0) {
+        // the operands start at source row src_y0: addressed with the frame's row numbers through pointers moved back by that many rows
+        // (never dereferenced outside the rows the caller passed: its guarantee, see lerf_warp_geo_t)
+        auto back = [&](const void* p, int dtype, int64_t sy) {
+            const int64_t es = dtype == LERF_U8 ? 1 : (dtype == LERF_F64 ? 8 : (dtype == LERF_I16 ? 2 : 4));
+            return (const void*)((const char*)p - (int64_t)geo->src_y0 * sy * es);
+        };
+        a.feat = back(a.feat, a.in_dtype, a.fy);
+        for (int k = 0; k < 3; ++k) a.h[k] = nh > 0 ? back(a.h[k], a.h_dtype, a.hy) : a.feat;
+    }
     if (geo->pad_mode < LERF_PAD_CONSTANT || geo->pad_mode > LERF_PAD_WRAP) return LERF_EINVAL;
     if (geo->pad_mode != LERF_PAD_CONSTANT && out->dtype == LERF_U8) return LERF_EUNSUPPORTED;
     a.kind = kind; a.max_sigma = max_sigma;
@@ -263,12 +275,13 @@ static void warp_fused_args(FusedArgs& f, WarpGeo& wg, int n, int H, int W, int 
     memcpy(wg.minv, geo->minv, sizeof(wg.minv));
     wg.pad_r_lo = geo->pad_r_lo; wg.pad_r_hi = geo->pad_r_hi; wg.pad_c_lo = geo->pad_c_lo; wg.pad_c_hi = geo->pad_c_hi;
     wg.pad_mode = geo->pad_mode;
+    wg.oy0 = geo->out_y0; wg.ox0 = geo->out_x0;
     f.n = n; f.H = H; f.W = W; f.C = C; f.luts = luts; f.S = geo->S; f.oH = geo->out_h; f.oW = geo->out_w;
     f.kind = kind; f.max_sigma = (float)max_sigma; f.wgeo = &wg;
 }
 
 int lerf_warp_fused_supported(int C, const lerf_luts_t* luts, const lerf_warp_geo_t* geo, int H, int W, int kind, double max_sigma) {
-    if (!luts || !geo || H < 1 || W < 1) return 0;
+    if (!luts || !geo || H < 1 || W < 1 || geo->out_y0 != 0 || geo->out_x0 != 0 || geo->src_y0 != 0) return 0;
     FusedArgs f{};
     WarpGeo wg{};
     warp_fused_args(f, wg, 1, H, W, C, luts, geo, kind, max_sigma);
@@ -280,6 +293,7 @@ int lerf_warp_fused_u8(const uint8_t* img, int64_t in_sn, int n, int H, int W, i
                        size_t workspace_bytes, void* stream) {
     if (!img || !luts || !geo || !tile_boxes || !out || !workspace || n < 1 || H < 1 || W < 1 || C < 1) return LERF_EINVAL;
     if (workspace_bytes < lerf_sr_fused_workspace_bytes(H, W, C, n)) return LERF_EINVAL;
+    if (geo->out_y0 != 0 || geo->out_x0 != 0 || geo->src_y0 != 0) return LERF_EUNSUPPORTED;
     FusedArgs f{};
     WarpGeo wg{};
     warp_fused_args(f, wg, n, H, W, C, luts, geo, kind, max_sigma);
@@ -304,7 +318,10 @@ int lerf_warp_packed(const uint32_t* packed, int64_t packed_sn, int n, int H, in
     memcpy(g.minv, geo->minv, sizeof(g.minv));
     g.pad_r_lo = geo->pad_r_lo; g.pad_r_hi = geo->pad_r_hi; g.pad_c_lo = geo->pad_c_lo; g.pad_c_hi = geo->pad_c_hi;
     g.pad_mode = LERF_PAD_CONSTANT;
+    g.oy0 = geo->out_y0; g.ox0 = geo->out_x0;
     if (geo->pad_mode != LERF_PAD_CONSTANT) return LERF_EUNSUPPORTED;
+    if (geo->out_y0 < 0 || geo->out_x0 < 0 || geo->src_y0 < 0 || geo->src_y0 >= H) return LERF_EINVAL;
+    packed -= (int64_t)geo->src_y0 * W * C;                    // rows of the frame from src_y0 on (lerf_warp_geo_t)
     int rc = launch_warp_packed(packed, packed_sn, n, H, W, C, g, kind, (float)max_sigma, out->ptr, out->dtype, out->sy, out->sx,
                                 out->sc, out_sn, as_stream(stream));
     return rc != LERF_OK ? rc : check_launch();

@@ -33,6 +33,7 @@ struct WarpGeo {
     double minv[9];
     int pad_r_lo, pad_r_hi, pad_c_lo, pad_c_hi;
     int pad_mode;                    // LERF_PAD_* of the image operand
+    int oy0, ox0;                    // the launch covers the output rectangle that starts at (oy0, ox0) (lerf_warp_geo_t.out_y0 / out_x0)
 };
 
 struct WarpArgs {

@@ -454,7 +454,7 @@ warp_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
     int c = xc - j * C;
     const int S = g.S;
     double gr, gc;
-    project_point(g.minv, i, j, H, W, &gr, &gc);
+    project_point(g.minv, i + g.oy0, j + g.ox0, H, W, &gr, &gc);
     int lr = left_boundary(gr, S) + g.pad_r_lo;
     int lc = left_boundary(gc, S) + g.pad_c_lo;
     gr += (double)g.pad_r_lo;      // calc_pad_sz shifts grid and field of view (:366-367)
@@ -583,7 +583,7 @@ warp_packed_kernel(const uint32_t* __restrict__ packed, int64_t packed_sn, int H
     int c = xc - j * C;
     const int S = g.S;
     double gr, gc;
-    project_point(g.minv, i, j, H, W, &gr, &gc);
+    project_point(g.minv, i + g.oy0, j + g.ox0, H, W, &gr, &gc);
     int lr = left_boundary(gr, S) + g.pad_r_lo;
     int lc = left_boundary(gc, S) + g.pad_c_lo;
     gr += (double)g.pad_r_lo;

@@ -69,7 +69,7 @@ __device__ __forceinline__ WarpPx2 warp_px_geometry(const WarpGeo& g, int i, int
     constexpr int S = 2;
     WarpPx2 G;
     double gr, gc;
-    project_point(g.minv, i, j, H, W, &gr, &gc);
+    project_point(g.minv, i + g.oy0, j + g.ox0, H, W, &gr, &gc);
     G.lr = left_boundary(gr, S) + g.pad_r_lo;
     G.lc = left_boundary(gc, S) + g.pad_c_lo;
     gr += (double)g.pad_r_lo;

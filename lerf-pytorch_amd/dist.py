@@ -594,6 +594,87 @@ def sr_frame_blocks(engine, own_block, H, W, scale, grid=None, group=None, gathe
 
 
 # --------------------------------------------------------------------------- data-parallel LUT fine-tuning
+# --------------------------------------------------------------------------- homographic warp over ranks
+class WarpRowPlan:
+    """Partition of a homographic warp (resize_right/resize_right2d_numpy.py:306-407) over `world` ranks by OUTPUT rows: rank r owns
+    the output rows [i0, i1) (all columns) and needs the SOURCE rows [b0, b1): the rows its taps read, found by projecting the
+    rectangle's border pixels through inv(M) with the reference's own float64 steps (a linear-fractional map is monotone along a
+    line: the extremes of the projected row coordinate lie on the rectangle's border), widened by the reach of the two LUT stages
+    (3 + 3 rows, recomputed in the band like the halo of the SR partitions) -- clipped projections fall on the frame's border rows,
+    which are then part of the band.  Nothing is exchanged between ranks: every rank is handed (or reads) its band of the input;
+    outputs stay sharded or are gathered (gather_strips).  The bands of neighbouring ranks overlap."""
+
+    def __init__(self, H, W, matrix, out_hw, world, rank, support=2):
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError("bad rank/world")
+        self.H, self.W, self.world, self.rank, self.S = int(H), int(W), int(world), int(rank), int(support)
+        self.out_hw = (int(out_hw[0]), int(out_hw[1]))
+        oH, oW = self.out_hw
+        if oH < world:
+            raise ValueError("fewer output rows than ranks")
+        self.matrix = np.asarray(matrix, dtype=np.float64)
+        self.i0, self.i1 = rank * oH // world, (rank + 1) * oH // world
+        lo, hi = self._tap_rows(self.i0, self.i1)
+        reach = STAGE1_RADIUS + STAGE2_RADIUS
+        self.t0, self.t1 = lo, hi + 1                                  # rows the warp's taps read
+        self.b0, self.b1 = max(lo - reach, 0), min(hi + 1 + reach, self.H)
+
+    def _tap_rows(self, i0, i1):
+        """(first, last) source row read by the taps of output rows [i0, i1): the border pixels of the rectangle, every one"""
+        from . import _lib
+        oH, oW = self.out_hw
+        minv = np.linalg.inv(self.matrix)                              # :327
+        pads = _lib.warp_pads(minv, (self.H, self.W), self.out_hw, self.S)
+        ii = np.concatenate([np.full(oW, i0), np.full(oW, i1 - 1), np.arange(i0, i1), np.arange(i0, i1)]).astype(np.float64)
+        jj = np.concatenate([np.arange(oW), np.arange(oW), np.zeros(i1 - i0), np.full(i1 - i0, oW - 1)]).astype(np.float64)
+        Y = minv[1, 0] * jj + minv[1, 1] * ii + minv[1, 2]
+        Wh = minv[2, 0] * jj + minv[2, 1] * ii + minv[2, 2]
+        if not ((Wh > 0).all() or (Wh < 0).all()):
+            return 0, self.H - 1                                       # the horizon crosses the rectangle: the whole frame
+        gr = np.clip(Y / Wh, 0, self.H)                                # :338-339
+        eps = float(np.finfo(np.float32).eps)
+        lr = np.ceil(gr - self.S / 2 - eps).astype(np.int64) + pads[0]
+        lo = np.clip(np.clip(lr, 0, self.H - 1) - pads[0], 0, self.H - 1)
+        hi = np.clip(np.clip(lr + self.S - 1, 0, self.H - 1) - pads[0], 0, self.H - 1)
+        return int(lo.min()), int(hi.max())
+
+    def band(self):
+        return self.b0, self.b1
+
+    def out_rows(self):
+        return self.i0, self.i1
+
+    def geometry(self, support=None):
+        """ops.WarpGeometry of this rank's output rows reading a band that starts at source row b0"""
+        from . import ops
+        oH, oW = self.out_hw
+        return ops.WarpGeometry((self.H, self.W), self.matrix, self.out_hw, self.S if support is None else support,
+                                out_rect=(self.i0, self.i1, 0, oW), src_y0=self.b0)
+
+
+def warp_rows(engine, band_u8, plan: WarpRowPlan, border=4):
+    """This rank's output rows [i0, i1) of the warp and their validity mask from its band of the input: uint8 [b1 - b0, W, C]
+    (or a batch [N, ...] sharing the homography) -> (uint8 [.., i1 - i0, oW, C], bool mask [i1 - i0, oW, C]).  The LUT stages run
+    on the band as a frame of its own (their values are wrong only within 6 rows of an artificial band edge, which no tap reads);
+    the warp and the nearest-warp mask (resample/eval_lut_warp.py:197-204, 229) run with the WHOLE frame's geometry."""
+    import torch
+    from . import ops
+    squeeze = band_u8.dim() == 3
+    x = band_u8.unsqueeze(0) if squeeze else band_u8
+    if x.shape[1] != plan.b1 - plan.b0 or x.shape[2] != plan.W:
+        raise ValueError("the band must hold source rows [%d, %d)" % (plan.b0, plan.b1))
+    geo = plan.geometry()
+    packed = ops.stages_packed(x, engine.luts)
+    out = ops.warp_packed(packed, geo, engine.kind, engine.max_sigma, out="u8")
+    Cn = x.shape[-1]
+    white = torch.zeros((plan.b1 - plan.b0, plan.W, Cn), dtype=torch.uint8, device=x.device)
+    ya, yb = max(border, plan.b0), min(plan.H - border, plan.b1)
+    if yb > ya:
+        white[ya - plan.b0:yb - plan.b0, border:plan.W - border] = 255
+    mask = ops.warp_hwc_u8(white, None, plan.geometry(support=1), "nearest", 1.0, out="f32") == 255
+    return (out[0] if squeeze else out), mask
+
+
 def allreduce_grads(model, group=None):
     """Average the parameter gradients of a fine-tuning model over the ranks: the data-parallel counterpart of the
     reference's nn.DataParallel wrapper (train_model.py:355-357, gpuNum > 1), one process per GPU.

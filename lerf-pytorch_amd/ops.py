@@ -142,7 +142,10 @@ class SrGeometry:
 class WarpGeometry:
     """Homography geometry (Warp2dNumpy.set_shape, resize_right2d_numpy.py:292-407)."""
 
-    def __init__(self, in_hw, matrix, out_hw, support=2, pad_mode=0):
+    def __init__(self, in_hw, matrix, out_hw, support=2, pad_mode=0, out_rect=None, src_y0=0):
+        """out_rect = (i0, i1, j0, j1): the geometry of that rectangle of the output alone (`out_hw` stays the WHOLE output's: the
+        pads come from its corner pixels); src_y0: the source operands hold the frame's rows from src_y0 on (a rank's band of a
+        partitioned warp, dist.WarpRowPlan).  Same float64 arithmetic as the whole frame's, bit for bit."""
         m = np.asarray(matrix.detach().cpu().numpy() if hasattr(matrix, "detach") else matrix, dtype=np.float64)
         if m.shape != (3, 3):
             raise ValueError("matrix must be 3x3")
@@ -157,6 +160,14 @@ class WarpGeometry:
             g.minv[i] = float(v)
         g.pad_r_lo, g.pad_r_hi, g.pad_c_lo, g.pad_c_hi = pads
         g.pad_mode = self.pad_mode = int(pad_mode)                          # LERF_PAD_* of the image operand (:560)
+        self.full_out_hw = self.out_hw
+        if out_rect is not None:
+            i0, i1, j0, j1 = (int(v) for v in out_rect)
+            if not (0 <= i0 < i1 <= self.out_hw[0] and 0 <= j0 < j1 <= self.out_hw[1]):
+                raise ValueError("out_rect outside the output")
+            g.out_y0, g.out_x0, g.out_h, g.out_w = i0, j0, i1 - i0, j1 - j0
+            self.out_hw = (i1 - i0, j1 - j0)
+        g.src_y0 = self.src_y0 = int(src_y0)
         self.struct = g
 
     def ref(self):
@@ -384,7 +395,10 @@ def warp_packed(packed, geo: "WarpGeometry", kind="gauss", max_sigma=10.0, out="
     p = packed.unsqueeze(0) if squeeze else packed
     if not p[0].is_contiguous():
         p = p.contiguous()
-    N, H, W, Cn = p.shape
+    N, Hb, W, Cn = p.shape
+    H = geo.in_hw[0]                                        # the frame's height; `packed` may hold its rows from geo.src_y0 on only
+    if W != geo.in_hw[1] or geo.src_y0 + Hb > H:
+        raise ValueError("packed maps do not match the geometry's frame")
     oshape = (N, geo.out_hw[0], geo.out_hw[1], Cn)
     if isinstance(out, str):
         o = torch.empty(oshape, dtype=_out_dtype(out), device=p.device)
@@ -515,7 +529,10 @@ def resize_planar_u8(feat_u8, hq_u8, geo: SrGeometry, kind="gauss", max_sigma=10
 def warp_hwc_u8(feat_u8, hq_u8, geo: WarpGeometry, kind="gauss", max_sigma=10.0, out="u8"):
     torch = _torch()
     feat = feat_u8.contiguous()
-    H, W, Cn = feat.shape
+    Hb, W, Cn = feat.shape
+    H = geo.in_hw[0]                                        # (a band of the frame from geo.src_y0 on: see WarpGeometry)
+    if W != geo.in_hw[1] or geo.src_y0 + Hb > H:
+        raise ValueError("the maps do not match the geometry's frame")
     nh = {"gauss": 3, "linear": 1}.get(kind, 0)
     o = torch.empty((geo.out_hw[0], geo.out_hw[1], Cn), dtype=_out_dtype(out), device=feat.device)
     pf = _planes_hwc(feat)

@@ -106,3 +106,24 @@ def test_tile_boxes_bound_every_owner(oracle):
         t = (np.minimum(r0 + 1, H - 1) // 64) * nt_x + np.minimum(c0 + 1, W - 1) // 64
         bb = b[t]
         assert ((ii >= bb[..., 0]) & (ii < bb[..., 1]) & (jj >= bb[..., 2]) & (jj < bb[..., 3])).all()
+
+
+@pytest.mark.parametrize("case", [("isc", M_ISC, (300, 420), (600, 840), 4), ("osc", M_OSC, (300, 420), (600, 840), 8), ("rot", M_ROT, (257, 391), (500, 700), 3)])
+def test_warp_row_partition_single_gpu(torch, case):
+    """dist.WarpRowPlan / warp_rows with the product kernels, every rank's launches in turn on one device: each rank sees only
+    its band of the input (lerf_warp_geo_t out_y0 / src_y0); the stitched rows and masks are the whole-frame warp's, byte for byte"""
+    import lerf_pytorch_amd as L
+    from lerf_pytorch_amd import dist as ldist
+    name, M, (H, W), out_hw, world = case
+    eng = L.LerfEngine.shipped("lerf-g")
+    rng = np.random.default_rng(world)
+    img = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda()
+    want, wmask = eng.warp(img, np.array(M), out_hw)
+    rows, masks = [], []
+    for r in range(world):
+        plan = ldist.WarpRowPlan(H, W, M, out_hw, world, r, 2)
+        o, m = ldist.warp_rows(eng, img[plan.b0:plan.b1].contiguous(), plan)
+        assert o.shape[0] == plan.i1 - plan.i0
+        rows.append(o)
+        masks.append(m)
+    assert torch.equal(torch.cat(rows, 0), want) and torch.equal(torch.cat(masks, 0), wmask)
