@@ -503,10 +503,11 @@ def parse():
                     help="seconds of back-to-back steps for the `sustained` leg (0 = skip; reported beside `value`, never replacing it)")
     ap.add_argument("--lib", default=None, help="diagnostic: load this build of liblerf_hip.so (A/B variants, tools/ab.sh); reported in the line")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (default run only)")
-    ap.add_argument("--mode", choices=["frames", "strips", "blocks"], default=None,
+    ap.add_argument("--mode", choices=["frames", "strips", "blocks", "rows"], default=None,
                     help="frames: independent frames per GPU (default; config 5: the batch is divided over the GPUs); "
-                         "strips: every frame is split into LR strips over the GPUs with an RCCL halo exchange "
-                         "(default for --config 5 with N > 1); blocks: a 2-D grid of blocks instead (8 GPUs: 2 x 4)")
+                         "blocks: every frame is split into a 2-D grid of blocks over the GPUs (8 GPUs: 2 x 4) with an RCCL halo "
+                         "exchange (default for --config 5 with N > 1); strips: LR strips instead; rows (config 4): every "
+                         "frame's OUTPUT rows over the GPUs, each rank warps from its band of the source (no exchange)")
     return ap.parse_args()
 
 
@@ -583,7 +584,11 @@ def main():
     strips = mode in ("strips", "blocks") and world > 1          # any partition of the FRAME over the ranks
     blocks = mode == "blocks" and world > 1
     if strips and cfg == 4:
-        raise SystemExit("strips / blocks are SR partitions; the warp path scales by frames")
+        raise SystemExit("strips / blocks are SR partitions; the warp path scales by frames, or by output rows (--mode rows)")
+    rows = mode == "rows" and world > 1 and cfg == 4             # every frame's OUTPUT rows divided over the ranks (dist.WarpRowPlan)
+    if mode == "rows" and cfg != 4:
+        raise SystemExit("--mode rows partitions the warp (config 4)")
+    strips = strips or rows                                      # (strong scaling: one batch, every rank works on every frame)
 
     eng = L.LerfEngine.shipped(model, support=S, max_sigma=10.0)
     B = args.frames
@@ -657,6 +662,20 @@ def main():
         return step, out, (oH, oW), frames
 
     def make_warp(matrix, out_hw):
+        nonlocal buf_px
+        if rows:
+            # no exchange: a rank is handed its band of every frame (the source rows its output rows read + the LUT stages' reach)
+            from lerf_pytorch_amd import dist as ldist
+            plan = ldist.WarpRowPlan(H, W, np.array(matrix), out_hw, world, rank, eng.support)
+            rgeo = plan.geometry()
+            band = torch.from_numpy(np.ascontiguousarray(host[:, plan.b0:plan.b1])).cuda()
+            outs = torch.empty((B_local, plan.i1 - plan.i0, out_hw[1], C), dtype=torch.uint8, device="cuda")
+            wsr = torch.empty(max(1, L._lib.lib().lerf_sr_fused_workspace_bytes(plan.b1 - plan.b0, W, C, B_local)), dtype=torch.uint8, device="cuda")
+            buf_px = (plan.b1 - plan.b0) * W
+
+            def step(x=band, o=outs):
+                ops.warp_packed(ops.stages_packed(x, eng.luts, workspace=wsr), rgeo, kind, ms, out=o)
+            return step, outs, out_hw, band
         geo = ops.WarpGeometry((H, W), np.array(matrix), out_hw, eng.support)
         frames = torch.from_numpy(host).cuda()
         outs = torch.empty((B_local, out_hw[0], out_hw[1], C), dtype=torch.uint8, device="cuda")
@@ -805,6 +824,8 @@ def main():
         from lerf_pytorch_amd import dist as ldist
         par = "2-D blocks of every frame over %d GPUs (%d x %d grid), RCCL halo exchange of %d raw uint8 rows / columns with up to 8 neighbours (one batch_isend_irecv), one pack and one unpack launch" % (
             (n_gpus,) + ldist.block_grid(n_gpus) + (3 + 3 + S // 2,))
+    elif rows:
+        par = "output rows of every frame over %d GPUs (dist.WarpRowPlan): each rank holds its band of the source rows (+ 6 rows of LUT reach), no data-path collective" % n_gpus
     elif strips:
         par = "LR strips of every frame over %d GPUs, RCCL halo exchange of %d raw uint8 rows per side (batch_isend_irecv)" % (n_gpus, 3 + 3 + S // 2)
     elif cfg == 5:
