@@ -1032,8 +1032,10 @@ def run_callsite(args):
            "speedup_inside_library_lazy_over_naive": round(in_naive / max(in_lazy, 1e-9), 1),
            "speedup_lazy_plus_one_line_over_naive": round(t_naive / t_dev, 1),
            "reference_numpy_same_frame_s": 692.0,
-           "note": "direct kernels (lut_interp_kernel x 24, resize_kernel float64), not the tile-fused path: each call is one LUT pass as the "
-                   "caller asked for it; reference numpy on the build container: 692 s for this frame size (SURVEY.md section 6)"}
+           "note": "the class-API kernels, not the tile-fused path: each FourSimplexInterpFaster call is one LUT pass as the caller asked for "
+                   "it (24 launches of the LDS-resident kernel lut_interp_lds_kernel, 22 of them accumulating into the caller's sum), one "
+                   "resampler launch (uint8 cell kernel when the results are deferred, float64 per-pixel kernel otherwise); reference numpy "
+                   "on the build container: 692 s for this frame size (SURVEY.md section 6)"}
     print(json.dumps(res))
 
 

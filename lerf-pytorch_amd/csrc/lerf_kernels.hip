@@ -307,8 +307,167 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
     Storer<TO>::put(out + i * oy + j * ox + c * oc, num / den);
 }
 
+// ---------------------------------------------------------------------------
+// The uint8 production form of the same resampler by SOURCE CELL (S = 2): the outputs whose first tap is (lr, lc) -- about
+// scale_h x scale_w of them -- share their four taps.  One thread per (cell, channel) loads and converts the taps once
+// (16 byte loads, the per-tap terms of the quadratic form) and walks its outputs: per output column the column-only terms
+// (ty^2, -2 rho ty: s3::gauss_form_cols), per output 4 x (tx, two FMAs, exp2) + the normalisation -- a quarter of the
+// per-pixel kernel's instructions at x2 (every thread of resize_kernel repeats the loads, the index arithmetic and the
+// conversions of its own four taps).  Same operations in the same order on every output: byte-identical results, same
+// float64 tie guard.  The cell's outputs are found in the geometry tables themselves (left_r / left_c are nondecreasing:
+// a guess from the scale factor, corrected by walking), so the C ABI and its tables stay as they are.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int first_at_least(const int* __restrict__ t, int n, int l, int guess) {
+    int i = min(max(guess, 0), n);
+    while (i > 0 && t[i - 1] >= l) --i;
+    while (i < n && t[i] < l) ++i;
+    return i;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+resize_cells_u8_kernel(const uint8_t* __restrict__ feat, int fy, int fx, int fc,
+                       const uint8_t* __restrict__ h0, const uint8_t* __restrict__ h1, const uint8_t* __restrict__ h2,
+                       int hy, int hx, int hc, int H, int W, int C, int oH, int oW,
+                       const int* __restrict__ left_r, const float* __restrict__ dis_r,
+                       const int* __restrict__ left_c, const float* __restrict__ dis_c,
+                       const double* __restrict__ dis_r64, const double* __restrict__ dis_c64,
+                       float max_sigma, uint8_t* __restrict__ out, int64_t oy, int64_t ox, int64_t oc, int pad_mode) {
+#pragma clang fp contract(off)
+    constexpr int S = 2;
+    constexpr bool GAUSS = KIND == LERF_KIND_GAUSS;
+    const int xq = blockIdx.x * 256 + threadIdx.x;
+    if (xq >= (W + S) * C) return;
+    const int qc = xq / C, c = xq - qc * C;
+    const int lr = (int)blockIdx.y - S, lc = qc - S;                  // the cell's first tap: -S .. H - 1, -S .. W - 1
+    const float ry = (float)oH / (float)H, rx = (float)oW / (float)W;
+    const int i0 = first_at_least(left_r, oH, lr, (int)((float)(lr + 1) * ry) - 1);
+    const int i1 = first_at_least(left_r, oH, lr + 1, i0 + (int)ry);
+    if (i0 >= i1) return;
+    const int j0 = first_at_least(left_c, oW, lc, (int)((float)(lc + 1) * rx) - 1);
+    const int j1 = first_at_least(left_c, oW, lc + 1, j0 + (int)rx);
+    if (j0 >= j1) return;
+    uint32_t dd[S * S];                                               // (k0, k1, k2, value) per tap: what the tie guard reads
+    float v[S * S];
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+#pragma unroll
+        for (int b = 0; b < S; ++b) {
+            const int rr = lr + b, cc = lc + a;
+            const int rcl = clampi(rr, 0, H - 1), ccl = clampi(cc, 0, W - 1);                          // hyper: edge pad (:172-174)
+            bool zr, zc;                                                                               // image pad rule (:208)
+            const int rs = pad_index(rr, H, pad_mode, &zr), cs = pad_index(cc, W, pad_mode, &zc);
+            const uint32_t val = (zr || zc) ? 0u : (uint32_t)feat[rs * fy + cs * fx + c * fc];
+            const int hh = rcl * hy + ccl * hx + c * hc;
+            dd[a * S + b] = (uint32_t)h0[hh] | ((GAUSS ? (uint32_t)h1[hh] : 0u) << 8) | ((GAUSS ? (uint32_t)h2[hh] : 0u) << 16) | (val << 24);
+            v[a * S + b] = (float)val;
+        }
+    }
+    uint8_t* const oc0 = out + (int64_t)c * oc;
+    auto put = [&](int i, int j, float xf) {
+        uint8_t r;
+        if (dis_r64 != nullptr && s3::near_tie(xf)) {
+            double dx64[S], dy64[S];
+#pragma unroll
+            for (int b = 0; b < S; ++b) dx64[b] = dis_r64[i * S + b];
+#pragma unroll
+            for (int a = 0; a < S; ++a) dy64[a] = dis_c64[j * S + a];
+            r = s3::to_u8_d(s3::eval64<GAUSS, S>(dd, dx64, dy64, max_sigma));
+        } else {
+            r = s3::to_u8(xf);
+        }
+        oc0[(int64_t)i * oy + (int64_t)j * ox] = r;
+    };
+    if (GAUSS) {
+        const float gs = s3::gauss_scale(max_sigma);
+        float m2rho[S * S], k1[S * S], k2[S * S];
+#pragma unroll
+        for (int t = 0; t < S * S; ++t) {
+            m2rho[t] = s3::gauss_m2rho_u8((float)(dd[t] & 0xFFu));
+            k1[t] = (float)((dd[t] >> 8) & 0xFFu);
+            k2[t] = (float)((dd[t] >> 16) & 0xFFu);
+        }
+        for (int j = j0; j < j1; ++j) {
+            float ty2[S * S], mty[S * S];
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float dys = dis_c[j * S + a] * gs;
+#pragma unroll
+                for (int b = 0; b < S; ++b) {
+                    const float ty = s3::gauss_t_u8(k2[a * S + b], dys);
+                    ty2[a * S + b] = ty * ty;
+                    mty[a * S + b] = m2rho[a * S + b] * ty;
+                }
+            }
+            for (int i = i0; i < i1; ++i) {
+                float e[S * S];
+#pragma unroll
+                for (int b = 0; b < S; ++b) {
+                    const float dxs = dis_r[i * S + b] * gs;
+#pragma unroll
+                    for (int a = 0; a < S; ++a)
+                        e[a * S + b] = s3::gauss_form_cols(s3::gauss_t_u8(k1[a * S + b], dxs), ty2[a * S + b], mty[a * S + b]);
+                }
+                put(i, j, s3::finish<true, S * S, true, true, true>(e, v));
+            }
+        }
+    } else {
+        const float ms255 = max_sigma * (1.0f / 255.0f);
+        float alpha[S * S];
+#pragma unroll
+        for (int t = 0; t < S * S; ++t) alpha[t] = s3::lin_alpha_u8((float)(dd[t] & 0xFFu), ms255);
+        for (int j = j0; j < j1; ++j) {
+            float fyv[S * S];
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float dy = dis_c[j * S + a];
+                const int cls = s3::dist_class_f(dy);
+#pragma unroll
+                for (int b = 0; b < S; ++b) fyv[a * S + b] = s3::lin_factor(alpha[a * S + b], dy, cls);
+            }
+            for (int i = i0; i < i1; ++i) {
+                float e[S * S];
+#pragma unroll
+                for (int b = 0; b < S; ++b) {
+                    const float dx = dis_r[i * S + b];
+                    const int cls = s3::dist_class_f(dx);
+#pragma unroll
+                    for (int a = 0; a < S; ++a) e[a * S + b] = s3::lin_factor(alpha[a * S + b], dx, cls) * fyv[a * S + b];
+                }
+                put(i, j, s3::finish<false, S * S, true, true, true>(e, v));
+            }
+        }
+    }
+}
+
+// the cell kernel takes the call when every operand is uint8, S = 2, the grid is an up-sampling one (the cells' outputs are
+// contiguous runs of the tables) and the planes can be addressed with 32-bit offsets
+template <int KIND>
+static bool resize_cells_u8(const ResizeArgs& a, hipStream_t st) {
+    if (a.S != 2 || a.oH < a.H || a.oW < a.W || !a.dis_r || !a.dis_c || !a.left_r || !a.left_c) return false;
+    auto fits = [](int64_t sy, int64_t sx, int64_t sc, int H, int W, int C) {
+        const int64_t m = (sy < 0 ? -sy : sy) * (H - 1) + (sx < 0 ? -sx : sx) * (W - 1) + (sc < 0 ? -sc : sc) * (C - 1);
+        return sy >= 0 && sx >= 0 && sc >= 0 && m < (1ll << 31) - 1;
+    };
+    if (!fits(a.fy, a.fx, a.fc, a.H, a.W, a.C) || !fits(a.hy, a.hx, a.hc, a.H, a.W, a.C)) return false;
+    const int64_t xq = (int64_t)(a.W + 2) * a.C;
+    if (xq > 0x7FFFFFFF || (int64_t)a.H + 2 > 65535) return false;
+    dim3 block(256), grid((unsigned)((xq + 255) / 256), (unsigned)(a.H + 2));
+    const bool guard = a.dis_r64 && a.dis_c64;
+    hipLaunchKernelGGL((resize_cells_u8_kernel<KIND>), grid, block, 0, st, (const uint8_t*)a.feat, (int)a.fy, (int)a.fx, (int)a.fc,
+                       (const uint8_t*)a.h[0], (const uint8_t*)a.h[1], (const uint8_t*)a.h[2], (int)a.hy, (int)a.hx, (int)a.hc,
+                       a.H, a.W, a.C, a.oH, a.oW, a.left_r, a.dis_r, a.left_c, a.dis_c, guard ? a.dis_r64 : nullptr,
+                       guard ? a.dis_c64 : nullptr, (float)a.max_sigma, (uint8_t*)a.out, a.oy, a.ox, a.oc, a.pad_mode);
+    return true;
+}
+
 template <typename TI, typename TH, typename TO, typename A, int KIND>
 static int resize_dispatch_S(const ResizeArgs& a, hipStream_t st) {
+#ifndef LERF_NO_RESIZE_CELLS                                          // A/B builds only (tools/build_li_variant.sh): never the product
+    if constexpr (sizeof(TI) == 1 && sizeof(TH) == 1 && sizeof(TO) == 1 && sizeof(A) == 4) {
+        if (resize_cells_u8<KIND>(a, st)) return LERF_OK;
+    }
+#endif
     dim3 block(256), grid((a.oW * a.C + 255) / 256, a.oH);
     const A* dr = sizeof(A) == 4 ? (const A*)a.dis_r : (const A*)a.dis_r64;
     const A* dc = sizeof(A) == 4 ? (const A*)a.dis_c : (const A*)a.dis_c64;

@@ -295,6 +295,32 @@ __device__ __forceinline__ void li_store2(TOUT* __restrict__ o, int lo, int hi, 
     }
 }
 
+// the accumulate form: the pair already in the plane is FETCHED at the top of the pass (li_load2) and added at its end
+// (li_store2_pre), so the read's HBM latency runs under the walk instead of in front of the store (a load issued next to the add
+// costs the pass its whole latency: the int16 `+=` passes of the call sites ran 54 / 26 us against 45 / 21 for plain stores)
+template <typename TOUT>
+__device__ __forceinline__ typename LiPair<TOUT>::type li_load2(const TOUT* __restrict__ o, bool both) {
+    typedef typename LiPair<TOUT>::type P;
+    P v = {(TOUT)0, (TOUT)0};
+    if (both) v = *reinterpret_cast<const P*>(o);                 // one exec-masked load, no join of two loads (that would wait)
+    return v;                                                     // the frame's last odd position is read where it is stored
+}
+template <typename TOUT>
+__device__ __forceinline__ void li_store2_pre(TOUT* __restrict__ o, int lo, int hi, bool both, typename LiPair<TOUT>::type pre) {
+    typedef typename LiPair<TOUT>::type P;
+    if (both) {
+        P v = {li_value<TOUT>(lo), li_value<TOUT>(hi)};
+        v += pre;
+#ifndef LERF_LI_PLAIN_STORE
+        __builtin_nontemporal_store(v, reinterpret_cast<P*>(o));
+#else
+        *reinterpret_cast<P*>(o) = v;
+#endif
+    } else {
+        *o = (TOUT)(li_value<TOUT>(lo) + *o);
+    }
+}
+
 // four pixels -> four bytes, rounded half-to-even and clipped like pixel_value<float>: v_rndne_f32 + v_cvt_pk_u8_f32 (the
 // saturating convert with byte insert) per pixel
 __device__ __forceinline__ uint32_t li_pack4(const li_v4f& v) {
@@ -612,6 +638,15 @@ lut_interp_lds_kernel(LiArgs A_) {
                 all = all && r < nrows && o[j] < ovalid;                   // wave-uniform
             }
             if (all) {
+                TOUT* op[LI_NR];
+                [[maybe_unused]] typename LiPair<TOUT>::type pre[LI_NR];
+#pragma unroll
+                for (int j = 0; j < LI_NR; ++j) op[j] = out_row(c[j], o0 + o[j]) + lane_out;
+                if constexpr (ACC) {
+#pragma unroll
+                    for (int j = 0; j < LI_NR; ++j) pre[j] = li_load2<TOUT>(op[j], ok1);
+                    __builtin_amdgcn_sched_barrier(0);                      // issued here, consumed after the walks
+                }
                 uint32_t px[LI_NR][2][4];
 #pragma unroll
                 for (int j = 0; j < LI_NR; ++j) {
@@ -649,7 +684,10 @@ lut_interp_lds_kernel(LiArgs A_) {
 #else
                     if (ok0)
 #endif
-                        li_store2<TOUT, ACC>(out_row(c[j], o0 + o[j]) + lane_out, rev && ok1 ? n1 : n0, rev ? n0 : n1, ok1);
+                    {
+                        if constexpr (ACC) li_store2_pre<TOUT>(op[j], rev && ok1 ? n1 : n0, rev ? n0 : n1, ok1, pre[j]);
+                        else li_store2<TOUT, false>(op[j], rev && ok1 ? n1 : n0, rev ? n0 : n1, ok1);
+                    }
                 }
             } else {
 #pragma unroll

@@ -44,6 +44,19 @@ def main():
                 dy, dx = _lib.mode_offsets(mode, 0)
                 out = torch.empty((3 * oC,) + ((h, w) if rot % 2 == 0 else (w, h)), dtype=torch.float64, device="cuda")
                 row = {"oC": oC, "mode": mode, "rot": rot}
+                if rot == 0 and mode == "s":
+                    # the practical floor of the call's stream on this chip: writing the output planes alone (a device fill)
+                    for _ in range(3):
+                        out.fill_(0.5)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(a.iters):
+                        out.fill_(0.5)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    row["fill_output_us"] = round(e0.elapsed_time(e1) * 1000.0 / a.iters, 2)
+                    row["fill_output_tb_s"] = round(out.numel() * 8 / (row["fill_output_us"] * 1e6), 2)
                 for kern in a.kernels.split(","):
                     for acc in ((False,) if a.no_acc else (False, True)):
                         if acc:

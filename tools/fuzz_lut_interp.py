@@ -13,12 +13,12 @@ from lerf_pytorch_amd import _lib, ops
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda")
-luts = {oC: torch.from_numpy(rng.integers(-128, 128, (17 ** 4, oC), dtype=np.int8)).to(dev) for oC in (1, 2, 3)}
+luts = {oC: torch.from_numpy(rng.integers(-128, 128, (17 ** 4, oC), dtype=np.int8)).to(dev) for oC in (1, 3)}    # the reference's oC
 planes = {oC: ops.lut_planes(l) for oC, l in luts.items()}
-bad = tot = 0
+bad = tot = declined = 0
 for i in range(n):
-    oC = int(rng.choice([1, 3, 3, 1, 2]))
-    Cn = int(rng.choice([1, 3, 3, 4]))
+    oC = int(rng.choice([1, 3]))
+    Cn = int(rng.choice([1, 3, 3, 4, 5]))                     # 5 channels: the LDS kernel declines, the library falls back
     big = rng.random() < 0.3
     h, w = (int(rng.integers(200, 700)), int(rng.integers(200, 900))) if big else (int(rng.integers(1, 140)), int(rng.integers(1, 300)))
     mode = "sctdy"[int(rng.integers(0, 5))]
@@ -50,6 +50,7 @@ for i in range(n):
     except _lib.LerfError as e:                                  # a forced LDS kernel may refuse a shape (tiny frames): say so, go on
         if kern is None:
             raise
+        declined += 1
         continue
     torch.cuda.synchronize()
     tot += want.numel() * want.element_size()
@@ -57,5 +58,5 @@ for i in range(n):
         bad += 1
         print("DIFF", dict(oC=oC, C=Cn, h=h, w=w, mode=mode, krot=krot, layout=layout, dt=str(dt), rot=rot, acc=acc, kern=kern, planar=pl is not None),
               int((want != got).sum()))
-print("fuzz_lut_interp: %d cases, %d bytes compared, %d mismatching cases" % (n, tot, bad))
+print("fuzz_lut_interp: %d cases (%d declined by a forced LDS kernel), %d bytes compared, %d mismatching cases" % (n, declined, tot, bad))
 sys.exit(1 if bad else 0)

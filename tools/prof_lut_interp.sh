@@ -10,6 +10,21 @@ f=$(find $out/stats -name "*kernel_stats.csv" | head -1)
 cp $f $out/kernel_stats.csv
 python3 - "$f" <<'PY'
 import csv,sys
+import re
+# roofline of the call the tool makes (a float32 HWC frame of 3 channels in, [3 oC, h, w] out): algorithmic bytes = frame in + values
+# out (+ the planes read when accumulating) over the kernel's average duration, against 8 TB/s
+hw = 1080 * 1920
+for a in sys.argv[2:]:
+    pass
 for r in csv.DictReader(open(sys.argv[1])):
-    if "lut_interp" in r["Name"]: print("%-110s calls %4s avg %9.1f us min %9.1f"%(r["Name"][:110],r["Calls"],float(r["AverageNs"])/1e3,float(r["MinNs"])/1e3))
+    if "lut_interp" not in r["Name"]: continue
+    us = float(r["AverageNs"]) / 1e3
+    m = re.search(r"lut_interp(?:_lds)?_kernel<(\d), (\w+(?: \w+)?), (\w+), (true|false)", r["Name"])
+    roof = ""
+    if m:
+        oC, tout, acc = int(m.group(1)), m.group(3), m.group(4) == "true"
+        eb = {"double": 8, "float": 4, "short": 2}.get(tout, 8)
+        b = hw * 3 * 4 + hw * 3 * oC * eb * (2 if acc else 1)
+        roof = "  %6.1f MB -> %5.2f TB/s = %4.1f %% of 8 TB/s" % (b / 1e6, b / us / 1e6, 100 * b / us / 1e6 / 8.0)
+    print("%-104s calls %4s avg %7.1f us min %7.1f%s" % (r["Name"][:104], r["Calls"], us, float(r["MinNs"]) / 1e3, roof))
 PY
