@@ -260,7 +260,10 @@ __device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
 // (resize_right2d_numpy.py:150-160, 168-170, 200-221) -- so the uint8 output equals the reference's
 // byte for byte unless the float32 error exceeds kTieEps = 1.5e-4 (the float32 path is typically within 5e-6, 9e-5 at worst in the tests).
 // ---------------------------------------------------------------------------
-constexpr float kTieEps = 1.5e-4f;
+#ifndef LERF_TIE_EPS                                                  // A/B builds only (experiments): the product uses the value below
+#define LERF_TIE_EPS 1.5e-4f
+#endif
+constexpr float kTieEps = LERF_TIE_EPS;
 
 __device__ __forceinline__ bool near_tie(float x) {
     return __builtin_fabsf(x - __builtin_rintf(x)) > 0.5f - kTieEps;
