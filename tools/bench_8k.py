@@ -143,3 +143,43 @@ print("8 frames per rank, interior + border parts (%d launches pairs): %.3f ms m
       "halo exchange hides in" % (len(ovl.parts), max(tov) * 1e3, max(tb2) * 1e3, max(tin) * 1e3))
 print("1 frame per rank, interior + border parts: %.3f ms max (one region-of-interest launch: %.3f ms); the interior alone %.3f ms"
       % (max(tov1) * 1e3, max(tb) * 1e3, max(tin1) * 1e3))
+
+# ---- round 6: the warp over 8 ranks (dist.WarpRowPlan): config 4 (1080p -> 4K, isc matrix, 8 frames sharing the homography), every
+#      rank computes an eighth of the OUTPUT rows from its band of the source; nothing is exchanged.  Emulated per rank on one GPU:
+#      band sizes, per-rank time (LUT stages on the band + the warp of its rows), stitched == the whole-frame warp
+del st2, x8, whole8
+torch.cuda.empty_cache()
+M = np.array([[2.05, 0.12, 15.0], [-0.08, 1.95, 40.0], [1.5e-5, -1.0e-5, 1.0]])      # bench.py's M_ISC
+Hs, Ws, ohw = 1080, 1920, (2160, 3840)
+fr = torch.from_numpy(rng.integers(0, 256, (8, Hs, Ws, 3), dtype=np.uint8)).cuda()
+geo_w = ops.WarpGeometry((Hs, Ws), M, ohw, eng.support)
+
+
+def whole_warp():
+    return ops.warp_packed(ops.stages_packed(fr, eng.luts), geo_w, eng.kind, eng.max_sigma, out="u8")
+
+
+ref_w = whole_warp()
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(5): whole_warp()
+torch.cuda.synchronize(); t_whole = (time.perf_counter() - t) / 5
+tw, bands = [], []
+st_w = torch.zeros_like(ref_w)
+for r in range(8):
+    wp = ldist.WarpRowPlan(Hs, Ws, M, ohw, 8, r, eng.support)
+    band = fr[:, wp.b0:wp.b1].contiguous()
+    gw = wp.geometry()
+
+    def run_w():
+        return ops.warp_packed(ops.stages_packed(band, eng.luts), gw, eng.kind, eng.max_sigma, out="u8")
+    o = run_w()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): run_w()
+    torch.cuda.synchronize(); tw.append((time.perf_counter() - t) / 5)
+    st_w[:, wp.i0:wp.i1] = o
+    bands.append(wp.b1 - wp.b0)
+print("warp 1080p -> 4K over 8 ranks by output rows: stitched == whole-frame warp:", bool(torch.equal(st_w, ref_w)))
+print("source bands (rows of 1080): %s; per-rank ms (8 frames): %s" % (" ".join(str(b) for b in bands), " ".join("%.3f" % (t * 1e3) for t in tw)))
+print("8 frames, one rank's output rows: %.3f ms max, %.3f ms mean vs 1/8 of the whole-frame batch %.3f ms -> strong-scaling efficiency of the "
+      "compute part %.0f %% (the bands overlap by the taps' and the LUT stages' reach: %.0f source rows are computed in all, %.2fx the frame)"
+      % (max(tw) * 1e3, np.mean(tw) * 1e3, t_whole / 8 * 1e3, 100 * t_whole / 8 / max(tw), sum(bands), sum(bands) / Hs))
