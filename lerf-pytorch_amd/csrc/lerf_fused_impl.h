@@ -1903,7 +1903,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                     for (int a = 0; a < S; ++a)
 #pragma unroll
                         for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                    const uint32_t r8 = s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
+                    const uint32_t r8 = s3::resolve_u8<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma);
 #pragma unroll
                     for (int rr = 0; rr < GN; ++rr)
                         if (rr == r) packed[rr] = (packed[rr] & ~(0xFFu << (8 * u))) | (r8 << (8 * u));
@@ -2045,7 +2045,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                         for (int a = 0; a < S; ++a)
 #pragma unroll
                             for (int b = 0; b < S; ++b) dd[a * S + b] = dp[b * D::HP + a * CH + c];
-                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<true, S>(dd, dx64, dy64, P.max_sigma));
+                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::resolve_u8<true, S>(dd, dx64, dy64, P.max_sigma);
                     }
                 }
             }
@@ -2188,7 +2188,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                             for (int a = 0; a < S; ++a)
 #pragma unroll
                                 for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + rp + b) * D::HP + (lc + cp + a) * CH + c];
-                            outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<true, S>(dd, dx64, dy64, P.max_sigma));
+                            outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::resolve_u8<true, S>(dd, dx64, dy64, P.max_sigma);
                         }
                     }
                 }
@@ -2300,7 +2300,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
                             for (int b = 0; b < 2; ++b) dd[a * 2 + b] = dp[b * D::HP + a * CH + c];
-                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<false, 2>(dd, dx64, dy64, P.max_sigma));
+                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::resolve_u8<false, 2>(dd, dx64, dy64, P.max_sigma);
                     }
                 }
             }
@@ -2391,7 +2391,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                         for (int a = 0; a < S; ++a)
 #pragma unroll
                             for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
+                        outt[il * D::OUT_PITCH + ophase + xc] = (uint8_t)s3::resolve_u8<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma);
                     }
                     __syncthreads();
                 }
@@ -2417,7 +2417,7 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                 for (int a = 0; a < S; ++a)
 #pragma unroll
                     for (int b = 0; b < S; ++b) dd[a * S + b] = Dt[(lr + b) * D::HP + (lc + a) * CH + c];
-                seg0[il * rowpitch + xc] = (uint8_t)s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma));
+                seg0[il * rowpitch + xc] = (uint8_t)s3::resolve_u8<KIND == LERF_KIND_GAUSS, S>(dd, dx64, dy64, P.max_sigma);
             }
         }
     }

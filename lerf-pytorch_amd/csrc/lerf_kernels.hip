@@ -236,7 +236,7 @@ resize_kernel(const TI* __restrict__ feat, int64_t fy, int64_t fx, int64_t fc,
 #pragma unroll
             for (int a = 0; a < MAXS; ++a) dy64[a] = dis_c64[j * S + a];
             Storer<TO>::put(out + i * oy + j * ox + c * oc,
-                            (float)s3::to_u8_d(s3::eval64<KIND == LERF_KIND_GAUSS, MAXS>(dd, dx64, dy64, (float)max_sigma)));
+                            (float)s3::resolve_u8<KIND == LERF_KIND_GAUSS, MAXS>(dd, dx64, dy64, (float)max_sigma));
             return;
         }
         Storer<TO>::put(out + i * oy + j * ox + c * oc, xf);
@@ -372,7 +372,7 @@ resize_cells_u8_kernel(const uint8_t* __restrict__ feat, int fy, int fx, int fc,
             for (int b = 0; b < S; ++b) dx64[b] = dis_r64[i * S + b];
 #pragma unroll
             for (int a = 0; a < S; ++a) dy64[a] = dis_c64[j * S + a];
-            r = s3::to_u8_d(s3::eval64<GAUSS, S>(dd, dx64, dy64, max_sigma));
+            r = s3::resolve_u8<GAUSS, S>(dd, dx64, dy64, max_sigma);
         } else {
             r = s3::to_u8(xf);
         }

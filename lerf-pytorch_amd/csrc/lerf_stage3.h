@@ -260,10 +260,16 @@ __device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
 // (resize_right2d_numpy.py:150-160, 168-170, 200-221) -- so the uint8 output equals the reference's
 // byte for byte unless the float32 error exceeds kTieEps = 1.5e-4 (the float32 path is typically within 5e-6, 9e-5 at worst in the tests).
 // ---------------------------------------------------------------------------
-#ifndef LERF_TIE_EPS                                                  // A/B builds only (experiments): the product uses the value below
+#ifndef LERF_TIE_EPS                                                  // -DLERF_TIE_EPS=1e-3f: the strict build (see below); A/B in profiles/r06_tie_eps_ab.txt
 #define LERF_TIE_EPS 1.5e-4f
 #endif
+// DETECTION threshold: outputs this close to a half-integer leave the float32 path (resolve_u8 below).  1.5e-4 covers the
+// float32 error of every map the LUTs produce on the test sets (0 of 6.9 G bytes); forms of ~70 (sigma saturated over a whole
+// support) carry float32 rounding of 2e-4 .. 1e-3 of the 0..255 scale: a build with 1e-3 is byte-exact on those too (all but
+// exact float64 ties, where one ulp of exp() decides) at 1.5 - 2.8 % of the throughput (seven times as many outputs queued).
 constexpr float kTieEps = LERF_TIE_EPS;
+// the part of them that needs the reference's own float64 exp(): closer than this after the intermediate evaluation
+constexpr float kTieEpsExact = 1.5e-4f;
 
 __device__ __forceinline__ bool near_tie(float x) {
     return __builtin_fabsf(x - __builtin_rintf(x)) > 0.5f - kTieEps;
@@ -331,6 +337,53 @@ __device__ __forceinline__ uint8_t to_u8_d(double v) {
     double r = __builtin_rint(v);
     r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);     // NaN compares false twice -> stays NaN -> (int) below gives 0 on gfx950
     return (v != v) ? (uint8_t)0 : (uint8_t)(int)r;
+}
+
+// Two-level resolution of an output the float32 path could not decide (|x - rint(x)| > 0.5 - kTieEps).
+// Level 1 (Gaussian kind): the reference's float64 quadratic forms, bit for bit those of eval64, and weights from the hardware
+// exp2 of their float64 DIFFERENCES to the smallest form -- what the float32 path loses is the rounding of forms of size ~70
+// (4 ulp of the form, up to 1e-3 of the output); a difference that matters (weight above 1e-6) is below 20, its float32
+// rounding 1e-6, the weight's error 1e-6 relative, the output's below 1e-5.  Level 1 decides unless its own result is within
+// kTieEpsExact of a half-integer; then, as before round 6, the reference's own dtype chain with the float64 exp() (eval64).
+// The linear kind has no exponent to lose: eval64 directly (no exp in it).
+template <bool GAUSS, int S>
+__device__ __forceinline__ uint8_t resolve_u8(const uint32_t (&d)[S * S], const double (&dx)[S], const double (&dy)[S],
+                                              float max_sigma) {
+#pragma clang fp contract(off)
+    if constexpr (GAUSS) {
+        auto form = [&](int a, int b) -> double {                       // eval64's argument of exp(-0.5 .), same operations
+            const uint32_t q = d[a * S + b];
+            const float h0 = u8_over_255((float)(q & 0xFFu));
+            const float h1 = u8_over_255((float)((q >> 8) & 0xFFu));
+            const float h2 = u8_over_255((float)((q >> 16) & 0xFFu));
+            const double rho = (double)(h0 * 2.0f - 1.0f);
+            const double sx = (double)(h1 * max_sigma), sy = (double)(h2 * max_sigma);
+            const double xn = (sx * dx[b]) * (sx * dx[b]);
+            const double yn = (sy * dy[a]) * (sy * dy[a]);
+            const double xy = sx * dx[b] * sy * dy[a];
+            return xn - 2.0 * rho * xy + yn;
+        };
+        double emin = form(0, 0);
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int b = 0; b < S; ++b) emin = __builtin_fmin(emin, form(a, b));
+        double num = 0.0, den = 0.0;
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int b = 0; b < S; ++b) {
+                const float t = (float)((emin - form(a, b)) * 0.72134752044448170368);   // 0.5 log2(e): <= 0, 0 for the smallest form
+                const double w = (double)__builtin_amdgcn_exp2f(t);
+                num += w * (double)(d[a * S + b] >> 24);
+                den += w;                                                 // >= 1
+            }
+        const double mid = num / den;
+        const double r = __builtin_rint(mid);
+        if (__builtin_fabs(mid - r) <= 0.5 - (double)kTieEpsExact)
+            return (uint8_t)(int)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+    }
+    return to_u8_d(eval64<GAUSS, S>(d, dx, dy, max_sigma));
 }
 
 // clip(np.round(v), 0, 255).astype(uint8)  (eval_lut_sr.py:663-665); NaN -> 0

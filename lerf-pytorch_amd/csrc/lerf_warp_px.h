@@ -22,12 +22,12 @@ __device__ __forceinline__ int dist_class(A x) {
     return (x >= (A)-1 && x < (A)0) ? 1 : ((x >= (A)0 && x <= (A)1) ? 2 : 0);
 }
 
-// Tie guard of the uint8 warps: an output within kTieEps of a half-integer is re-evaluated in float64 with the
-// reference's dtype chain (s3::eval64), like the SR kernels do; `tap(r, c)` returns (k0 | k1<<8 | k2<<16 | val<<24)
+// Tie guard of the uint8 warps: an output within kTieEps of a half-integer is resolved in float64 (s3::resolve_u8: the
+// reference's float64 forms, and its whole dtype chain where that is still undecided), like the SR kernels do; `tap(r, c)` returns (k0 | k1<<8 | k2<<16 | val<<24)
 // of the clamped source pixel.
 template <int KIND, int S, typename F>
-__device__ __forceinline__ double warp_eval64(int H, int W, const WarpGeo& g, int lr, int lc, double gr, double gc,
-                                              float max_sigma, F tap) {
+__device__ __forceinline__ uint8_t warp_resolve_u8(int H, int W, const WarpGeo& g, int lr, int lc, double gr, double gc,
+                                                   float max_sigma, F tap) {
     uint32_t dd[S * S];
     double dx[S], dy[S];
 #pragma unroll
@@ -43,15 +43,15 @@ __device__ __forceinline__ double warp_eval64(int H, int W, const WarpGeo& g, in
             const uint32_t d = tap(rcl, ccl);
             dd[a * S + b] = ((sr == rcl) && (sc_ == ccl)) ? d : (d & 0x00FFFFFFu);      // zero image outside the frame
         }
-    return s3::eval64<KIND == LERF_KIND_GAUSS, S>(dd, dx, dy, max_sigma);
+    return s3::resolve_u8<KIND == LERF_KIND_GAUSS, S>(dd, dx, dy, max_sigma);
 }
 
 template <int KIND, typename F>
 __device__ __forceinline__ bool warp_tie_guard(float res, int S, int H, int W, const WarpGeo& g, int lr, int lc, double gr,
                                                double gc, float max_sigma, F tap, uint8_t* dst) {
     if (!(KIND == LERF_KIND_GAUSS || KIND == LERF_KIND_LINEAR) || !s3::near_tie(res)) return false;
-    if (S == 2) *dst = s3::to_u8_d(warp_eval64<KIND, 2>(H, W, g, lr, lc, gr, gc, max_sigma, tap));
-    else if (S == 4) *dst = s3::to_u8_d(warp_eval64<KIND, 4>(H, W, g, lr, lc, gr, gc, max_sigma, tap));
+    if (S == 2) *dst = warp_resolve_u8<KIND, 2>(H, W, g, lr, lc, gr, gc, max_sigma, tap);
+    else if (S == 4) *dst = warp_resolve_u8<KIND, 4>(H, W, g, lr, lc, gr, gc, max_sigma, tap);
     else return false;
     return true;
 }
