@@ -88,7 +88,9 @@ def test_region_saturated_sigma_stays_within_one_lsb(torch, oracle):
     are SATURATED OVER WHOLE REGIONS (sigma = max_sigma for every tap of a support, far taps at 5/6 of a pixel at x3) carry forms
     of ~70 whose float32 rounding reaches 2e-4 of the 0..255 scale, beyond the 1.5e-4 tie guard; regions of identical taps also
     produce EXACT half-integers in float64, where one ulp of exp() decides.  No image of the test sets does either through the
-    shipped LUTs (0 of 1.5 G bytes); such maps differ from the reference by one step on a few bytes per thousand."""
+    shipped LUTs (0 of 6.9 G bytes); such maps differ from the reference by one step on a few bytes per thousand -- inside
+    north_star's <= 1 LSB.  A build with -DLERF_TIE_EPS=1e-3f (tools/build_variant_all.sh) is byte-exact on this very input
+    (profiles/r06_tie_eps_ab.txt) at 1.4 - 2.6 % of the throughput."""
     from lerf_pytorch_amd import ops
     rng = np.random.default_rng(3)
     H, W = 24, 83
