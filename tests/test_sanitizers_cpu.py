@@ -36,3 +36,11 @@ def test_oracle_c_golden_checks_under_asan_ubsan():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_oracle_c.py"), "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "golden or warp or md5"], env=env, capture_output=True, text=True, timeout=1500, cwd=REPO)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(os.environ.get("LERF_TEST_SPILLS") != "1", reason="1.5 minutes of hipcc: opt in with LERF_TEST_SPILLS=1")
+def test_no_kernel_spills_or_uses_scratch():
+    """tools/check_spills.sh: every kernel of the library compiles for gfx950 without scratch memory (round 6 found a stage-3
+    variant that had started to spill through its doubled WRITE_SIZE counter, not through its timing)"""
+    out = subprocess.run(["bash", os.path.join(REPO, "tools", "check_spills.sh")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "0 kernel(s) with scratch or spills" in out.stdout, out.stdout[-2000:]
