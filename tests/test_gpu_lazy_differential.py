@@ -124,9 +124,45 @@ def s_copy_semantics(interp, pads, luts, dev):
     return [c, a, x, np.array(x), np.asarray(x).dtype.str]
 
 
+def _stages(interp, pads, luts, dev, seed):
+    import callsite_driver as cd
+    img = dev(_img(seed))
+    s1 = cd.lut_ensemble(interp, pads, luts, img, 1, "sct", 1, 4, lambda r: "r0")
+    feat = np.round(np.clip(s1 / 3 + 0, 0, 255)).astype(np.float32).transpose((1, 2, 0))
+    s2 = cd.lut_ensemble(interp, pads, luts, feat, 2, "sct", 3, 4, lambda r: "r%d" % (r & 1))
+    hyper = np.round(np.clip(s2 / 12 + 127, 0, 255)).astype(np.float32) / 255.0
+    return feat.transpose((2, 0, 1)), hyper
+
+
+def s_resize_tails(interp, pads, luts, dev, resizer):
+    chw, hyper = _stages(interp, pads, luts, dev, 11)
+    resizer.set_shape(chw.shape, scale_factors=[2.0, 1.5])
+    n = hyper.shape[0]
+    args = (hyper[list(range(0, n, 3)), :, :], hyper[list(range(1, n + 1, 3)), :, :], hyper[list(range(2, n + 2, 3)), :, :])
+    a = np.clip(np.round(resizer.resize(chw, *args)).transpose((1, 2, 0)), 0, 255).astype(np.uint8)     # the worker's tail
+    b = np.clip(np.round(resizer.resize(chw, *args)), 0, 255).astype(np.uint8)                          # no transpose
+    c = resizer.resize(chw, *args)                                                                      # the float64 values
+    d = resizer.resize(chw, *args).astype(np.uint8)                                                     # truncation, not rounding
+    e = np.round(resizer.resize(chw, *args) * 0.5)                                                      # something else in between
+    return [a, b, c, d, e]
+
+
+def s_resize_after_operands_changed(interp, pads, luts, dev, resizer):
+    chw, hyper = _stages(interp, pads, luts, dev, 12)
+    resizer.set_shape(chw.shape, scale_factors=[2.0, 2.0])
+    n = hyper.shape[0]
+    out = resizer.resize(chw, hyper[0:n:3], hyper[1:n:3], hyper[2:n:3])          # maybe pending ...
+    hyper *= 0.5                                                                   # ... when its operands change (and lose their
+    chw += 1                                                                       #     exact uint8 form)
+    out2 = resizer.resize(chw, hyper[0:n:3], hyper[1:n:3], hyper[2:n:3])
+    t = lambda o: np.clip(np.round(o).transpose((1, 2, 0)), 0, 255).astype(np.uint8)
+    return [t(out), t(out2)]
+
+
 SCENARIOS = [s_used_twice, s_mutated_after_derivation, s_view_before_iadd, s_operand_overwritten_while_pending,
              s_sum_started_on_the_host, s_int_start_and_reversed_operands, s_stage_epilogue_variants,
              s_results_dropped_unread, s_three_channel_lut_and_slices, s_copy_semantics]
+RESIZE_SCENARIOS = [s_resize_tails, s_resize_after_operands_changed]
 
 
 @pytest.mark.parametrize("hw", [(41, 57), (260, 330)])
@@ -151,3 +187,24 @@ def test_lazy_results_equal_numpy_results(env, scenario, device_image, hw):
         gn, wn = np.asarray(g), np.asarray(w)
         assert gn.dtype == wn.dtype and gn.shape == wn.shape, (scenario.__name__, k, gn.dtype, wn.dtype, gn.shape, wn.shape)
         assert np.array_equal(gn, wn), (scenario.__name__, k, float(np.max(np.abs(gn.astype(np.float64) - wn.astype(np.float64)))))
+
+
+@pytest.mark.parametrize("device_image", [True, False])
+@pytest.mark.parametrize("scenario", RESIZE_SCENARIOS, ids=lambda f: f.__name__[2:])
+def test_lazy_resize_chains_equal_numpy_results(env, scenario, device_image):
+    from lerf_pytorch_amd import lazy
+    interp, pads, resizer, luts = env
+    HW[:] = (41, 57)
+    lazy.set_enabled(False)
+    try:
+        want = scenario(interp, pads, luts, lambda a: a, resizer)
+    finally:
+        lazy.set_enabled(True)
+    got = scenario(interp, pads, luts, (lambda a: lazy.asdevice(a)) if device_image else (lambda a: a), resizer)
+    for k, (g, w) in enumerate(zip(got, want)):
+        gn, wn = np.asarray(g), np.asarray(w)
+        assert gn.dtype == wn.dtype and gn.shape == wn.shape, (scenario.__name__, k, gn.dtype, wn.dtype, gn.shape, wn.shape)
+        if gn.dtype == np.float64:                               # float64 values of the resampler: the class contract is 1e-9
+            np.testing.assert_allclose(gn, wn, rtol=0, atol=1e-9, err_msg="%s %d" % (scenario.__name__, k))
+        else:
+            assert np.array_equal(gn, wn), (scenario.__name__, k, int((gn != wn).sum()))
