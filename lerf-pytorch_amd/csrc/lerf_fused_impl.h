@@ -1879,9 +1879,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                         if ((GS > 0 || (q >> 2) < gs) && __builtin_fabsf(dist[DIST ? q : 0]) > 0.5f - s3::kTieEps) tiemask |= 1u << q;
                 }
                 // rare: the output is re-evaluated in float64 exactly as the reference does (lerf_stage3.h, tie guard)
-#pragma unroll 1
-                for (int q = 0; q < GN * 4; ++q) {
-                    if (!((tiemask >> q) & 1u)) continue;
+                while (tiemask != 0) {                                     // one round per queued output of the lane, not per output
+                    const int q = __builtin_ctz(tiemask);
+                    tiemask &= tiemask - 1;
                     const int r = q >> 2, u = q & 3;
                     const int xc = min(max(b0 + u, 0), ncolc - 1);
                     // queued for the pass behind the task loop; only a full queue is worked off on the spot
@@ -2024,9 +2024,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 #pragma unroll
                     for (int q = 0; q < 4 * CH; ++q)
                         if (__builtin_fabsf(dist[q]) > 0.5f - s3::kTieEps) tiemask |= 1u << q;
-#pragma unroll 1
-                    for (int q = 0; q < 4 * CH; ++q) {
-                        if (!((tiemask >> q) & 1u)) continue;
+                    while (tiemask != 0) {                                 // one round per queued output of the lane, not per output
+                        const int q = __builtin_ctz(tiemask);
+                        tiemask &= tiemask - 1;
                         const int c = q >> 2, r = (q >> 1) & 1, qq = q & 1;
                         const int il = il0 + r, xc = (jl0 + qq) * CH + c;
                         const int slot = atomicAdd(tq_count, 1);
@@ -2163,12 +2163,13 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
                                     ob[(2 * rp + r) * D::OUT_PITCH + (2 * cp + q) * CH + c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(rr, 0u, 0u);
                                 }
                     if (dmax > 0.5f - s3::kTieEps && F.dis_r64 != nullptr) {
-#pragma unroll 1
-                        for (int k = 0; k < RP * CP * 4; ++k) {
-                            float dk = 0.0f;
+                        unsigned tiemask = 0;
 #pragma unroll
-                            for (int u = 0; u < RP * CP * 4; ++u) dk = (u == k) ? dist[u] : dk;       // (a register array: no dynamic index)
-                            if (!(__builtin_fabsf(dk) > 0.5f - s3::kTieEps)) continue;
+                        for (int u = 0; u < RP * CP * 4; ++u)
+                            if (__builtin_fabsf(dist[u]) > 0.5f - s3::kTieEps) tiemask |= 1u << u;
+                        while (tiemask != 0) {                             // one round per queued output of the lane, not per output
+                            const int k = __builtin_ctz(tiemask);
+                            tiemask &= tiemask - 1;
                             const int blkq = k >> 2, r = (k >> 1) & 1, q = k & 1;
                             const int rp = blkq / CP, cp = blkq - rp * CP;
                             const int il = il0 + 2 * rp + r, jl = jl0 + 2 * cp + q, xc = jl * CH + c;
@@ -2280,9 +2281,9 @@ sr_fused_kernel(Params P, std::conditional_t<GEN, RaggedTable, NoTable> T) {
 #pragma unroll
                     for (int q = 0; q < 4 * CH; ++q)
                         if (__builtin_fabsf(dist[q]) > 0.5f - s3::kTieEps) tiemask |= 1u << q;
-#pragma unroll 1
-                    for (int q = 0; q < 4 * CH; ++q) {
-                        if (!((tiemask >> q) & 1u)) continue;
+                    while (tiemask != 0) {                                 // one round per queued output of the lane, not per output
+                        const int q = __builtin_ctz(tiemask);
+                        tiemask &= tiemask - 1;
                         const int c = q >> 2, r = (q >> 1) & 1, qq = q & 1;
                         const int il = il0 + r, xc = (jl0 + qq) * CH + c;
                         const int slot = atomicAdd(tq_count, 1);
