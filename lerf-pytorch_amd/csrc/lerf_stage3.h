@@ -266,7 +266,8 @@ __device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
 // DETECTION threshold: outputs this close to a half-integer leave the float32 path (resolve_u8 below).  1.5e-4 covers the
 // float32 error of every map the LUTs produce on the test sets (0 of 6.9 G bytes); forms of ~70 (sigma saturated over a whole
 // support) carry float32 rounding of 2e-4 .. 1e-3 of the 0..255 scale: a build with 1e-3 is byte-exact on those too (all but
-// exact float64 ties, where one ulp of exp() decides) at 1.5 - 2.8 % of the throughput (seven times as many outputs queued).
+// exact float64 ties, where one ulp of exp() decides) at 0.7 % of the SR throughput, 2.7 % of the warp's (seven times as many
+// outputs detected).
 constexpr float kTieEps = LERF_TIE_EPS;
 // the part of them that needs the reference's own float64 exp(): closer than this after the intermediate evaluation
 constexpr float kTieEpsExact = 1.5e-4f;
