@@ -351,7 +351,9 @@ template <bool GAUSS, int S>
 __device__ __forceinline__ uint8_t resolve_u8(const uint32_t (&d)[S * S], const double (&dx)[S], const double (&dy)[S],
                                               float max_sigma) {
 #pragma clang fp contract(off)
-    if constexpr (GAUSS && S == 2) {                                    // (S = 4: sixteen forms twice over cost the kernels registers they do not have)
+    // (S = 4: sixteen forms twice over cost the kernels registers they do not have; detection at the exact threshold -- the shipped
+    //  build -- leaves level 1 nothing to decide: it would only delay the float64 chain)
+    if constexpr (GAUSS && S == 2 && (kTieEps > kTieEpsExact)) {
         auto form = [&](int a, int b) -> double {                       // eval64's argument of exp(-0.5 .), same operations
             const uint32_t q = d[a * S + b];
             const float h0 = u8_over_255((float)(q & 0xFFu));
